@@ -1,0 +1,198 @@
+"""Pins the CPU oracle (oracle/bobe_oracle.py) against independent implementations.
+
+The reference (BOBE/gp.py, BOBE/acquisition.py) cannot be imported here and its tests hold no
+numeric golden vectors, so the oracle is checked against scipy.linalg / scipy.stats /
+scipy.special, torch fp64 autograd, finite differences, closed forms, and the reference tests'
+own invariants (tests/test_gp.py, tests/test_acquisition.py data recipes).
+"""
+import math
+
+import numpy as np
+import pytest
+import scipy.stats as st
+from scipy.linalg import cho_factor, cho_solve
+
+from oracle import bobe_oracle as O
+
+
+def ref_test_data(n=50, d=2, seed=42):
+    # reference tests/test_gp.py:21-27
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(0, 1, size=(n, d))
+    y = -np.sum((X - 0.5) ** 2, axis=1).reshape(-1, 1)
+    return X, y
+
+
+def test_kernel_closed_forms():
+    rng = np.random.default_rng(0)
+    A, B = rng.uniform(size=(7, 3)), rng.uniform(size=(5, 3))
+    ls = np.array([0.3, 0.7, 1.1])
+    K = O.rbf_kernel(A, B, ls, 2.0, 1e-6, include_noise=False)
+    for i in range(7):
+        for j in range(5):
+            r2 = np.sum(((A[i] - B[j]) / ls) ** 2)
+            assert K[i, j] == pytest.approx(2.0 * math.exp(-0.5 * r2), rel=1e-14)
+    Km = O.matern_kernel(A, B, ls, 2.0, 1e-6, include_noise=False)
+    r = math.sqrt(np.sum(((A[2] - B[3]) / ls) ** 2))
+    assert Km[2, 3] == pytest.approx(2.0 * (1 + math.sqrt(5) * r + 5 / 3 * r * r) * math.exp(-math.sqrt(5) * r), rel=1e-14)
+    Kxx = O.rbf_kernel(A, A, ls, 2.0, 1e-3, include_noise=True)
+    assert np.allclose(np.diag(Kxx), 2.0 + 1e-3, rtol=0, atol=0)        # exact zero distance on the diagonal
+    Kmm = O.matern_kernel(A, A, ls, 2.0, 1e-3, include_noise=True)
+    assert np.allclose(np.diag(Kmm), 2.0 * (1 + 1e-15 * math.sqrt(5)) * math.exp(-math.sqrt(5) * 1e-15) + 1e-3, rtol=1e-14)
+
+
+def test_mll_against_scipy_and_closed_form():
+    X, y = ref_test_data(30, 3)
+    ys = (y - y.mean()) / y.std()
+    ls = np.array([0.5, 0.8, 1.2])
+    K = O.rbf_kernel(X, X, ls, 1.3, 1e-6)
+    c = cho_factor(K, lower=True)
+    alpha = cho_solve(c, ys)
+    want = -0.5 * float((ys.T @ alpha)[0, 0]) - np.sum(np.log(np.diag(c[0]))) - 0.5 * 30 * math.log(2 * math.pi)
+    assert O.gp_mll(K, ys, 30) == pytest.approx(want, rel=1e-13)
+    # multivariate normal log-pdf is the same number
+    assert O.gp_mll(K, ys, 30) == pytest.approx(st.multivariate_normal(np.zeros(30), K, allow_singular=True).logpdf(ys.ravel()), rel=1e-9)
+    # N=1 closed form
+    assert O.gp_mll(np.array([[2.0]]), np.array([[0.7]]), 1) == pytest.approx(
+        -0.5 * 0.49 / 2.0 - 0.5 * math.log(2.0) - 0.5 * math.log(2 * math.pi), rel=1e-14)
+    # not PD -> NaN, no exception
+    assert math.isnan(O.gp_mll(np.array([[1.0, 2.0], [2.0, 1.0]]), np.ones((2, 1)), 2))
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern"])
+def test_mll_gradient_vs_torch_autograd_and_fd(kernel):
+    import torch
+    rng = np.random.default_rng(3)
+    n, d = 60, 3
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X[:, 0]) + X[:, 1] ** 2 - X[:, 2]
+    y = (y - y.mean()) / y.std()
+    ls = np.array([0.4, 0.9, 0.6])
+    kvar, noise = 1.7, 1e-6
+    mll, g = O.mll_value_and_grad(kernel, X, y, ls, kvar, noise)
+
+    th = torch.tensor(np.log(np.append(ls, kvar)), dtype=torch.float64, requires_grad=True)
+    Xt, yt = torch.tensor(X), torch.tensor(y)
+    l_, kv = torch.exp(th[:d]), torch.exp(th[d])
+    Xs = Xt / l_
+    dsq = ((Xs[:, None, :] - Xs[None, :, :]) ** 2).sum(-1)
+    if kernel == "rbf":
+        K = kv * torch.exp(-0.5 * dsq)
+    else:
+        r = torch.sqrt(torch.where(dsq < 1e-30, torch.full_like(dsq, 1e-30), dsq))
+        K = kv * (1 + r * (math.sqrt(5) + r * 5 / 3)) * torch.exp(-math.sqrt(5) * r)
+    K = K + noise * torch.eye(n, dtype=torch.float64)
+    L = torch.linalg.cholesky(K)
+    a = torch.cholesky_solve(yt[:, None], L)
+    val = -0.5 * (yt[None, :] @ a)[0, 0] - torch.log(torch.diagonal(L)).sum() - 0.5 * n * math.log(2 * math.pi)
+    val.backward()
+    assert mll == pytest.approx(val.item(), rel=1e-12)
+    assert np.max(np.abs(g - th.grad.numpy())) <= 1e-8 * np.max(np.abs(g))
+    # central finite differences
+    for i in range(d + 1):
+        t = np.log(np.append(ls, kvar))
+        tp, tm = t.copy(), t.copy()
+        tp[i] += 1e-5
+        tm[i] -= 1e-5
+        fp = O.mll_value_and_grad(kernel, X, y, np.exp(tp[:d]), math.exp(tp[d]), noise)[0]
+        fm = O.mll_value_and_grad(kernel, X, y, np.exp(tm[:d]), math.exp(tm[d]), noise)[0]
+        assert g[i] == pytest.approx((fp - fm) / 2e-5, rel=2e-5, abs=1e-6)
+
+
+def test_priors_against_scipy_stats():
+    x = np.array([0.05, 0.7, 3.0])
+    assert np.allclose(O._logpdf_lognormal(x, 0.3, 1.7), st.lognorm(s=1.7, scale=math.exp(0.3)).logpdf(x), rtol=1e-13)
+    assert np.allclose(O._logpdf_halfcauchy(x, 0.1), st.halfcauchy(scale=0.1).logpdf(x), rtol=1e-13)
+    assert np.allclose(O._logpdf_uniform(x, 0.01, 5), st.uniform(0.01, 4.99).logpdf(x), rtol=1e-13)
+    assert np.allclose(O._logpdf_gamma(x, 2.0, 3.0), st.gamma(a=2.0, scale=1 / 3.0).logpdf(x), rtol=1e-13)
+    ls = np.array([0.2, 1.5])
+    want = (st.lognorm(s=1.0).logpdf(2.0) + st.halfcauchy(scale=0.1).logpdf(0.5)
+            + np.sum(st.halfcauchy(scale=1.0).logpdf(1.0 / (0.5 * ls ** 2))))
+    assert O.saas_prior_logprob(ls, 2.0, 0.5) == pytest.approx(want, rel=1e-13)
+    X, y = ref_test_data(20, 2)
+    gp = O.OracleGP(X, y, noise=1e-6, lengthscale_prior="DSLP")
+    want = np.sum(st.lognorm(s=math.sqrt(3), scale=math.exp(math.sqrt(2) + 0.5 * math.log(2))).logpdf(ls)) \
+        + st.uniform(1e-4, 1e8 - 1e-4).logpdf(2.0)
+    assert gp.prior_logprob(ls, 2.0, 1.0) == pytest.approx(want, rel=1e-13)
+
+
+@pytest.mark.parametrize("prior", [None, "DSLP", "SAAS"])
+def test_neg_mll_value_and_grad_with_priors_fd(prior):
+    X, y = ref_test_data(25, 2)
+    gp = O.OracleGP(X, y, noise=1e-6, lengthscale_prior=prior)
+    th = np.log(gp.get_hyperparams()) + 0.1
+    f, g = gp.neg_mll_value_and_grad(th)
+    assert f == pytest.approx(gp.neg_mll(th), rel=1e-12)
+    for i in range(len(th)):
+        tp, tm = th.copy(), th.copy()
+        tp[i] += 1e-5
+        tm[i] -= 1e-5
+        assert g[i] == pytest.approx((gp.neg_mll(tp) - gp.neg_mll(tm)) / 2e-5, rel=1e-4, abs=1e-6)
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern"])
+def test_fantasy_literal_equals_rank1(kernel):
+    rng = np.random.default_rng(5)
+    n, d, M, C = 60, 3, 17, 23
+    X = rng.uniform(size=(n, d))
+    y = np.cos(4 * X[:, 0]) + X[:, 1]
+    gp = O.OracleGP(X, y, noise=1e-6, kernel=kernel, lengthscales=[0.3, 0.5, 0.4], kernel_variance=1.2)
+    Z, cand = rng.uniform(size=(M, d)), rng.uniform(size=(C, d))
+    cand[0] = X[3]                                 # candidate on top of a training point -> s_c ~ noise
+    wv, ws = O.wip_sweep_literal(gp, cand, Z)
+    r = O.wip_sweep(gp, cand, Z)
+    assert np.max(np.abs(r["wipv"] - wv)) <= 1e-9 * gp.y_std ** 2
+    assert np.max(np.abs(r["wipstd"] - ws)) <= 1e-8 * gp.y_std
+    assert r["argmin_v"] == int(np.argmin(wv)) and r["argmin_s"] == int(np.argmin(ws))
+    m, v = gp.predict_batched(cand)
+    assert np.allclose(r["mean"], m, rtol=0, atol=1e-12) and np.allclose(r["var"], v, rtol=0, atol=1e-12)
+
+
+def test_reference_gp_invariants():
+    # reference tests/test_gp.py:129-139 — variance at a training point < 1e-3 (noise 1e-6, ls=1, kvar=1, N=25, d=2)
+    X, y = ref_test_data(25, 2)
+    gp = O.OracleGP(X, y, noise=1e-6)
+    assert gp.predict_var_single(X[0]) < 1e-3
+    assert gp.predict_var_single(np.array([0.5, 0.5])) > 0
+    # GP interpolation mu(X) ~ y
+    assert np.allclose(gp.predict_mean_batched(X), y.ravel(), atol=5e-3)
+    # update adds two points and rejects a duplicate (tests/test_gp.py:165-169)
+    n0 = gp.npoints
+    gp.update(np.array([[0.11, 0.93], [0.87, 0.07]]), np.array([[-0.3], [-0.2]]))
+    assert gp.npoints == n0 + 2
+    gp.update(X[:1], y[:1])
+    assert gp.npoints == n0 + 2
+    # RBF vs Matern differ by > 1 % at (0.5, 0.5) (tests/test_gp.py:295)
+    g1 = O.OracleGP(X, y, noise=1e-6, kernel="rbf", lengthscales=[0.2, 0.2])
+    g2 = O.OracleGP(X, y, noise=1e-6, kernel="matern", lengthscales=[0.2, 0.2])
+    m1, m2 = g1.predict_mean_single([0.5, 0.5]), g2.predict_mean_single([0.5, 0.5])
+    assert m1 != m2
+
+
+def test_fit_improves_mll_and_matches_restart_recipe():
+    X, y = ref_test_data(40, 2)
+    gp = O.OracleGP(X, y, noise=1e-6)
+    rng = np.random.default_rng(7)
+    x0 = O.restart_points(np.log(gp.get_hyperparams()), gp.hyperparam_bounds, 3, rng)
+    assert x0.shape == (3, 3) and np.allclose(x0[0], 0.0)
+    assert np.all(x0[1:] >= gp.hyperparam_bounds[0]) and np.all(x0[1:] <= gp.hyperparam_bounds[1])
+    before = -gp.neg_mll(x0[0])
+    res = gp.fit(x0=x0, maxiter=100)
+    assert res["mll"] >= before
+    gp.update_hyperparams(res["params"])
+    assert np.all(np.isfinite(gp.cholesky))
+
+
+def test_ei_logei():
+    u = np.array([-50.0, -5.0, -1.0, -0.5, 0.0, 0.7, 3.0])
+    direct = st.norm.pdf(u) + u * st.norm.cdf(u)
+    assert np.allclose(O.ei_helper(u), direct, rtol=1e-12, atol=0)
+    le = O.log_ei_helper(u)
+    good = u > -30
+    assert np.allclose(le[good], np.log(direct[good]), rtol=1e-9, atol=1e-9)
+    # deep tail: asymptotic log EI ~ log phi(u) - 2 log|u|
+    assert le[0] == pytest.approx(st.norm.logpdf(-50.0) - 2 * math.log(50.0), rel=1e-3)
+    assert np.all(np.isfinite(O.log_ei_helper(np.array([-1e7, -1e6, -999999.0]))))
+    assert np.all(O.ei_score(np.array([0.1, -2.0]), np.array([0.5, 1e-30]), 0.3) >= 0)     # tests/test_acquisition.py:92-95
+    x = np.array([1e-3, 0.5, 0.7, 5.0])
+    assert np.allclose(O.log1mexp(x), np.log(1 - np.exp(-x)), rtol=1e-12)
