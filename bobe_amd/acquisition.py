@@ -1,0 +1,178 @@
+"""Acquisition functions on top of the GPU GP — counterpart of BOBE/acquisition.py.
+
+WIPV / WIPStd evaluate every candidate in ONE call of ``bobe_gp_wip_sweep`` (the reference maps
+``fun`` over the candidates sequentially with ``lax.map``, acquisition.py:390-394).  EI / LogEI are
+pointwise scorers on the batched posterior (``bobe_gp_acq_ei``).
+
+Deviation from the reference, stated once: where the reference differentiates ``fun`` with JAX
+(local L-BFGS-B refinement for N <= 500, acquisition.py:403-412; EI restarts, acquisition.py:281-290)
+this module uses batched forward differences evaluated on the GPU (d+1 points per gradient in one
+call), because a C-ABI GP is opaque to autodiff.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+from scipy.stats import qmc
+
+from .gp import GP
+from .optim import optimize_scipy
+from .utils import get_logger, get_numpy_rng
+
+log = get_logger("acq")
+
+_FD_STEP = 1e-6
+
+
+class AcquisitionFunction:
+    """BOBE/acquisition.py:79-196."""
+
+    name: str = "BaseAcquisitionFunction"
+
+    def __init__(self, optimizer: str = "scipy", optimizer_options: Optional[Dict[str, Any]] = None):
+        self.optimizer = optimizer
+        self.optimizer_options = optimizer_options if optimizer_options is not None else {}
+        self.acq_optimize = optimize_scipy
+
+    def fun(self, x, *args, **kwargs):
+        raise NotImplementedError
+
+    def get_next_point(self, gp: GP, acq_kwargs=None, maxiter=500, n_restarts=8, verbose=True,
+                       early_stop_patience=25, rng=None):
+        raise NotImplementedError("Base class get_next() not implemented")
+
+    def get_next_batch(self, gp: GP, n_batch: int = 1, acq_kwargs=None, maxiter: int = 500, n_restarts: int = 8,
+                       verbose: bool = True, early_stop_patience: int = 25, rng=None):
+        """Kriging-believer batch (BOBE/acquisition.py:147-196)."""
+        rng = rng if rng is not None else get_numpy_rng()
+        acq_kwargs = acq_kwargs if acq_kwargs is not None else {}
+        x_batch, acq_vals = [], []
+        x_next, val = self.get_next_point(gp, acq_kwargs=acq_kwargs, maxiter=maxiter, n_restarts=n_restarts,
+                                          verbose=verbose, early_stop_patience=early_stop_patience, rng=rng)
+        x_batch.append(np.asarray(x_next))
+        acq_vals.append(val)
+        if n_batch > 1:
+            dummy_gp = GP(train_x=gp.train_x, train_y=gp.train_y * gp.y_std + gp.y_mean, noise=gp.noise,
+                          kernel=gp.kernel_name, lengthscales=gp.lengthscales, kernel_variance=gp.kernel_variance,
+                          device=gp.device)                                    # acquisition.py:175-180
+            dummy_gp.update(x_next, dummy_gp.predict_mean_single(x_next))
+            for _ in range(1, n_batch):
+                x_next, val = self.get_next_point(dummy_gp, acq_kwargs=acq_kwargs, maxiter=maxiter,
+                                                  n_restarts=n_restarts, verbose=verbose,
+                                                  early_stop_patience=early_stop_patience, rng=rng)
+                x_batch.append(np.asarray(x_next))
+                acq_vals.append(val)
+                dummy_gp.update(x_next, dummy_gp.predict_mean_single(x_next))
+        return np.array(x_batch), np.array(acq_vals)
+
+
+class EI(AcquisitionFunction):
+    """BOBE/acquisition.py:199-291."""
+
+    name: str = "EI"
+    _log = False
+
+    def fun(self, x, gp, best_y, zeta):
+        """-EI(x) (acquisition.py:226-253); x may be (d,) or (C, d)."""
+        val = -gp.acq_ei(np.atleast_2d(x), best_y, zeta, log_ei=self._log)
+        return val[0] if np.ndim(x) == 1 else val
+
+    def _value_and_grad(self, gp, best_y, zeta):
+        def vg(x):
+            x = np.asarray(x, dtype=np.float64)
+            pts = np.vstack([x] + [x + _FD_STEP * e for e in np.eye(len(x))])
+            v = self.fun(pts, gp, best_y, zeta)
+            return float(v[0]), (v[1:] - v[0]) / _FD_STEP
+        return vg
+
+    def get_next_point(self, gp, acq_kwargs=None, maxiter: int = 250, n_restarts: int = 20, verbose: bool = True,
+                       early_stop_patience: int = 25, rng=None):
+        rng = rng if rng is not None else get_numpy_rng()
+        acq_kwargs = acq_kwargs if acq_kwargs is not None else {}
+        zeta = acq_kwargs.get("zeta", 0.0)
+        best_y = acq_kwargs.get("best_y", float(np.max(gp.train_y)))
+        best_x = gp.train_x[int(np.argmax(gp.train_y))]
+        if n_restarts > 1:                                                     # acquisition.py:271-278
+            n_random = int(n_restarts / 2)
+            x0 = np.vstack([gp.get_random_point(rng, nstd=5) for _ in range(n_random)])
+            x0 = np.vstack([x0, np.full((n_restarts - n_random, gp.ndim), best_x)])
+        else:
+            x0 = np.atleast_2d(best_x)
+        x0 = np.clip(x0 + rng.normal(0.0, 0.005, size=x0.shape), 0.0, 1.0)
+        pts, vals = self.acq_optimize(self._value_and_grad(gp, best_y, zeta), num_params=gp.ndim, x0=x0,
+                                      bounds=[0, 1], optimizer_options=dict(self.optimizer_options),
+                                      maxiter=maxiter, n_restarts=n_restarts, verbose=verbose)
+        return pts, -vals
+
+
+class LogEI(EI):
+    """BOBE/acquisition.py:293-330."""
+
+    name: str = "LogEI"
+    _log = True
+
+
+class WeightedIntegratedPosteriorBase(AcquisitionFunction):
+    """BOBE/acquisition.py:333-412."""
+
+    _key = "wipv"
+
+    def fun(self, x, gp, mc_points=None, k_train_mc=None):
+        r = gp.wip_sweep(np.atleast_2d(x), mc_points)
+        return r[self._key][0] if np.ndim(x) == 1 else r[self._key]
+
+    def sweep(self, gp, candidates, mc_points):
+        """Scores of all candidates and the argmin (acquisition.py:394-398)."""
+        r = gp.wip_sweep(candidates, mc_points)
+        idx = r["argmin_v"] if self._key == "wipv" else r["argmin_s"]
+        return r[self._key], idx
+
+    def get_next_point(self, gp, acq_kwargs=None, maxiter: int = 100, n_restarts: int = 1, verbose: bool = True,
+                       early_stop_patience: int = 25, rng=None):
+        acq_kwargs = acq_kwargs if acq_kwargs is not None else {}
+        mc_samples = acq_kwargs.get("mc_samples")
+        mc_points_size = acq_kwargs.get("mc_points_size", 128)
+        mc_points = get_mc_points(mc_samples, mc_points_size=mc_points_size, rng=rng)
+        vals, idx = self.sweep(gp, mc_points, mc_points)                      # candidates == integration points
+        best_x, best_val = np.array(mc_points[idx]), float(vals[idx])
+        if gp.train_x.shape[0] > 500:                                          # acquisition.py:400-401
+            return best_x, best_val
+
+        def vg(x):
+            x = np.asarray(x, dtype=np.float64)
+            pts = np.vstack([x] + [x + _FD_STEP * e for e in np.eye(len(x))])
+            v = self.fun(pts, gp, mc_points=mc_points)
+            return float(v[0]), (v[1:] - v[0]) / _FD_STEP
+        return self.acq_optimize(vg, num_params=gp.ndim, x0=best_x, bounds=[0, 1],
+                                 optimizer_options=dict(self.optimizer_options), maxiter=maxiter,
+                                 n_restarts=n_restarts, verbose=verbose)
+
+
+class WIPV(WeightedIntegratedPosteriorBase):
+    """BOBE/acquisition.py:415-440."""
+    name: str = "WIPV"
+    _key = "wipv"
+
+
+class WIPStd(WeightedIntegratedPosteriorBase):
+    """BOBE/acquisition.py:443-465."""
+    name: str = "WIPStd"
+    _key = "wipstd"
+
+
+def get_mc_samples(gp: GP, warmup_steps=512, num_samples=1024, thinning=4, method="uniform", num_chains=4,
+                   np_rng=None, rng_key=None):
+    """BOBE/acquisition.py:468-482.  Only the 'uniform' (scrambled Sobol) method lives on the hot path;
+    NUTS / nested sampling are sampler consumers ('next')."""
+    if method == "uniform":
+        return {"x": qmc.Sobol(gp.ndim, scramble=True, seed=np_rng).random(num_samples)}
+    raise NotImplementedError(f"mc-sample method {method!r} is outside the GPU hot path (see DESIGN.md)")
+
+
+def get_mc_points(mc_samples, mc_points_size=128, rng=None):
+    """BOBE/acquisition.py:485-489."""
+    mc_size = max(mc_samples["x"].shape[0], mc_points_size)
+    rng = rng if rng is not None else get_numpy_rng()
+    idxs = rng.choice(mc_size, size=mc_points_size, replace=False)
+    return mc_samples["x"][idxs]

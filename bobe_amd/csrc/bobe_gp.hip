@@ -1,0 +1,908 @@
+// libbobe_gp.so — C ABI (include/bobe_gp.h) over the gfx950 kernels in kernels.hpp.
+// Host side: buffer management, launch sequencing, host/device pointer handling.  No CPU
+// compute path exists here: without a HIP device every entry point fails with BOBE_ERR_HIP.
+#include "../../include/bobe_gp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace bobe;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Err : std::runtime_error {
+  int code;
+  Err(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      throw Err(BOBE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                  std::to_string(__LINE__) + ")");                                     \
+  } while (0)
+
+#define LAUNCH_CHECK() HIPCHK(hipGetLastError())
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+struct DBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  void ensure(size_t b) {
+    if (b <= bytes) return;
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr;
+    bytes = 0;
+    HIPCHK(hipMalloc(&p, b));
+    bytes = b;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  double* d() const { return static_cast<double*>(p); }
+};
+
+template <typename K>
+void allow_big_lds(K kernel, int bytes) {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(256) void k_debug_gemm(const double* __restrict__ A, int64_t lda,
+                                                    const double* __restrict__ B, int64_t ldb, double* __restrict__ C,
+                                                    int64_t ldc, int64_t K) {
+  extern __shared__ double smem[];
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<LA, LB>(acc, A, lda, (int64_t)blockIdx.y * TILE, B, ldb, (int64_t)blockIdx.x * TILE, 0, K, smem);
+  store_tile(acc, C, ldc, (int64_t)blockIdx.y * TILE, (int64_t)blockIdx.x * TILE, 1.0, 0.0);
+}
+
+void configure_kernels_once() {
+  static bool done[64] = {false};
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || done[dev]) return;
+  allow_big_lds(k_potf2_inv<true>, POTF2_SMEM_BYTES);
+  allow_big_lds(k_potf2_inv<false>, POTF2_SMEM_BYTES);
+  allow_big_lds(k_trsm_panel, GEMM_SMEM_BYTES);
+  allow_big_lds(k_syrk_trail, GEMM_SMEM_BYTES);
+  allow_big_lds(k_trtri_T, GEMM_SMEM_BYTES);
+  allow_big_lds(k_trtri_R, GEMM_SMEM_BYTES);
+  allow_big_lds(k_trimul, GEMM_SMEM_BYTES);
+  allow_big_lds(k_trimul_t, GEMM_SMEM_BYTES);
+  allow_big_lds(k_cross_score<0>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_cross_score<1>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 8>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 16>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 32>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 8>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 16>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 32>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_kernel_matrix<0, true>, 2 * MAX_D * TILE * 8);
+  allow_big_lds(k_kernel_matrix<0, false>, 2 * MAX_D * TILE * 8);
+  allow_big_lds(k_kernel_matrix<1, true>, 2 * MAX_D * TILE * 8);
+  allow_big_lds(k_kernel_matrix<1, false>, 2 * MAX_D * TILE * 8);
+  allow_big_lds(k_debug_gemm<0, 0>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_debug_gemm<0, 1>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_debug_gemm<1, 0>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_debug_gemm<1, 1>, GEMM_SMEM_BYTES);
+  done[dev] = true;
+}
+
+struct Depth { int first, count, nblocks; };
+
+}  // namespace
+
+struct bobe_gp {
+  int device = 0;
+  int kern = 0;
+  int d = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int64_t N = 0, Np = 0;
+  int nb = 0;
+  Hyper hyp;
+  bool have_data = false, factored = false;
+  int64_t chunk = 2048;
+
+  DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs;
+  // sweep / predict workspace
+  DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
+      o_misc, kin_a, kin_b, kout;
+  std::vector<Depth> depths;
+  double* h_res = nullptr;  // pinned, 128 doubles
+
+  void use() {
+    HIPCHK(hipSetDevice(device));
+    configure_kernels_once();
+  }
+  void sync() { HIPCHK(hipStreamSynchronize(stream)); }
+
+  // host or device input -> device pointer (staged through `stage` when it is host memory)
+  const double* fetch(const double* p, size_t n, DBuf& stage) {
+    if (is_device_ptr(p)) return p;
+    stage.ensure(n * sizeof(double));
+    HIPCHK(hipMemcpyAsync(stage.p, p, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    return stage.d();
+  }
+  // output: device pointer to write to (user's when it is device memory, else `stage`)
+  double* out_dev(double* user, size_t n, DBuf& stage) {
+    if (!user) return nullptr;
+    if (is_device_ptr(user)) return user;
+    stage.ensure(n * sizeof(double));
+    return stage.d();
+  }
+  void out_finish(double* user, size_t n, DBuf& stage) {
+    if (!user || is_device_ptr(user)) return;
+    HIPCHK(hipMemcpyAsync(user, stage.p, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  }
+
+  void build_probs();
+  void alloc_for_n();
+  void scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo);
+  void kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT, int64_t ldb,
+                           int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo);
+  void assemble_kxx(const Hyper& h, const double* xst, double* a);
+  void potrf(double* a, double* linv);
+  void trtri(const double* a, double* linv);
+  void solve_alpha(const double* linv, double* wv, double* al);
+  void factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al);
+  int read_info();
+  void prepare_z(const double* Z, int64_t M, int64_t Mp);
+  void sweep(const double* cand, int64_t C, const double* Z, int64_t M, double y_std, double* wipv, double* wipstd,
+             double* mean, double* var, int policy, int64_t* argmin_v, double* min_v, int64_t* argmin_s, double* min_s,
+             double* fantasy_out);
+};
+
+void bobe_gp::build_probs() {
+  struct Item { int depth, lo, mid, hi; };
+  std::vector<Item> items;
+  struct Rec {
+    static void go(std::vector<Item>& it, int depth, int lo, int hi) {
+      if (hi - lo <= 1) return;
+      const int mid = lo + (hi - lo) / 2;
+      it.push_back({depth, lo, mid, hi});
+      go(it, depth + 1, lo, mid);
+      go(it, depth + 1, mid, hi);
+    }
+  };
+  Rec::go(items, 0, 0, nb);
+  int maxd = -1;
+  for (auto& i : items) maxd = i.depth > maxd ? i.depth : maxd;
+  std::vector<TriProb> flat;
+  depths.clear();
+  for (int dd = 0; dd <= maxd; ++dd) {
+    Depth D{(int)flat.size(), 0, 0};
+    for (auto& i : items)
+      if (i.depth == dd) {
+        flat.push_back({i.lo, i.mid, i.hi, D.nblocks});
+        D.nblocks += (i.hi - i.mid) * (i.mid - i.lo);
+        D.count++;
+      }
+    depths.push_back(D);
+  }
+  if (!flat.empty()) {
+    probs.ensure(flat.size() * sizeof(TriProb));
+    HIPCHK(hipMemcpy(probs.p, flat.data(), flat.size() * sizeof(TriProb), hipMemcpyHostToDevice));
+  }
+}
+
+void bobe_gp::alloc_for_n() {
+  const size_t mat = (size_t)Np * Np * sizeof(double);
+  const size_t vec = (size_t)Np * sizeof(double);
+  A.ensure(mat);
+  Linv.ensure(mat);
+  A2.ensure(mat);
+  Linv2.ensure(mat);
+  Tmp.ensure(mat);
+  y.ensure(vec);
+  alpha.ensure(vec);
+  w.ensure(vec);
+  alpha2.ensure(vec);
+  w2.ensure(vec);
+  XsT.ensure((size_t)d * vec);
+  XsT2.ensure((size_t)d * vec);
+  const int64_t pw = Np > chunk ? Np : chunk;
+  part.ensure((size_t)nb * pw * sizeof(double));
+  gpart.ensure((size_t)nb * (nb + 1) / 2 * (MAX_D + 1) * sizeof(double));
+  res.ensure(128 * sizeof(double));
+  info.ensure(sizeof(int));
+  build_probs();
+}
+
+void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo) {
+  hipLaunchKernelGGL(k_scale_coords, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, stream, in, n, npad, h, out, ldo);
+  LAUNCH_CHECK();
+}
+
+void bobe_gp::kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT,
+                                  int64_t ldb, int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo) {
+  const dim3 grid((unsigned)(nbpad / TILE), (unsigned)(napad / TILE));
+  const size_t sm = (size_t)2 * h.d * TILE * sizeof(double);
+  if (h.kern == 0)
+    hipLaunchKernelGGL((k_kernel_matrix<0, false>), grid, dim3(256), sm, stream, AT, lda, na, BT, ldb, nbv, h, out, ldo);
+  else
+    hipLaunchKernelGGL((k_kernel_matrix<1, false>), grid, dim3(256), sm, stream, AT, lda, na, BT, ldb, nbv, h, out, ldo);
+  LAUNCH_CHECK();
+}
+
+void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a) {
+  const dim3 grid((unsigned)(nb * (nb + 1) / 2));
+  const size_t sm = (size_t)2 * h.d * TILE * sizeof(double);
+  if (h.kern == 0)
+    hipLaunchKernelGGL((k_kernel_matrix<0, true>), grid, dim3(256), sm, stream, xst, Np, N, xst, Np, N, h, a, Np);
+  else
+    hipLaunchKernelGGL((k_kernel_matrix<1, true>), grid, dim3(256), sm, stream, xst, Np, N, xst, Np, N, h, a, Np);
+  LAUNCH_CHECK();
+}
+
+void bobe_gp::potrf(double* a, double* linv) {
+  for (int k = 0; k < nb; ++k) {
+    hipLaunchKernelGGL(k_potf2_inv<true>, dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
+                       static_cast<int*>(info.p));
+    const int rem = nb - k - 1;
+    if (rem > 0) {
+      hipLaunchKernelGGL(k_trsm_panel, dim3(rem), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np, k);
+      hipLaunchKernelGGL(k_syrk_trail, dim3(rem * (rem + 1) / 2), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, k);
+    }
+  }
+  LAUNCH_CHECK();
+}
+
+void bobe_gp::trtri(const double* a, double* linv) {
+  for (int dd = (int)depths.size() - 1; dd >= 0; --dd) {
+    const Depth& D = depths[dd];
+    const TriProb* pr = static_cast<const TriProb*>(probs.p) + D.first;
+    hipLaunchKernelGGL(k_trtri_T, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np,
+                       Tmp.d(), Np, pr, D.count);
+    hipLaunchKernelGGL(k_trtri_R, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, linv, Np, (const double*)Tmp.d(),
+                       Np, pr, D.count);
+  }
+  LAUNCH_CHECK();
+}
+
+void bobe_gp::solve_alpha(const double* linv, double* wv, double* al) {
+  hipLaunchKernelGGL(k_gemv_lower, dim3((unsigned)(Np / 4)), dim3(256), 0, stream, linv, Np, Np, (const double*)y.d(), wv);
+  hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(Np / 64), (unsigned)nb), dim3(256), 0, stream, linv, Np, 1,
+                     (const double*)wv, part.d(), Np);
+  hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, stream, (const double*)part.d(),
+                     Np, nb, 1, Np, al);
+  LAUNCH_CHECK();
+}
+
+void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al) {
+  scale(X.d(), N, Np, h, xst, Np);
+  assemble_kxx(h, xst, a);
+  HIPCHK(hipMemsetAsync(info.p, 0x7f, sizeof(int), stream));
+  potrf(a, linv);
+  trtri(a, linv);
+  solve_alpha(linv, wv, al);
+}
+
+int bobe_gp::read_info() {
+  int v = 0;
+  HIPCHK(hipMemcpyAsync(&v, info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+  sync();
+  return v;
+}
+
+// Z-side quantities of the sweep: ZsT, kXZ, V_Z = Linv kXZ, base_z = kself - |V_Z[:,z]|^2, W_Z = Linv^T V_Z
+void bobe_gp::prepare_z(const double* Z, int64_t M, int64_t Mp) {
+  const double* zin = fetch(Z, (size_t)M * d, z_stage);
+  ZsT.ensure((size_t)d * Mp * sizeof(double));
+  kXZ.ensure((size_t)Np * Mp * sizeof(double));
+  VZ.ensure((size_t)Np * Mp * sizeof(double));
+  WZ.ensure((size_t)Np * Mp * sizeof(double));
+  basez.ensure((size_t)Mp * sizeof(double));
+  qpart.ensure((size_t)nb * (Mp > chunk ? Mp : chunk) * sizeof(double));
+  scale(zin, M, Mp, hyp, ZsT.d(), Mp);
+  kernel_matrix_cross(XsT.d(), Np, N, Np, ZsT.d(), Mp, M, Mp, hyp, kXZ.d(), Mp);
+  hipLaunchKernelGGL(k_trimul, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
+                     (const double*)Linv.d(), Np, nb, (const double*)kXZ.d(), Mp, VZ.d(), Mp, qpart.d(), Mp);
+  hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, stream,
+                     (const double*)qpart.d(), Mp, nb, Mp, hyp.kvar + hyp.noise, 0, basez.d(), (double*)nullptr);
+  hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
+                     (const double*)Linv.d(), Np, nb, (const double*)VZ.d(), Mp, WZ.d(), Mp);
+  LAUNCH_CHECK();
+}
+
+void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, double y_std, double* wipv,
+                    double* wipstd, double* mean, double* var, int policy, int64_t* argmin_v, double* min_v,
+                    int64_t* argmin_s, double* min_s, double* fantasy_out) {
+  if (!factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  if (C <= 0) throw Err(BOBE_ERR_ARG, "C must be positive");
+  const bool do_wip = (Z != nullptr);
+  if (do_wip && M <= 0) throw Err(BOBE_ERR_ARG, "M must be positive");
+  const int64_t Mp = do_wip ? round_up(M, TILE) : 0;
+  const int nzt = (int)(Mp / TILE);
+  const double kself = hyp.kvar + hyp.noise;
+  const bool need_v = wipv || argmin_v || min_v;
+  const bool need_s = wipstd || argmin_s || min_s;
+  const double* cin = fetch(cand, (size_t)C * d, in_stage);
+  if (do_wip) prepare_z(Z, M, Mp);
+  const int64_t CH = chunk;
+  CsT.ensure((size_t)d * CH * sizeof(double));
+  kXC.ensure((size_t)Np * CH * sizeof(double));
+  sc.ensure((size_t)CH * sizeof(double));
+  qpart.ensure((size_t)nb * (Mp > CH ? Mp : CH) * sizeof(double));
+  part.ensure((size_t)nb * (Np > CH ? Np : CH) * sizeof(double));
+  if (do_wip) {
+    pv.ensure((size_t)CH * nzt * sizeof(double));
+    ps.ensure((size_t)CH * nzt * sizeof(double));
+  }
+  double* d_mean = out_dev(mean, C, o_mean);
+  double* d_var = out_dev(var, C, o_var);
+  double* d_wipv = nullptr;
+  double* d_wipstd = nullptr;
+  if (do_wip) {
+    if (need_v) {
+      if (wipv) d_wipv = out_dev(wipv, C, o_wipv);
+      else { o_wipv.ensure(C * sizeof(double)); d_wipv = o_wipv.d(); }
+    }
+    if (need_s) {
+      if (wipstd) d_wipstd = out_dev(wipstd, C, o_wipstd);
+      else { o_wipstd.ensure(C * sizeof(double)); d_wipstd = o_wipstd.d(); }
+    }
+  }
+  double* d_fant = nullptr;
+  if (fantasy_out) {
+    // dumped with leading dimension Mp, compacted afterwards
+    kout.ensure((size_t)round_up(C, TILE) * Mp * sizeof(double));
+    d_fant = kout.d();
+  }
+  for (int64_t c0 = 0; c0 < C; c0 += CH) {
+    const int64_t nc = (C - c0 < CH) ? (C - c0) : CH;
+    const int64_t ncp = round_up(nc, TILE);
+    scale(cin + c0 * d, nc, ncp, hyp, CsT.d(), CH);
+    kernel_matrix_cross(XsT.d(), Np, N, Np, CsT.d(), CH, nc, ncp, hyp, kXC.d(), CH);
+    if (d_mean) {
+      hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(ncp / 64), (unsigned)nb), dim3(256), 0, stream,
+                         (const double*)kXC.d(), CH, 0, (const double*)alpha.d(), part.d(), CH);
+      hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
+                         (const double*)part.d(), CH, nb, 0, nc, d_mean + c0);
+    }
+    hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
+                       (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, (double*)nullptr, (int64_t)0,
+                       qpart.d(), CH);
+    // s_c for the whole padded chunk (scoring reads padded columns), var only for valid columns
+    hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((ncp + 255) / 256)), dim3(256), 0, stream,
+                       (const double*)qpart.d(), CH, nb, ncp, kself, policy, sc.d(), (double*)nullptr);
+    if (d_var)
+      hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
+                         (const double*)qpart.d(), CH, nb, nc, kself, policy, (double*)nullptr, d_var + c0);
+    if (do_wip) {
+      const dim3 grid((unsigned)nzt, (unsigned)(ncp / TILE));
+      double* vo = d_fant ? d_fant + c0 * Mp : nullptr;
+      if (hyp.kern == 0)
+        hipLaunchKernelGGL(k_cross_score<0>, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)kXC.d(), CH, nb,
+                           (const double*)WZ.d(), Mp, (const double*)CsT.d(), CH, (const double*)ZsT.d(), Mp, M,
+                           (const double*)sc.d(), (const double*)basez.d(), hyp, y_std * y_std, pv.d(), ps.d(),
+                           (int64_t)nzt, vo, Mp);
+      else
+        hipLaunchKernelGGL(k_cross_score<1>, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)kXC.d(), CH, nb,
+                           (const double*)WZ.d(), Mp, (const double*)CsT.d(), CH, (const double*)ZsT.d(), Mp, M,
+                           (const double*)sc.d(), (const double*)basez.d(), hyp, y_std * y_std, pv.d(), ps.d(),
+                           (int64_t)nzt, vo, Mp);
+      hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
+                         (const double*)pv.d(), (const double*)ps.d(), (int64_t)nzt, nzt, M, nc,
+                         d_wipv ? d_wipv + c0 : nullptr, d_wipstd ? d_wipstd + c0 : nullptr);
+    }
+    LAUNCH_CHECK();
+  }
+  o_misc.ensure(8 * sizeof(double));
+  double* m_val = o_misc.d();                                        // [0],[1]
+  int64_t* m_idx = reinterpret_cast<int64_t*>(o_misc.d() + 2);       // [2],[3]
+  const bool want_v = do_wip && (argmin_v || min_v);
+  const bool want_s = do_wip && (argmin_s || min_s);
+  if (want_v) hipLaunchKernelGGL(k_argmin, dim3(1), dim3(1024), 0, stream, (const double*)d_wipv, C, m_val, m_idx);
+  if (want_s)
+    hipLaunchKernelGGL(k_argmin, dim3(1), dim3(1024), 0, stream, (const double*)d_wipstd, C, m_val + 1, m_idx + 1);
+  LAUNCH_CHECK();
+  out_finish(mean, C, o_mean);
+  out_finish(var, C, o_var);
+  if (do_wip) {
+    out_finish(wipv, C, o_wipv);
+    out_finish(wipstd, C, o_wipstd);
+  }
+  if (fantasy_out) {
+    const bool dev = is_device_ptr(fantasy_out);
+    HIPCHK(hipMemcpy2DAsync(fantasy_out, (size_t)M * sizeof(double), d_fant, (size_t)Mp * sizeof(double),
+                            (size_t)M * sizeof(double), (size_t)C, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                            stream));
+  }
+  if (want_v || want_s) {
+    HIPCHK(hipMemcpyAsync(h_res, o_misc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    const int64_t* hi = reinterpret_cast<const int64_t*>(h_res + 2);
+    if (want_v) {
+      if (argmin_v) *argmin_v = hi[0];
+      if (min_v) *min_v = h_res[0];
+    }
+    if (want_s) {
+      if (argmin_s) *argmin_s = hi[1];
+      if (min_s) *min_s = h_res[1];
+    }
+  } else {
+    sync();
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// extern "C"
+// -------------------------------------------------------------------------------------------------
+#define API_BEGIN try {
+#define API_END                      \
+  }                                  \
+  catch (const Err& e) {             \
+    g_err = e.what();                \
+    return e.code;                   \
+  }                                  \
+  catch (const std::exception& e) {  \
+    g_err = e.what();                \
+    return BOBE_ERR_HIP;             \
+  }                                  \
+  catch (...) {                      \
+    g_err = "unknown error";         \
+    return BOBE_ERR_HIP;             \
+  }
+
+extern "C" {
+
+const char* bobe_version(void) { return "bobe_gp 0.1.0 gfx950"; }
+const char* bobe_last_error(void) { return g_err.c_str(); }
+
+int bobe_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int bobe_gp_create(bobe_gp_t** out, int device, int kernel, int d) {
+  API_BEGIN
+  if (!out) throw Err(BOBE_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (d < 1 || d > MAX_D) throw Err(BOBE_ERR_ARG, "d must be in [1, 32]");
+  if (kernel != BOBE_KERNEL_RBF && kernel != BOBE_KERNEL_MATERN) throw Err(BOBE_ERR_ARG, "unknown kernel id");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) throw Err(BOBE_ERR_HIP, "no such HIP device (a MI355X is required; there is no CPU path)");
+  bobe_gp* g = new bobe_gp();
+  g->device = device;
+  g->kern = kernel;
+  g->d = d;
+  g->hyp.d = d;
+  g->hyp.kern = kernel;
+  for (int j = 0; j < MAX_D; ++j) g->hyp.ls[j] = 1.0;
+  g->hyp.kvar = 1.0;
+  g->hyp.noise = 1e-8;
+  try {
+    g->use();
+    HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    g->own_stream = true;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->h_res), 128 * sizeof(double), hipHostMallocDefault));
+  } catch (...) {
+    delete g;
+    throw;
+  }
+  *out = g;
+  return BOBE_OK;
+  API_END
+}
+
+void bobe_gp_destroy(bobe_gp_t* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  DBuf* bufs[] = {&g->X, &g->y, &g->XsT, &g->XsT2, &g->A, &g->Linv, &g->A2, &g->Linv2, &g->Tmp, &g->alpha, &g->w,
+                  &g->alpha2, &g->w2, &g->part, &g->gpart, &g->res, &g->info, &g->probs, &g->in_stage, &g->z_stage,
+                  &g->CsT, &g->ZsT, &g->kXC, &g->kXZ, &g->VZ, &g->WZ, &g->basez, &g->sc, &g->qpart, &g->pv, &g->ps,
+                  &g->o_mean, &g->o_var, &g->o_wipv, &g->o_wipstd, &g->o_misc, &g->kin_a, &g->kin_b, &g->kout};
+  for (DBuf* b : bufs) b->release();
+  if (g->h_res) (void)hipHostFree(g->h_res);
+  if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+}
+
+void* bobe_gp_get_stream(bobe_gp_t* g) { return g ? (void*)g->stream : nullptr; }
+
+int bobe_gp_set_stream(bobe_gp_t* g, void* s) {
+  API_BEGIN
+  if (!g) throw Err(BOBE_ERR_ARG, "gp is NULL");
+  g->use();
+  g->sync();
+  if (g->own_stream && g->stream) HIPCHK(hipStreamDestroy(g->stream));
+  g->stream = static_cast<hipStream_t>(s);
+  g->own_stream = false;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_sync(bobe_gp_t* g) {
+  API_BEGIN
+  if (!g) throw Err(BOBE_ERR_ARG, "gp is NULL");
+  g->use();
+  g->sync();
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_set_chunk(bobe_gp_t* g, int64_t chunk) {
+  API_BEGIN
+  if (!g) throw Err(BOBE_ERR_ARG, "gp is NULL");
+  if (chunk == 0) chunk = 2048;
+  if (chunk < TILE || chunk % TILE) throw Err(BOBE_ERR_ARG, "chunk must be a positive multiple of 128");
+  g->use();
+  g->sync();
+  g->chunk = chunk;
+  return BOBE_OK;
+  API_END
+}
+
+int64_t bobe_gp_npoints(bobe_gp_t* g) { return g ? g->N : 0; }
+
+int bobe_gp_set_data(bobe_gp_t* g, const double* X, const double* ys, int64_t N) {
+  API_BEGIN
+  if (!g || !X || !ys) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (N < 1) throw Err(BOBE_ERR_ARG, "N must be >= 1");
+  g->use();
+  g->sync();
+  const int64_t Np = round_up(N, TILE);
+  g->N = N;
+  if (Np != g->Np) {
+    g->Np = Np;
+    g->nb = (int)(Np / TILE);
+    g->alloc_for_n();
+  }
+  g->X.ensure((size_t)N * g->d * sizeof(double));
+  HIPCHK(hipMemcpyAsync(g->X.p, X, (size_t)N * g->d * sizeof(double),
+                        is_device_ptr(X) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g->stream));
+  HIPCHK(hipMemsetAsync(g->y.p, 0, (size_t)Np * sizeof(double), g->stream));
+  HIPCHK(hipMemcpyAsync(g->y.p, ys, (size_t)N * sizeof(double),
+                        is_device_ptr(ys) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g->stream));
+  g->sync();
+  g->have_data = true;
+  g->factored = false;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_set_hyper(bobe_gp_t* g, const double* ls, double kvar, double noise) {
+  API_BEGIN
+  if (!g || !ls) throw Err(BOBE_ERR_ARG, "NULL argument");
+  for (int j = 0; j < g->d; ++j) g->hyp.ls[j] = ls[j];
+  g->hyp.kvar = kvar;
+  g->hyp.noise = noise;
+  g->factored = false;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_factor(bobe_gp_t* g) {
+  API_BEGIN
+  if (!g) throw Err(BOBE_ERR_ARG, "gp is NULL");
+  if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
+  g->use();
+  g->factor_into(g->hyp, g->XsT.d(), g->A.d(), g->Linv.d(), g->w.d(), g->alpha.d());
+  const int inf = g->read_info();
+  g->factored = true;
+  if (inf != 0x7f7f7f7f) {
+    const double nan = std::nan("");
+    const int64_t nn = g->Np * g->Np;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, g->stream, g->A.d(), nn, nan);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, g->stream, g->Linv.d(), nn, nan);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((g->Np + 255) / 256)), dim3(256), 0, g->stream, g->alpha.d(), g->Np, nan);
+    LAUNCH_CHECK();
+    g->sync();
+    g_err = "kernel matrix not positive definite at column " + std::to_string(inf - 1);
+    return BOBE_NOT_PD;
+  }
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_mll(bobe_gp_t* g, const double* ls, double kvar, double* mll, double* grad) {
+  API_BEGIN
+  if (!g || !ls || !mll) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
+  g->use();
+  Hyper h = g->hyp;
+  for (int j = 0; j < g->d; ++j) h.ls[j] = ls[j];
+  h.kvar = kvar;
+  g->factor_into(h, g->XsT2.d(), g->A2.d(), g->Linv2.d(), g->w2.d(), g->alpha2.d());
+  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, g->stream, (const double*)g->w2.d(), (const double*)g->A2.d(),
+                     g->Np, g->Np, g->res.d());
+  const int d = g->d;
+  if (grad) {
+    const int ntiles = g->nb * (g->nb + 1) / 2;
+    const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+#define LG(KE, DC)                                                                                                   \
+  hipLaunchKernelGGL((k_lauum_grad<KE, DC>), dim3(ntiles), dim3(256), GEMM_SMEM_BYTES, g->stream,                   \
+                     (const double*)g->Linv2.d(), g->Np, g->nb, g->N, (const double*)g->alpha2.d(),                  \
+                     (const double*)g->XsT2.d(), g->Np, h, g->gpart.d(), (double*)nullptr, (int64_t)0)
+    if (h.kern == 0) {
+      if (dcap == 8) LG(0, 8); else if (dcap == 16) LG(0, 16); else LG(0, 32);
+    } else {
+      if (dcap == 8) LG(1, 8); else if (dcap == 16) LG(1, 16); else LG(1, 32);
+    }
+#undef LG
+    hipLaunchKernelGGL(k_grad_reduce, dim3(1), dim3(64), 0, g->stream, (const double*)g->gpart.d(), ntiles, dcap + 1, d,
+                       dcap, g->res.d() + 2);
+  }
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(g->h_res, g->res.p, (size_t)(3 + d) * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  const int inf = g->read_info();
+  if (inf != 0x7f7f7f7f) {
+    *mll = std::nan("");
+    if (grad)
+      for (int j = 0; j <= d; ++j) grad[j] = std::nan("");
+    g_err = "kernel matrix not positive definite at column " + std::to_string(inf - 1);
+    return BOBE_NOT_PD;
+  }
+  *mll = -0.5 * g->h_res[0] - g->h_res[1] - 0.5 * (double)g->N * std::log(2.0 * M_PI);
+  if (grad)
+    for (int j = 0; j <= d; ++j) grad[j] = g->h_res[2 + j];
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_predict(bobe_gp_t* g, const double* Xq, int64_t C, double* mean, double* var, int nan_policy) {
+  API_BEGIN
+  if (!g || !Xq) throw Err(BOBE_ERR_ARG, "NULL argument");
+  g->use();
+  g->sweep(Xq, C, nullptr, 0, 1.0, nullptr, nullptr, mean, var, nan_policy ? 1 : 0, nullptr, nullptr, nullptr, nullptr,
+           nullptr);
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_wip_sweep(bobe_gp_t* g, const double* cand, int64_t C, const double* Z, int64_t M, double y_std,
+                      double* wipv, double* wipstd, double* mean, double* var, int64_t* argmin_v, double* min_v,
+                      int64_t* argmin_s, double* min_s) {
+  API_BEGIN
+  if (!g || !cand || !Z) throw Err(BOBE_ERR_ARG, "NULL argument");
+  g->use();
+  g->sweep(cand, C, Z, M, y_std, wipv, wipstd, mean, var, 1, argmin_v, min_v, argmin_s, min_s, nullptr);
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_fantasy_var(bobe_gp_t* g, const double* cand, int64_t C, const double* Z, int64_t M, double y_std,
+                        double* out) {
+  API_BEGIN
+  if (!g || !cand || !Z || !out) throw Err(BOBE_ERR_ARG, "NULL argument");
+  g->use();
+  g->sweep(cand, C, Z, M, y_std, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, out);
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_acq_ei(bobe_gp_t* g, const double* Xq, int64_t C, double best_y, double zeta, int mode, double* out) {
+  API_BEGIN
+  if (!g || !Xq || !out) throw Err(BOBE_ERR_ARG, "NULL argument");
+  g->use();
+  g->o_mean.ensure(C * sizeof(double));
+  g->o_var.ensure(C * sizeof(double));
+  g->sweep(Xq, C, nullptr, 0, 1.0, nullptr, nullptr, g->o_mean.d(), g->o_var.d(), 1, nullptr, nullptr, nullptr, nullptr,
+           nullptr);
+  double* d_out = g->out_dev(out, C, g->o_wipv);
+  hipLaunchKernelGGL(k_ei, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, g->stream, (const double*)g->o_mean.d(),
+                     (const double*)g->o_var.d(), C, best_y, zeta, mode, d_out);
+  LAUNCH_CHECK();
+  g->out_finish(out, C, g->o_wipv);
+  g->sync();
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_kernel(bobe_gp_t* g, const double* A, int64_t nA, const double* B, int64_t nB, const double* ls,
+                   double kvar, double noise, int include_noise, double* out) {
+  API_BEGIN
+  if (!g || !A || !B || !out) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (nA < 1 || nB < 1) throw Err(BOBE_ERR_ARG, "empty input");
+  if (include_noise && nA != nB) throw Err(BOBE_ERR_ARG, "include_noise needs a square kernel matrix (gp.py:153)");
+  g->use();
+  const int d = g->d;
+  Hyper hk = g->hyp;
+  if (ls) {
+    for (int j = 0; j < d; ++j) hk.ls[j] = ls[j];
+    hk.kvar = kvar;
+    hk.noise = noise;
+  }
+  const int64_t pa = round_up(nA, TILE), pb = round_up(nB, TILE);
+  const double* a_in = g->fetch(A, (size_t)nA * d, g->in_stage);
+  const double* b_in = g->fetch(B, (size_t)nB * d, g->z_stage);
+  g->kin_a.ensure((size_t)d * pa * sizeof(double));
+  g->kin_b.ensure((size_t)d * pb * sizeof(double));
+  g->kout.ensure((size_t)pa * pb * sizeof(double));
+  g->scale(a_in, nA, pa, hk, g->kin_a.d(), pa);
+  g->scale(b_in, nB, pb, hk, g->kin_b.d(), pb);
+  g->kernel_matrix_cross(g->kin_a.d(), pa, nA, pa, g->kin_b.d(), pb, nB, pb, hk, g->kout.d(), pb);
+  const bool dev = is_device_ptr(out);
+  HIPCHK(hipMemcpy2DAsync(out, (size_t)nB * sizeof(double), g->kout.p, (size_t)pb * sizeof(double),
+                          (size_t)nB * sizeof(double), (size_t)nA, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                          g->stream));
+  g->sync();
+  if (include_noise) {
+    // noise * eye(n) (gp.py:153): added on the host side of the copy for host outputs, by a tiny kernel otherwise
+    if (!dev) {
+      for (int64_t i = 0; i < nA; ++i) out[i * nB + i] += hk.noise;
+    } else {
+      std::vector<double> diag((size_t)nA);
+      HIPCHK(hipMemcpy2D(diag.data(), sizeof(double), out, (size_t)(nB + 1) * sizeof(double), sizeof(double), (size_t)nA,
+                         hipMemcpyDeviceToHost));
+      for (auto& v : diag) v += hk.noise;
+      HIPCHK(hipMemcpy2D(out, (size_t)(nB + 1) * sizeof(double), diag.data(), sizeof(double), sizeof(double), (size_t)nA,
+                         hipMemcpyHostToDevice));
+    }
+  }
+  return BOBE_OK;
+  API_END
+}
+
+static void copy_out_matrix(bobe_gp* g, const double* src, double* dst, int lower_only) {
+  const int64_t N = g->N;
+  double* d_out = g->out_dev(dst, (size_t)N * N, g->kout);
+  hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, g->stream, src, g->Np, d_out,
+                     N, N, N, lower_only);
+  LAUNCH_CHECK();
+  g->out_finish(dst, (size_t)N * N, g->kout);
+}
+
+int bobe_gp_get_chol(bobe_gp_t* g, double* L, double* alpha) {
+  API_BEGIN
+  if (!g) throw Err(BOBE_ERR_ARG, "gp is NULL");
+  if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  g->use();
+  if (L) copy_out_matrix(g, g->A.d(), L, 1);
+  if (alpha)
+    HIPCHK(hipMemcpyAsync(alpha, g->alpha.p, (size_t)g->N * sizeof(double),
+                          is_device_ptr(alpha) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, g->stream));
+  g->sync();
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_set_chol(bobe_gp_t* g, const double* L, const double* alpha) {
+  API_BEGIN
+  if (!g || !L || !alpha) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
+  g->use();
+  const int64_t N = g->N, Np = g->Np;
+  const double* l_in = g->fetch(L, (size_t)N * N, g->kout);
+  hipLaunchKernelGGL(k_load_padded_lower, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, g->stream, l_in,
+                     N, g->A.d(), Np, Np);
+  HIPCHK(hipMemsetAsync(g->alpha.p, 0, (size_t)Np * sizeof(double), g->stream));
+  HIPCHK(hipMemcpyAsync(g->alpha.p, alpha, (size_t)N * sizeof(double),
+                        is_device_ptr(alpha) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g->stream));
+  g->scale(g->X.d(), N, Np, g->hyp, g->XsT.d(), Np);
+  for (int k = 0; k < g->nb; ++k)
+    hipLaunchKernelGGL(k_potf2_inv<false>, dim3(1), dim3(256), POTF2_SMEM_BYTES, g->stream, g->A.d(), Np, g->Linv.d(), Np,
+                       k, static_cast<int*>(g->info.p));
+  LAUNCH_CHECK();
+  g->trtri(g->A.d(), g->Linv.d());
+  g->sync();
+  g->factored = true;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_debug_gemm(int device, int la, int lb, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                    const double* B, int64_t ldb, double* C, int64_t ldc) {
+  API_BEGIN
+  if (M % TILE || N % TILE || K % TK || M <= 0 || N <= 0 || K <= 0) throw Err(BOBE_ERR_ARG, "bad GEMM shape");
+  HIPCHK(hipSetDevice(device));
+  configure_kernels_once();
+  const size_t na = (size_t)(la == 0 ? M * lda : K * lda), nbb = (size_t)(lb == 0 ? N * ldb : K * ldb), nc = (size_t)M * ldc;
+  DBuf da, db, dc;
+  const double *pa = A, *pb = B;
+  double* pc = C;
+  const bool ha = !is_device_ptr(A), hb = !is_device_ptr(B), hc = !is_device_ptr(C);
+  if (ha) { da.ensure(na * 8); HIPCHK(hipMemcpy(da.p, A, na * 8, hipMemcpyHostToDevice)); pa = da.d(); }
+  if (hb) { db.ensure(nbb * 8); HIPCHK(hipMemcpy(db.p, B, nbb * 8, hipMemcpyHostToDevice)); pb = db.d(); }
+  if (hc) { dc.ensure(nc * 8); pc = dc.d(); }
+  const dim3 grid((unsigned)(N / TILE), (unsigned)(M / TILE));
+#define DG(a, b) hipLaunchKernelGGL((k_debug_gemm<a, b>), grid, dim3(256), GEMM_SMEM_BYTES, 0, pa, lda, pb, ldb, pc, ldc, K)
+  if (la == 0 && lb == 0) DG(0, 0); else if (la == 0) DG(0, 1); else if (lb == 0) DG(1, 0); else DG(1, 1);
+#undef DG
+  LAUNCH_CHECK();
+  HIPCHK(hipDeviceSynchronize());
+  if (hc) HIPCHK(hipMemcpy(C, dc.p, nc * 8, hipMemcpyDeviceToHost));
+  da.release(); db.release(); dc.release();
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_debug_kinv(bobe_gp_t* g, double* Kinv) {
+  API_BEGIN
+  if (!g || !Kinv) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  g->use();
+  const int ntiles = g->nb * (g->nb + 1) / 2;
+  hipLaunchKernelGGL((k_lauum_grad<0, 32>), dim3(ntiles), dim3(256), GEMM_SMEM_BYTES, g->stream,
+                     (const double*)g->Linv.d(), g->Np, g->nb, g->N, (const double*)g->alpha.d(),
+                     (const double*)g->XsT.d(), g->Np, g->hyp, g->gpart.d(), g->Tmp.d(), g->Np);
+  LAUNCH_CHECK();
+  // symmetrise on the host side of the copy
+  const int64_t N = g->N;
+  std::vector<double> full((size_t)N * N);
+  HIPCHK(hipMemcpy2DAsync(full.data(), (size_t)N * 8, g->Tmp.p, (size_t)g->Np * 8, (size_t)N * 8, (size_t)N,
+                          hipMemcpyDeviceToHost, g->stream));
+  g->sync();
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = i + 1; j < N; ++j) full[i * N + j] = full[j * N + i];
+  if (is_device_ptr(Kinv)) HIPCHK(hipMemcpy(Kinv, full.data(), full.size() * 8, hipMemcpyHostToDevice));
+  else std::memcpy(Kinv, full.data(), full.size() * 8);
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_debug_linv(bobe_gp_t* g, double* Linv) {
+  API_BEGIN
+  if (!g || !Linv) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  g->use();
+  copy_out_matrix(g, g->Linv.d(), Linv, 1);
+  g->sync();
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_debug_time_potrf(bobe_gp_t* g, int reps, double* ms) {
+  API_BEGIN
+  if (!g || !ms || reps < 1) throw Err(BOBE_ERR_ARG, "bad argument");
+  if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
+  g->use();
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  double total = 0.0;
+  g->scale(g->X.d(), g->N, g->Np, g->hyp, g->XsT2.d(), g->Np);
+  for (int r = 0; r < reps; ++r) {
+    g->assemble_kxx(g->hyp, g->XsT2.d(), g->A2.d());
+    HIPCHK(hipMemsetAsync(g->info.p, 0x7f, sizeof(int), g->stream));
+    HIPCHK(hipEventRecord(e0, g->stream));
+    g->potrf(g->A2.d(), g->Linv2.d());
+    HIPCHK(hipEventRecord(e1, g->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    total += t;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms = total / reps;
+  return BOBE_OK;
+  API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,773 @@
+// HIP kernels of the BOBE GP hot path for gfx950.  See DESIGN.md for the data layout.
+//
+// Conventions
+//   * Np = N rounded up to 128.  The padded kernel matrix is [[K,0],[0,I]], so its Cholesky
+//     factor is [[L,0],[0,I]], its inverse factor [[L^-1,0],[0,I]], and padded y / alpha are 0.
+//     Kernels that evaluate k(x_a, x_b) mask padded points by index.
+//   * coordinates are stored SoA and pre-divided by the lengthscales: XsT[j*ld + i] = x_ij / ls_j
+//     (reference op order: dist_sq(xa/ls, xb/ls), BOBE/gp.py:149, 161).
+#pragma once
+#include "gemm_f64.hpp"
+
+namespace bobe {
+
+constexpr int MAX_D = 32;
+constexpr double SQRT5 = 2.23606797749978969641;
+constexpr double NOISE_FLOOR = 1e-12;   // BOBE/gp.py:16
+
+struct Hyper {
+  double ls[MAX_D];
+  double kvar;
+  double noise;
+  int d;
+  int kern;  // 0 rbf, 1 matern-5/2
+};
+
+// ---- kernel functions (BOBE/gp.py:124-168) ---------------------------------------------
+template <int KERN>
+__device__ __forceinline__ double kern_eval(double r2, double kvar) {
+  if (KERN == 0) {
+    return kvar * exp(-0.5 * r2);
+  } else {
+    const double dd = sqrt(r2 < 1e-30 ? 1e-30 : r2);
+    const double e = exp(-SQRT5 * dd);
+    const double poly = 1.0 + dd * (SQRT5 + (dd * 5.0) / 3.0);
+    return kvar * poly * e;
+  }
+}
+
+// d k / d log ls_j = grad_factor * D_j, with D_j the squared scaled difference in dim j
+template <int KERN>
+__device__ __forceinline__ double kern_grad_factor(double r2, double kvar, double kval) {
+  if (KERN == 0) {
+    return kval;
+  } else {
+    if (r2 < 1e-30) return 0.0;
+    const double dd = sqrt(r2);
+    return kvar * (5.0 / 3.0) * (1.0 + SQRT5 * dd) * exp(-SQRT5 * dd);
+  }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- coordinate scaling: out[j*ldo + i] = in[i*d + j] / ls[j]  (0 for i >= n) ------------
+__global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t npad, Hyper h,
+                               double* __restrict__ out, int64_t ldo) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  for (int j = 0; j < h.d; ++j) out[j * ldo + i] = (i < n) ? in[i * h.d + j] / h.ls[j] : 0.0;
+}
+
+// ---- kernel-matrix assembly ---------------------------------------------------------------
+// out[a*ldo + b] = k(A_a, B_b) for a < na, b < nb; padding is 0, or identity when SQUARE.
+// SQUARE: blockIdx.x enumerates lower tiles (ti >= tj) and noise is added on the diagonal.
+// else  : blockIdx.x = tile column, blockIdx.y = tile row.
+template <int KERN, bool SQUARE>
+__global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ AT, int64_t lda, int64_t na,
+                                                       const double* __restrict__ BT, int64_t ldb, int64_t nb,
+                                                       Hyper h, double* __restrict__ out, int64_t ldo) {
+  extern __shared__ double kmsm[];
+  double* xa = kmsm;                 // [d][128]
+  double* xb = kmsm + h.d * TILE;    // [d][128]
+  int ti, tj;
+  if (SQUARE) {
+    tri_decode(blockIdx.x, ti, tj);
+  } else {
+    ti = blockIdx.y;
+    tj = blockIdx.x;
+  }
+  const int t = threadIdx.x;
+  for (int e = t; e < h.d * TILE; e += 256) {
+    const int j = e >> 7, c = e & 127;
+    xa[j * TILE + c] = AT[j * lda + (int64_t)ti * TILE + c];
+    xb[j * TILE + c] = BT[j * ldb + (int64_t)tj * TILE + c];
+  }
+  __syncthreads();
+  const int b = t & 127;
+  const int64_t gb = (int64_t)tj * TILE + b;
+  for (int a = t >> 7; a < TILE; a += 2) {
+    const int64_t ga = (int64_t)ti * TILE + a;
+    double r2 = 0.0;
+    for (int j = 0; j < h.d; ++j) {
+      const double df = xa[j * TILE + a] - xb[j * TILE + b];
+      r2 += df * df;
+    }
+    double v;
+    if (ga < na && gb < nb) {
+      v = kern_eval<KERN>(r2, h.kvar);
+      if (SQUARE && ga == gb) v += h.noise;
+    } else {
+      v = (SQUARE && ga == gb) ? 1.0 : 0.0;
+    }
+    out[ga * ldo + gb] = v;
+  }
+}
+
+// ---- diagonal block: Cholesky of a 128x128 block + its triangular inverse ------------------
+constexpr int PLD = 130;                        // LDS leading dimension (doubles)
+constexpr int POTF2_SMEM_BYTES = TILE * PLD * 8;  // 133,120 B
+
+template <bool FACTOR>
+__global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
+                                                   int64_t ldl, int blk, int* __restrict__ info) {
+  extern __shared__ double S[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  double* Ab = A + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
+  {
+    const int c = t & 127;
+    for (int r = t >> 7; r < TILE; r += 2) S[r * PLD + c] = Ab[(int64_t)r * lda + c];
+  }
+  __syncthreads();
+
+  for (int p = 0; FACTOR && p < 8; ++p) {
+    const int o = 16 * p;
+    // (a) 16x16 diagonal sub-block, one row per lane (lanes >= 16 mirror lanes 0..15)
+    if (wave == 0) {
+      const int li = lane & 15;
+      double r[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) r[c] = S[(o + li) * PLD + o + c];
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double ajj = readlane_f64(r[j], j);
+        if (!(ajj > 0.0)) bad = true;
+        const double dj = sqrt(ajj);
+        const double inv = 1.0 / dj;
+        r[j] = (li == j) ? dj : r[j] * inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+          const double lcj = readlane_f64(r[j], c);
+          r[c] -= r[j] * lcj;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) S[(o + li) * PLD + o + c] = (c <= li) ? r[c] : 0.0;
+      }
+      if (bad && lane == 0) atomicMin(info, blk * TILE + o + 1);
+    }
+    __syncthreads();
+    // (b) rows below: x * Lpp^T = a  (forward substitution, one row per thread)
+    {
+      const int nrows = TILE - o - 16;
+      if (t < nrows) {
+        const int row = o + 16 + t;
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = S[row * PLD + o + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double s = x[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) s -= x[k] * S[(o + c) * PLD + o + k];
+          x[c] = s / S[(o + c) * PLD + o + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) S[row * PLD + o + c] = x[c];
+      }
+    }
+    __syncthreads();
+    // (c) trailing update inside the block: A[ti][tj] -= L[ti][p] L[tj][p]^T  (16x16 MFMA tiles)
+    {
+      const int nt = 7 - p;
+      const int ntiles = nt * (nt + 1) / 2;
+      for (int q = wave; q < ntiles; q += 4) {
+        int a, b;
+        tri_decode(q, a, b);
+        const int ti = p + 1 + a, tj = p + 1 + b;
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = S[(16 * ti + (lane >> 4) + 4 * r) * PLD + 16 * tj + (lane & 15)];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double av = -S[(16 * ti + (lane & 15)) * PLD + o + 4 * ks + (lane >> 4)];
+          const double bv = S[(16 * tj + (lane & 15)) * PLD + o + 4 * ks + (lane >> 4)];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(16 * ti + (lane >> 4) + 4 * r) * PLD + 16 * tj + (lane & 15)] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+  // write L (lower, zeros above the diagonal)
+  if (FACTOR) {
+    const int c = t & 127;
+    for (int r = t >> 7; r < TILE; r += 2) Ab[(int64_t)r * lda + c] = (c <= r) ? S[r * PLD + c] : 0.0;
+  }
+  __syncthreads();
+  // ---- in-place inverse ----
+  // I1: the eight 16x16 diagonal blocks, one column per thread
+  {
+    double x[16];
+    const int bb = t >> 4, col = t & 15, o = 16 * bb;
+    if (t < 128) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double s = (r == col) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) s -= S[(o + r) * PLD + o + k] * x[k];
+        x[r] = s / S[(o + r) * PLD + o + r];
+      }
+    }
+    __syncthreads();
+    if (t < 128) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[(o + r) * PLD + o + col] = x[r];
+    }
+    __syncthreads();
+  }
+  // I2: block rows 1..7:  inv[i][j] = -inv[i][i] * sum_{k=j}^{i-1} L[i][k] inv[k][j]
+  for (int i = 1; i < 8; ++i) {
+    v4d res0 = (v4d){0.0, 0.0, 0.0, 0.0}, res1 = res0;
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int j = wave + 4 * slot;
+      if (j < i) {
+        v4d tacc = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int k = j; k < i; ++k) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const double av = S[(16 * i + (lane & 15)) * PLD + 16 * k + 4 * ks + (lane >> 4)];
+            const double bv = S[(16 * k + 4 * ks + (lane >> 4)) * PLD + 16 * j + (lane & 15)];
+            tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, tacc, 0, 0, 0);
+          }
+        }
+        // R = -inv[i][i] * T ; T's accumulator register r holds row (lane>>4)+4r, used as the k index
+        v4d racc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double av = -S[(16 * i + (lane & 15)) * PLD + 16 * i + (lane >> 4) + 4 * r];
+          racc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tacc[r], racc, 0, 0, 0);
+        }
+        if (slot == 0) res0 = racc; else res1 = racc;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int j = wave + 4 * slot;
+      if (j < i) {
+        const v4d racc = slot == 0 ? res0 : res1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(16 * i + (lane >> 4) + 4 * r) * PLD + 16 * j + (lane & 15)] = racc[r];
+      }
+    }
+    __syncthreads();
+  }
+  {
+    double* Lb = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
+    const int c = t & 127;
+    for (int r = t >> 7; r < TILE; r += 2) Lb[(int64_t)r * ldl + c] = (c <= r) ? S[r * PLD + c] : 0.0;
+  }
+}
+
+// ---- blocked Cholesky pieces ---------------------------------------------------------------
+// panel: A[i][k] <- A[i][k] * invL_kk^T for block rows i = k+1 .. nb-1   (grid = nb-k-1)
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int64_t lda, const double* __restrict__ Linv,
+                                                    int64_t ldl, int k) {
+  extern __shared__ double smem[];
+  const int i = k + 1 + blockIdx.x;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<KC, KC>(acc, A, lda, (int64_t)i * TILE, Linv, ldl, (int64_t)k * TILE, (int64_t)k * TILE,
+                    (int64_t)(k + 1) * TILE, smem);
+  store_tile(acc, A, lda, (int64_t)i * TILE, (int64_t)k * TILE, 1.0, 0.0);
+}
+
+// trailing update: A[i][j] -= L[i][k] L[j][k]^T for k < j <= i < nb  (grid = n(n+1)/2, n = nb-k-1)
+__global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k) {
+  extern __shared__ double smem[];
+  int a, b;
+  tri_decode(blockIdx.x, a, b);
+  const int i = k + 1 + a, j = k + 1 + b;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<KC, KC>(acc, A, lda, (int64_t)i * TILE, A, lda, (int64_t)j * TILE, (int64_t)k * TILE,
+                    (int64_t)(k + 1) * TILE, smem);
+  store_tile(acc, A, lda, (int64_t)i * TILE, (int64_t)j * TILE, -1.0, 1.0);
+}
+
+// ---- recursive triangular inverse ------------------------------------------------------------
+// problem {lo, mid, hi} in tile units: with inv[lo:mid) and inv[mid:hi) known,
+//   T = L[mid:hi, lo:mid) * inv[lo:mid)            (k_trtri_T, written to Tmp)
+//   inv[mid:hi, lo:mid) = -inv[mid:hi) * T          (k_trtri_R)
+struct TriProb { int lo, mid, hi, off; };   // off = first block index of this problem
+
+__device__ __forceinline__ bool tri_find(const TriProb* __restrict__ probs, int nprob, int bid, TriProb& p) {
+  for (int q = 0; q < nprob; ++q) {
+    const TriProb c = probs[q];
+    const int nt = (c.hi - c.mid) * (c.mid - c.lo);
+    if (bid >= c.off && bid < c.off + nt) { p = c; return true; }
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void k_trtri_T(const double* __restrict__ L, int64_t ldl, const double* __restrict__ Linv,
+                                                 int64_t ldi, double* __restrict__ Tmp, int64_t ldt,
+                                                 const TriProb* __restrict__ probs, int nprob) {
+  extern __shared__ double smem[];
+  TriProb p;
+  if (!tri_find(probs, nprob, blockIdx.x, p)) return;
+  const int q = blockIdx.x - p.off;
+  const int w = p.mid - p.lo;
+  const int i = p.mid + q / w, j = p.lo + q % w;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<KC, RC>(acc, L, ldl, (int64_t)i * TILE, Linv, ldi, (int64_t)j * TILE, (int64_t)j * TILE,
+                    (int64_t)p.mid * TILE, smem);
+  store_tile(acc, Tmp, ldt, (int64_t)i * TILE, (int64_t)j * TILE, 1.0, 0.0);
+}
+
+__global__ __launch_bounds__(256) void k_trtri_R(double* __restrict__ Linv, int64_t ldi, const double* __restrict__ Tmp,
+                                                 int64_t ldt, const TriProb* __restrict__ probs, int nprob) {
+  extern __shared__ double smem[];
+  TriProb p;
+  if (!tri_find(probs, nprob, blockIdx.x, p)) return;
+  const int q = blockIdx.x - p.off;
+  const int w = p.mid - p.lo;
+  const int i = p.mid + q / w, j = p.lo + q % w;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<KC, RC>(acc, Linv, ldi, (int64_t)i * TILE, Tmp, ldt, (int64_t)j * TILE, (int64_t)p.mid * TILE,
+                    (int64_t)(i + 1) * TILE, smem);
+  store_tile(acc, Linv, ldi, (int64_t)i * TILE, (int64_t)j * TILE, -1.0, 0.0);
+}
+
+// ---- K^-1 = Linv^T Linv fused with the MLL gradient reduction ---------------------------------
+// tile (ti >= tj): Kinv = sum_{k >= ti} Linv[k][ti]^T Linv[k][tj];  W = alpha alpha^T - Kinv.
+// partial[(blockIdx.x)*(DCAP+1) + j] = sum_ab W_ab dK_ab/dlog ls_j (j < d), [DCAP] = sum_ab W_ab Kt_ab,
+// off-diagonal tiles weighted x2.  Optionally stores Kinv (lower tiles) for tests.
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_lauum_grad(const double* __restrict__ Linv, int64_t ldi, int nb, int64_t n,
+                                                    const double* __restrict__ alpha, const double* __restrict__ XsT,
+                                                    int64_t ldx, Hyper h, double* __restrict__ partial,
+                                                    double* __restrict__ Kinv, int64_t ldk) {
+  extern __shared__ double smem[];
+  int ti, tj;
+  tri_decode(blockIdx.x, ti, tj);
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<RC, RC>(acc, Linv, ldi, (int64_t)ti * TILE, Linv, ldi, (int64_t)tj * TILE, (int64_t)ti * TILE,
+                    (int64_t)nb * TILE, smem);
+  if (Kinv) store_tile(acc, Kinv, ldk, (int64_t)ti * TILE, (int64_t)tj * TILE, 1.0, 0.0);
+  // stage coordinates and alpha in the (now free) GEMM LDS
+  double* xa = smem;                   // [d][128]
+  double* xb = smem + MAX_D * TILE;    // [d][128]
+  double* aa = smem + 2 * MAX_D * TILE;  // [128]
+  double* ab = aa + TILE;              // [128]
+  double* red = ab + TILE;             // [4][DCAP+1]
+  const int t = threadIdx.x;
+  for (int e = t; e < h.d * TILE; e += 256) {
+    const int j = e >> 7, c = e & 127;
+    xa[j * TILE + c] = XsT[j * ldx + (int64_t)ti * TILE + c];
+    xb[j * TILE + c] = XsT[j * ldx + (int64_t)tj * TILE + c];
+  }
+  if (t < TILE) {
+    aa[t] = alpha[(int64_t)ti * TILE + t];
+    ab[t] = alpha[(int64_t)tj * TILE + t];
+  }
+  __syncthreads();
+  double g[DCAP + 1];
+#pragma unroll
+  for (int j = 0; j <= DCAP; ++j) g[j] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = acc_row(i, r), b = acc_col(jj);
+        const int64_t ga = (int64_t)ti * TILE + a, gb = (int64_t)tj * TILE + b;
+        if (ga < n && gb < n) {
+          const double w = aa[a] * ab[b] - acc[i][jj][r];
+          double dsq[DCAP];
+          double r2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) {
+            if (j < h.d) {
+              const double df = xa[j * TILE + a] - xb[j * TILE + b];
+              dsq[j] = df * df;
+              r2 += dsq[j];
+            } else {
+              dsq[j] = 0.0;
+            }
+          }
+          const double kv = kern_eval<KERN>(r2, h.kvar);
+          const double wf = w * kern_grad_factor<KERN>(r2, h.kvar, kv);
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) g[j] += wf * dsq[j];
+          g[DCAP] += w * kv;
+        }
+      }
+  const double wt = (ti == tj) ? 1.0 : 2.0;
+  const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int j = 0; j <= DCAP; ++j) {
+    const double s = wave_sum(g[j]);
+    if (lane == 0) red[wave * (DCAP + 1) + j] = s;
+  }
+  __syncthreads();
+  if (t <= DCAP) {
+    const double s = ((red[t] + red[(DCAP + 1) + t]) + red[2 * (DCAP + 1) + t]) + red[3 * (DCAP + 1) + t];
+    partial[(int64_t)blockIdx.x * (DCAP + 1) + t] = wt * s;
+  }
+}
+
+// ---- V = Linv * B  (lower-triangular times dense), optional store, optional column sum of squares
+// grid.x = column tile, grid.y = row tile (heavy rows first).  B is [Np x ncols] row-major (RC).
+// qpart[(row tile)*ldq + col] = sum over the tile's 128 rows of V^2.
+__global__ __launch_bounds__(256) void k_trimul(const double* __restrict__ Linv, int64_t ldi, int nb,
+                                                const double* __restrict__ B, int64_t ldb, double* __restrict__ V,
+                                                int64_t ldv, double* __restrict__ qpart, int64_t ldq) {
+  extern __shared__ double smem[];
+  const int ti = nb - 1 - blockIdx.y;
+  const int tc = blockIdx.x;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<KC, RC>(acc, Linv, ldi, (int64_t)ti * TILE, B, ldb, (int64_t)tc * TILE, 0, (int64_t)(ti + 1) * TILE, smem);
+  if (V) store_tile(acc, V, ldv, (int64_t)ti * TILE, (int64_t)tc * TILE, 1.0, 0.0);
+  if (qpart) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double* red = smem;  // [2][128]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 16) red[(wave >> 1) * TILE + (wave & 1) * 64 + 16 * j + lane] = s;
+    }
+    __syncthreads();
+    if (t < TILE) qpart[(int64_t)ti * ldq + (int64_t)tc * TILE + t] = red[t] + red[TILE + t];
+  }
+}
+
+// ---- W = Linv^T * V  (upper-triangular times dense):  W[m][z] = sum_{k >= m} Linv[k][m] V[k][z]
+__global__ __launch_bounds__(256) void k_trimul_t(const double* __restrict__ Linv, int64_t ldi, int nb,
+                                                  const double* __restrict__ V, int64_t ldv, double* __restrict__ W,
+                                                  int64_t ldw) {
+  extern __shared__ double smem[];
+  const int ti = blockIdx.y;
+  const int tc = blockIdx.x;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<RC, RC>(acc, Linv, ldi, (int64_t)ti * TILE, V, ldv, (int64_t)tc * TILE, (int64_t)ti * TILE,
+                    (int64_t)nb * TILE, smem);
+  store_tile(acc, W, ldw, (int64_t)ti * TILE, (int64_t)tc * TILE, 1.0, 0.0);
+}
+
+// ---- cross-covariance GEMM fused with the WIPV / WIPStd scoring epilogue ------------------------
+// tile (tc, tz): acc = sum_n kXC[n][c] WZ[n][z];  cross = k(x_c, z) - acc
+// var+(z|c) = base_z - cross^2 / s_c -> NaN / < 1e-12 -> 1e-12 -> * ystd2      (BOBE/gp.py:552-576)
+// pv[c*ldp + tz] = sum_z var+, ps[c*ldp + tz] = sum_z sqrt(var+)  over the tile's valid z.
+template <int KERN>
+__global__ __launch_bounds__(256) void k_cross_score(const double* __restrict__ kXC, int64_t ldk, int nb,
+                                                     const double* __restrict__ WZ, int64_t ldw,
+                                                     const double* __restrict__ CsT, int64_t ldc,
+                                                     const double* __restrict__ ZsT, int64_t ldz, int64_t mvalid,
+                                                     const double* __restrict__ sc, const double* __restrict__ basez,
+                                                     Hyper h, double ystd2, double* __restrict__ pv,
+                                                     double* __restrict__ ps, int64_t ldp,
+                                                     double* __restrict__ var_out, int64_t ldvo) {
+  extern __shared__ double smem[];
+  const int tc = blockIdx.y, tz = blockIdx.x;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<RC, RC>(acc, kXC, ldk, (int64_t)tc * TILE, WZ, ldw, (int64_t)tz * TILE, 0, (int64_t)nb * TILE, smem);
+  double* xc = smem;                      // [d][128]
+  double* xz = smem + MAX_D * TILE;       // [d][128]
+  double* s_c = smem + 2 * MAX_D * TILE;  // [128]
+  double* b_z = s_c + TILE;               // [128]
+  double* red = b_z + TILE;               // [2][2][128]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int e = t; e < h.d * TILE; e += 256) {
+    const int j = e >> 7, c = e & 127;
+    xc[j * TILE + c] = CsT[j * ldc + (int64_t)tc * TILE + c];
+    xz[j * TILE + c] = ZsT[j * ldz + (int64_t)tz * TILE + c];
+  }
+  if (t < TILE) {
+    s_c[t] = sc[(int64_t)tc * TILE + t];
+    b_z[t] = basez[(int64_t)tz * TILE + t];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = acc_row(i, r);
+      const double s = s_c[a];
+      double sv = 0.0, ss = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = acc_col(j);
+        const int64_t gz = (int64_t)tz * TILE + b;
+        double r2 = 0.0;
+        for (int q = 0; q < h.d; ++q) {
+          const double df = xc[q * TILE + a] - xz[q * TILE + b];
+          r2 += df * df;
+        }
+        const double cross = kern_eval<KERN>(r2, h.kvar) - acc[i][j][r];
+        double v = b_z[b] - (cross * cross) / s;
+        if (!(s >= 0.0)) v = NOISE_FLOOR;      // sqrt(negative) = NaN in fast_update_cholesky (gp.py:187)
+        if (v != v) v = NOISE_FLOOR;           // gp.py:574
+        if (v < NOISE_FLOOR) v = NOISE_FLOOR;  // gp.py:575
+        v *= ystd2;                            // gp.py:576
+        if (gz < mvalid) {
+          sv += v;
+          ss += sqrt(v);
+          if (var_out) var_out[((int64_t)tc * TILE + a) * ldvo + gz] = v;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        sv += __shfl_xor(sv, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+      }
+      if ((lane & 15) == 0) {
+        red[((wave & 1) * 2 + 0) * TILE + a] = sv;
+        red[((wave & 1) * 2 + 1) * TILE + a] = ss;
+      }
+    }
+  __syncthreads();
+  if (t < TILE) {
+    const int64_t gc = (int64_t)tc * TILE + t;
+    pv[gc * ldp + tz] = red[0 * TILE + t] + red[2 * TILE + t];
+    ps[gc * ldp + tz] = red[1 * TILE + t] + red[3 * TILE + t];
+  }
+}
+
+// ---- matrix-vector products ---------------------------------------------------------------------
+// w[i] = sum_{k <= i} M[i][k] y[k]   (one wave per row, fixed summation order)
+__global__ __launch_bounds__(256) void k_gemv_lower(const double* __restrict__ M, int64_t ld, int64_t np,
+                                                    const double* __restrict__ y, double* __restrict__ w) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= np) return;
+  double s = 0.0;
+  for (int64_t k = lane; k <= i; k += 64) s += M[i * ld + k] * y[k];
+  s = wave_sum(s);
+  if (lane == 0) w[i] = s;
+}
+
+// part[rb*ldp + c] = sum_{k in row block rb (128 rows)} M[k][c] w[k], only row blocks rb >= rb_min(c)
+// where rb_min = (lower ? c/128 : 0).  grid.x = column strips of 64, grid.y = row blocks.
+__global__ __launch_bounds__(256) void k_gemv_t_part(const double* __restrict__ M, int64_t ld, int lower,
+                                                     const double* __restrict__ w, double* __restrict__ part,
+                                                     int64_t ldp) {
+  __shared__ double red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
+  const int rb = blockIdx.y;
+  double s = 0.0;
+  if (!lower || rb >= (int)(blockIdx.x * 64 / TILE)) {
+    const int64_t k0 = (int64_t)rb * TILE + ry * 32;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) s += M[(k0 + k) * ld + c] * w[k0 + k];
+  }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0) part[(int64_t)rb * ldp + c] = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
+}
+
+// out[c] = sum_{rb=rb0(c)}^{nrb-1} part[rb*ldp + c]   (fixed order)
+__global__ void k_colsum_parts(const double* __restrict__ part, int64_t ldp, int nrb, int lower, int64_t ncols,
+                               double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  double s = 0.0;
+  for (int rb = lower ? (int)(c / TILE) : 0; rb < nrb; ++rb) s += part[(int64_t)rb * ldp + c];
+  out[c] = s;
+}
+
+// ---- scalar reductions ------------------------------------------------------------------------------
+// res[0] = sum_i w_i^2 ; res[1] = sum_i log L_ii        (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
+                                                   int64_t np, double* __restrict__ res) {
+  __shared__ double r0[4], r1[4];
+  double a = 0.0, b = 0.0;
+  for (int64_t i = threadIdx.x; i < np; i += 256) {
+    a += w[i] * w[i];
+    b += log(L[i * ld + i]);
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    r0[threadIdx.x >> 6] = a;
+    r1[threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    res[0] = ((r0[0] + r0[1]) + r0[2]) + r0[3];
+    res[1] = ((r1[0] + r1[1]) + r1[2]) + r1[3];
+  }
+}
+
+// res[j] = 0.5 * sum_tiles partial[tile*stride + j]   (one thread per component, fixed order)
+__global__ void k_grad_reduce(const double* __restrict__ partial, int ntiles, int stride, int d, int dcap,
+                              double* __restrict__ res) {
+  const int j = threadIdx.x;
+  if (j > d) return;
+  const int src = (j == d) ? dcap : j;
+  double s = 0.0;
+  for (int q = 0; q < ntiles; ++q) s += partial[(int64_t)q * stride + src];
+  res[j] = 0.5 * s;
+}
+
+// ---- sweep finalisers -------------------------------------------------------------------------------
+// q = sum of row-tile partials; s = kself - q.  var policy: 0 -> clip(s, floor) keeps NaN (gp.py:465),
+// 1 -> NaN and < floor -> floor (gp.py:487-488).  s_out keeps the raw s for the fantasy scoring.
+__global__ void k_predict_finalize(const double* __restrict__ qpart, int64_t ldq, int nb, int64_t ncols, double kself,
+                                   int policy, double* __restrict__ s_out, double* __restrict__ var_out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  double q = 0.0;
+  for (int rb = 0; rb < nb; ++rb) q += qpart[(int64_t)rb * ldq + c];
+  const double s = kself - q;
+  if (s_out) s_out[c] = s;
+  if (var_out) {
+    double v = s;
+    if (policy == 1 && v != v) v = NOISE_FLOOR;
+    if (v < NOISE_FLOOR) v = NOISE_FLOOR;
+    var_out[c] = v;
+  }
+}
+
+__global__ void k_score_finalize(const double* __restrict__ pv, const double* __restrict__ ps, int64_t ldp, int nzt,
+                                 int64_t m, int64_t ncols, double* __restrict__ wipv, double* __restrict__ wipstd) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  double a = 0.0, b = 0.0;
+  for (int z = 0; z < nzt; ++z) {
+    a += pv[c * ldp + z];
+    b += ps[c * ldp + z];
+  }
+  if (wipv) wipv[c] = a / (double)m;
+  if (wipstd) wipstd[c] = b / (double)m;
+}
+
+// argmin with first-occurrence tie-break (jnp.argmin, acquisition.py:397); NaN counts as minimal.
+__global__ __launch_bounds__(1024) void k_argmin(const double* __restrict__ v, int64_t n, double* __restrict__ best_val,
+                                                 int64_t* __restrict__ best_idx) {
+  __shared__ double sv[1024];
+  __shared__ int64_t si[1024];
+  double bv = 0.0;
+  int64_t bi = -1;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double x = v[i];
+    const bool xnan = (x != x);
+    const bool bnan = (bi >= 0) && (bv != bv);
+    if (bi < 0 || (!bnan && (xnan || x < bv))) {
+      bv = x;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double x = sv[threadIdx.x + o];
+      const int64_t xi = si[threadIdx.x + o];
+      const double b = sv[threadIdx.x];
+      const int64_t bi2 = si[threadIdx.x];
+      bool take = false;
+      if (xi >= 0) {
+        if (bi2 < 0) take = true;
+        else {
+          const bool xnan = (x != x), bnan = (b != b);
+          if (xnan && bnan) take = xi < bi2;
+          else if (xnan) take = true;
+          else if (bnan) take = false;
+          else take = (x < b) || (x == b && xi < bi2);
+        }
+      }
+      if (take) {
+        sv[threadIdx.x] = x;
+        si[threadIdx.x] = xi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *best_val = sv[0];
+    *best_idx = si[0];
+  }
+}
+
+// ---- misc ------------------------------------------------------------------------------------------
+__global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// dst[i*ldd + j] = (lower_only && j > i) ? 0 : src[i*lds + j]  for i < rows, j < cols
+__global__ void k_copy2d(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd, int64_t rows,
+                         int64_t cols, int lower_only) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (i < rows && j < cols) dst[i * ldd + j] = (lower_only && j > i) ? 0.0 : src[i * lds + j];
+}
+
+// pad-aware load of a caller-provided N x N lower factor into the padded [[L,0],[0,I]] layout
+__global__ void k_load_padded_lower(const double* __restrict__ src, int64_t n, double* __restrict__ dst, int64_t ld,
+                                    int64_t np) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (i >= np || j >= np) return;
+  double v;
+  if (i < n && j < n) v = (j <= i) ? src[i * n + j] : 0.0;
+  else v = (i == j) ? 1.0 : 0.0;
+  dst[i * ld + j] = v;
+}
+
+// EI / LogEI pointwise scorers (BOBE/acquisition.py:21-75, 226-253, 318-330); mu, var standardised
+__device__ __forceinline__ double norm_pdf(double u) { return exp(-0.5 * u * u) * 0.39894228040143267794; }
+__device__ __forceinline__ double norm_cdf(double u) { return 0.5 * erfc(-u * 0.70710678118654752440); }
+__device__ __forceinline__ double ei_helper(double u) { return norm_pdf(u) + u * norm_cdf(u); }
+__device__ __forceinline__ double log1mexp_tfp(double x) {
+  x = fabs(x);
+  return (x < 0.69314718055994530942) ? log(-expm1(-x)) : log1p(-exp(-x));
+}
+__device__ __forceinline__ double log_ei_helper(double u) {
+  const double bound = -1.0, neg_inv_sqrt_eps = -1e6;
+  if (u > bound) return log(ei_helper(u));
+  const double u_lower = u;
+  const double u_eps = (u_lower < neg_inv_sqrt_eps) ? neg_inv_sqrt_eps : u_lower;
+  const double w = log(fabs(u_eps) * erfcx(-0.70710678118654752440 * u_eps)) + 0.22579135264472743236;
+  const double log_phi_u = -0.5 * (u * u + 1.83787706640934548356);
+  const double second = (u > neg_inv_sqrt_eps) ? log1mexp_tfp(w) : -2.0 * log(fabs(u_lower));
+  return log_phi_u + second;
+}
+// mode 0: EI, 1: LogEI.  out = +EI / +logEI (the reference minimises the negative)
+__global__ void k_ei(const double* __restrict__ mu, const double* __restrict__ var, int64_t n, double best_y, double zeta,
+                     int mode, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = var[i];
+  const double lo = mode ? 1e-18 : 1e-20;
+  if (v < lo) v = lo;
+  const double sigma = sqrt(v);
+  const double u = (mu[i] - zeta - best_y) / sigma;
+  out[i] = mode ? (log_ei_helper(u) + log(sigma)) : (ei_helper(u) * sigma);
+}
+
+}  // namespace bobe

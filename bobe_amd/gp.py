@@ -1,0 +1,473 @@
+"""``GP`` — MI355X-resident counterpart of ``BOBE.gp.GP`` (BOBE/gp.py:199-772).
+
+Same constructor keywords, attributes and methods as the reference class; all O(N^2)/O(N^3)
+arithmetic (kernel assembly, Cholesky, solves, MLL + gradient, batched prediction, fantasy
+variance) runs on the GPU through libbobe_gp.so (include/bobe_gp.h).  Host side keeps only what
+the reference also keeps on the host: y standardisation, priors, bounds, the L-BFGS-B loop.
+
+There is no CPU fallback: constructing a GP without the library or without a HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from . import priors as P
+from .optim import optimize_scipy
+from .utils import get_logger, get_numpy_rng
+
+log = get_logger("gp")
+
+safe_noise_floor = 1e-12  # BOBE/gp.py:16
+
+KERNEL_IDS = {"rbf": 0, "matern": 1}
+
+
+def _tofloat(x) -> float:
+    return float(np.asarray(x).reshape(-1)[0]) if np.ndim(x) else float(x)
+
+
+class GP:
+    def __init__(self, train_x, train_y, noise=1e-8, kernel="rbf", optimizer="scipy", optimizer_options={},
+                 kernel_variance_bounds=[1e-4, 1e8], lengthscale_bounds=[0.01, 5], lengthscales=None,
+                 kernel_variance=None, kernel_variance_prior=None, lengthscale_prior=None, tausq=None,
+                 tausq_bounds=[1e-4, 1e4], param_names: Optional[List[str]] = None, device: int = 0):
+        """Same keywords as BOBE/gp.py:201-203 plus ``device`` (HIP device index)."""
+        self._lib = _lib.load()
+        self._h = C.c_void_p(0)
+        self.device = int(device)
+        self._setup_training_data(train_x, train_y)
+        self.param_names = param_names if param_names is not None else ["x_" + str(i) for i in range(self.ndim)]
+
+        self.kernel_name = kernel if kernel == "rbf" else "matern"              # gp.py:251
+        self.lengthscales = (np.array(lengthscales, dtype=np.float64).reshape(-1) if lengthscales is not None
+                             else np.ones(self.ndim))
+        self.kernel_variance = float(kernel_variance) if kernel_variance is not None else 1.0
+        self.noise = float(noise)
+
+        _lib.check(self._lib.bobe_gp_create(C.byref(self._h), self.device, KERNEL_IDS[self.kernel_name], self.ndim),
+                   "bobe_gp_create")
+
+        self.optimizer_method = optimizer
+        if optimizer != "scipy":
+            log.warning("only the scipy optimiser is implemented (optax variants are out of scope); using scipy")
+        self.mll_optimize = optimize_scipy
+        self.optimizer_options = optimizer_options
+
+        self.lengthscale_bounds = lengthscale_bounds
+        self.kernel_variance_bounds = kernel_variance_bounds
+        self.tausq = float(tausq) if tausq is not None else 1.0
+        self.tausq_bounds = tausq_bounds
+
+        self._setup_kernel_variance_prior(kernel_variance_prior)
+        self._setup_lengthscale_prior(lengthscale_prior)
+        self._setup_optimization_parameters()
+
+        self._push_data()
+        self.recompute_cholesky()                                               # gp.py:257-260
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._lib.bobe_gp_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ data
+    def _setup_training_data(self, train_x, train_y):
+        """BOBE/gp.py:283-307."""
+        train_x = np.asarray(train_x, dtype=np.float64)
+        train_y = np.asarray(train_y, dtype=np.float64)
+        if train_x.shape[0] != train_y.shape[0]:
+            raise ValueError("train_x and train_y must have the same number of points")
+        if train_y.ndim != 2:
+            train_y = train_y.reshape(-1, 1)
+        if train_x.ndim != 2:
+            raise ValueError("train_x must be 2D")
+        self.ndim = train_x.shape[1]
+        self.y_mean = float(np.mean(train_y)) if train_y.size > 0 else 0.0
+        self.y_std = float(np.std(train_y)) if train_y.size > 0 else 1.0
+        if self.y_std == 0:
+            log.warning("Training targets have zero variance. Setting std to 1.0 to avoid division by zero.")
+            self.y_std = 1.0
+        self.train_x = np.array(train_x)
+        self.train_y = (train_y - self.y_mean) / self.y_std
+
+    def _push_data(self):
+        x = _lib.as_f64(self.train_x)
+        y = _lib.as_f64(self.train_y).reshape(-1)
+        _lib.check(self._lib.bobe_gp_set_data(self._h, _lib.ptr(x), _lib.ptr(y), x.shape[0]), "bobe_gp_set_data")
+
+    def _push_hyper(self):
+        ls = _lib.as_f64(self.lengthscales).reshape(-1)
+        _lib.check(self._lib.bobe_gp_set_hyper(self._h, _lib.ptr(ls), float(self.kernel_variance), float(self.noise)),
+                   "bobe_gp_set_hyper")
+
+    # ------------------------------------------------------------------ priors / bounds
+    def _setup_kernel_variance_prior(self, kernel_variance_prior):
+        """BOBE/gp.py:309-320."""
+        self.kernel_variance_prior_spec = kernel_variance_prior
+        if self.kernel_variance_prior_spec is None:
+            self.kernel_variance_prior_spec = {"name": "Uniform", "low": self.kernel_variance_bounds[0],
+                                               "high": self.kernel_variance_bounds[1]}
+        self.fixed_kernel_variance = (self.kernel_variance_prior_spec == "fixed")
+        self.kernel_variance_prior_dist = (P.Dummy() if self.fixed_kernel_variance
+                                           else P.make_distribution(self.kernel_variance_prior_spec))
+
+    def _setup_lengthscale_prior(self, lengthscale_prior):
+        """BOBE/gp.py:322-337."""
+        self.lengthscale_prior_spec = lengthscale_prior
+        if self.lengthscale_prior_spec is None:
+            self.lengthscale_prior_spec = {"name": "Uniform", "low": self.lengthscale_bounds[0],
+                                           "high": self.lengthscale_bounds[1]}
+        if self.lengthscale_prior_spec == "DSLP":
+            self.lengthscale_prior_dist = P.dslp(self.ndim)
+        elif self.lengthscale_prior_spec == "SAAS":
+            self.lengthscale_prior_dist = None
+        else:
+            self.lengthscale_prior_dist = P.make_distribution(self.lengthscale_prior_spec)
+
+    def _setup_optimization_parameters(self):
+        """BOBE/gp.py:339-355."""
+        self.hyperparam_names = ["lengthscales"]
+        bounds = [self.lengthscale_bounds] * self.ndim
+        if not self.fixed_kernel_variance:
+            self.hyperparam_names.append("kernel_variance")
+            bounds.append(self.kernel_variance_bounds)
+        if self.lengthscale_prior_spec == "SAAS":
+            self.hyperparam_names.append("tausq")
+            bounds.append(self.tausq_bounds)
+        self.hyperparam_bounds = np.log(np.array(bounds, dtype=np.float64).T)
+        self.num_hyperparams = self.hyperparam_bounds.shape[1]
+
+    def prior_func(self, lengthscales, kernel_variance, tausq=None) -> float:
+        """BOBE/gp.py:357-366."""
+        return self._prior_and_grad(lengthscales, kernel_variance, tausq)[0]
+
+    def _prior_and_grad(self, lengthscales, kernel_variance, tausq):
+        """log prior and its derivative wrt (ls, kvar, tausq) (not yet in log space)."""
+        ls = np.asarray(lengthscales, dtype=np.float64)
+        if self.lengthscale_prior_spec == "SAAS":
+            return P.saas_logprob_and_grad(ls, kernel_variance, tausq)
+        lp = float(np.sum(self.kernel_variance_prior_dist.log_prob(kernel_variance)))
+        g_kvar = float(np.sum(self.kernel_variance_prior_dist.dlog_prob(kernel_variance)))
+        lp += float(np.sum(self.lengthscale_prior_dist.log_prob(ls)))
+        g_ls = np.asarray(self.lengthscale_prior_dist.dlog_prob(ls), dtype=np.float64)
+        return lp, g_ls, g_kvar, 0.0
+
+    def _parse_hyperparams(self, log_params):
+        """BOBE/gp.py:368-383."""
+        hp = np.exp(np.asarray(log_params, dtype=np.float64))
+        ls = hp[:self.ndim]
+        if self.fixed_kernel_variance:
+            kvar = self.kernel_variance
+            if "tausq" in self.hyperparam_names:
+                tausq = hp[self.ndim] if len(hp) > self.ndim else self.tausq
+            else:
+                tausq = self.tausq
+        else:
+            kvar = hp[self.ndim]
+            tausq = hp[self.ndim + 1] if len(hp) > self.ndim + 1 else self.tausq
+        return ls, float(kvar), float(tausq)
+
+    # ------------------------------------------------------------------ objective
+    def mll_data(self, lengthscales, kernel_variance, want_grad=True):
+        """Data term of the MLL (gp_mll, gp.py:170-178) and its gradient wrt (log ls, log kvar) on the GPU."""
+        ls = _lib.as_f64(lengthscales).reshape(-1)
+        mll = C.c_double(0.0)
+        grad = np.empty(self.ndim + 1) if want_grad else None
+        st = self._lib.bobe_gp_mll(self._h, _lib.ptr(ls), float(kernel_variance), C.byref(mll), _lib.ptr(grad))
+        _lib.check(st, "bobe_gp_mll")
+        return mll.value, grad
+
+    def neg_mll(self, log_params):
+        """BOBE/gp.py:385-398."""
+        return self.neg_mll_value_and_grad(log_params, want_grad=False)[0]
+
+    def neg_mll_value_and_grad(self, log_params, want_grad=True):
+        """(f, df/dtheta) with f = -(MLL + log prior), theta = log hp — the closure optim.py:306-309 builds."""
+        log_params = np.asarray(log_params, dtype=np.float64)
+        ls, kvar, tausq = self._parse_hyperparams(log_params)
+        mll, g_data = self.mll_data(ls, kvar, want_grad)
+        lp, g_ls, g_kvar, g_tau = self._prior_and_grad(ls, kvar, tausq)
+        val = -(mll + lp)
+        if not want_grad:
+            return val, None
+        grad = np.zeros(len(log_params))
+        grad[:self.ndim] = g_data[:self.ndim] + g_ls * ls                     # chain rule: d/dlog x = x d/dx
+        idx = self.ndim
+        if not self.fixed_kernel_variance:
+            grad[idx] = g_data[self.ndim] + g_kvar * kvar
+            idx += 1
+        if "tausq" in self.hyperparam_names and len(log_params) > idx:
+            grad[idx] = g_tau * tausq
+        return val, -grad
+
+    def fit(self, x0: np.ndarray = None, maxiter: int = 500) -> dict:
+        """BOBE/gp.py:400-437."""
+        if x0 is None:
+            x0 = np.log(self.get_hyperparams())[None, :]
+        x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
+        optimizer_options = dict(self.optimizer_options)
+        best_params_log, best_loss = self.mll_optimize(
+            self.neg_mll_value_and_grad, num_params=self.num_hyperparams, bounds=self.hyperparam_bounds, x0=x0,
+            maxiter=maxiter, n_restarts=x0.shape[0], optimizer_options=optimizer_options)
+        return {"mll": -best_loss, "params": best_params_log}
+
+    def update_hyperparams(self, hyperparams):
+        """BOBE/gp.py:439-448."""
+        ls, kvar, tausq = self._parse_hyperparams(hyperparams)
+        self.lengthscales = np.array(ls)
+        if not self.fixed_kernel_variance:
+            self.kernel_variance = kvar
+        self.tausq = tausq
+        self.recompute_cholesky()
+
+    def recompute_cholesky(self):
+        """BOBE/gp.py:544-550 — K, L, alpha on the GPU.  Not-PD leaves NaNs, like XLA."""
+        self._push_hyper()
+        st = _lib.check(self._lib.bobe_gp_factor(self._h), "bobe_gp_factor")
+        self._chol_cache = None
+        self._alpha_cache = None
+        self.not_pd = (st == _lib.BOBE_NOT_PD)
+
+    # ------------------------------------------------------------------ state on the host (lazy)
+    @property
+    def cholesky(self) -> np.ndarray:
+        """GP.cholesky (gp.py:259): N x N lower factor, fetched from the GPU on demand."""
+        if self._chol_cache is None:
+            n = self.npoints
+            L = np.empty((n, n))
+            _lib.check(self._lib.bobe_gp_get_chol(self._h, _lib.ptr(L), None), "bobe_gp_get_chol")
+            self._chol_cache = L
+        return self._chol_cache
+
+    @property
+    def alphas(self) -> np.ndarray:
+        """GP.alphas (gp.py:260): (N, 1)."""
+        if self._alpha_cache is None:
+            a = np.empty(self.npoints)
+            _lib.check(self._lib.bobe_gp_get_chol(self._h, None, _lib.ptr(a)), "bobe_gp_get_chol")
+            self._alpha_cache = a.reshape(-1, 1)
+        return self._alpha_cache
+
+    # ------------------------------------------------------------------ kernel
+    def kernel(self, xa, xb, lengthscales=None, kernel_variance=None, noise=None, include_noise=True):
+        """GP.kernel(xa, xb, ls, kvar, noise, include_noise) (gp.py:124-168; call site acquisition.py:388).
+
+        Evaluated on the GPU with the hyper-parameters passed (defaults: the GP's own)."""
+        xa = _lib.as_f64(np.atleast_2d(xa))
+        xb = _lib.as_f64(np.atleast_2d(xb))
+        ls = _lib.as_f64(lengthscales if lengthscales is not None else self.lengthscales).reshape(-1)
+        kvar = float(kernel_variance if kernel_variance is not None else self.kernel_variance)
+        nz = float(noise if noise is not None else self.noise)
+        out = np.empty((xa.shape[0], xb.shape[0]))
+        _lib.check(self._lib.bobe_gp_kernel(self._h, _lib.ptr(xa), xa.shape[0], _lib.ptr(xb), xb.shape[0],
+                                            _lib.ptr(ls), kvar, nz, 1 if include_noise else 0, _lib.ptr(out)),
+                   "bobe_gp_kernel")
+        return out
+
+    # ------------------------------------------------------------------ prediction
+    def _predict(self, x, want_mean, want_var, policy):
+        x = _lib.as_f64(np.atleast_2d(x))
+        c = x.shape[0]
+        mean = np.empty(c) if want_mean else None
+        var = np.empty(c) if want_var else None
+        _lib.check(self._lib.bobe_gp_predict(self._h, _lib.ptr(x), c, _lib.ptr(mean), _lib.ptr(var), policy),
+                   "bobe_gp_predict")
+        return mean, var
+
+    def predict_mean_batched(self, x):
+        """BOBE/gp.py:450-457, 468-470."""
+        m, _ = self._predict(x, True, False, 0)
+        return m * self.y_std + self.y_mean
+
+    def predict_mean_single(self, x):
+        return self.predict_mean_batched(x)[0]
+
+    def predict_var_batched(self, x):
+        """BOBE/gp.py:459-466, 472-474 (clip keeps NaN)."""
+        _, v = self._predict(x, False, True, 0)
+        return self.y_std ** 2 * v
+
+    def predict_var_single(self, x):
+        return self.predict_var_batched(x)[0]
+
+    def predict_batched(self, x):
+        """BOBE/gp.py:476-493 — standardised (mean, var), NaN / < 1e-12 -> 1e-12."""
+        return self._predict(x, True, True, 1)
+
+    def predict_single(self, x):
+        m, v = self.predict_batched(x)
+        return m[0], v[0:1]
+
+    # ------------------------------------------------------------------ update
+    def update(self, new_x, new_y):
+        """BOBE/gp.py:495-541 — duplicate filter, re-standardise, full refactor."""
+        new_x = np.atleast_2d(np.asarray(new_x, dtype=np.float64))
+        new_y = np.atleast_2d(np.asarray(new_y, dtype=np.float64))
+        pts, vals = [], []
+        for i in range(new_x.shape[0]):
+            if np.any(np.all(np.isclose(self.train_x, new_x[i], atol=1e-6, rtol=1e-4), axis=1)):
+                log.debug(f"Point {new_x[i]} already exists in the training set, not updating")
+            else:
+                pts.append(new_x[i])
+                vals.append(new_y[i])
+        if pts:
+            self.train_x = np.vstack([self.train_x, np.array(pts)])
+            y_orig = np.vstack([self.train_y * self.y_std + self.y_mean, np.array(vals).reshape(-1, 1)])
+            self.y_mean = float(np.mean(y_orig))
+            self.y_std = float(np.std(y_orig))
+            if self.y_std == 0:
+                log.warning("Training targets have zero variance. Setting std to 1.0 to avoid division by zero.")
+                self.y_std = 1.0
+            self.train_y = (y_orig - self.y_mean) / self.y_std
+            self._push_data()
+            self.recompute_cholesky()
+
+    # ------------------------------------------------------------------ fantasy variance / sweep
+    def fantasy_var(self, new_x, mc_points, k_train_mc=None):
+        """BOBE/gp.py:552-576.  ``k_train_mc`` is accepted for signature parity and recomputed on the GPU.
+        ``new_x`` may hold several candidates; the result is then (C, M)."""
+        new_x = _lib.as_f64(np.atleast_2d(new_x))
+        z = _lib.as_f64(np.atleast_2d(mc_points))
+        out = np.empty((new_x.shape[0], z.shape[0]))
+        _lib.check(self._lib.bobe_gp_fantasy_var(self._h, _lib.ptr(new_x), new_x.shape[0], _lib.ptr(z), z.shape[0],
+                                                 float(self.y_std), _lib.ptr(out)), "bobe_gp_fantasy_var")
+        return out[0] if out.shape[0] == 1 else out
+
+    def wip_sweep(self, candidates, mc_points, want_mean_var=False):
+        """All-candidate WIPV / WIPStd scores (acquisition.py:385-398 + 438-465) in one GPU call.
+
+        ``candidates`` / ``mc_points`` may be NumPy arrays or torch CUDA tensors (no copy then).
+        Returns dict(wipv, wipstd, argmin_v, min_v, argmin_s, min_s[, mean, var])."""
+        dev = hasattr(candidates, "data_ptr")
+        cand = candidates if dev else _lib.as_f64(np.atleast_2d(candidates))
+        z = mc_points if hasattr(mc_points, "data_ptr") else _lib.as_f64(np.atleast_2d(mc_points))
+        c, m = int(cand.shape[0]), int(z.shape[0])
+        wipv, wipstd = np.empty(c), np.empty(c)
+        mean = np.empty(c) if want_mean_var else None
+        var = np.empty(c) if want_mean_var else None
+        av, asd = C.c_int64(-1), C.c_int64(-1)
+        mv, ms = C.c_double(0.0), C.c_double(0.0)
+        _lib.check(self._lib.bobe_gp_wip_sweep(self._h, _lib.ptr(cand), c, _lib.ptr(z), m, float(self.y_std),
+                                               _lib.ptr(wipv), _lib.ptr(wipstd), _lib.ptr(mean), _lib.ptr(var),
+                                               C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)),
+                   "bobe_gp_wip_sweep")
+        out = {"wipv": wipv, "wipstd": wipstd, "argmin_v": av.value, "min_v": mv.value, "argmin_s": asd.value,
+               "min_s": ms.value}
+        if want_mean_var:
+            out["mean"], out["var"] = mean, var
+        return out
+
+    def acq_ei(self, x, best_y, zeta=0.0, log_ei=False):
+        """+EI / +log EI at x (acquisition.py:226-253, 318-330), standardised units."""
+        x = _lib.as_f64(np.atleast_2d(x))
+        out = np.empty(x.shape[0])
+        _lib.check(self._lib.bobe_gp_acq_ei(self._h, _lib.ptr(x), x.shape[0], float(best_y), float(zeta),
+                                            1 if log_ei else 0, _lib.ptr(out)), "bobe_gp_acq_ei")
+        return out
+
+    def get_random_point(self, rng=None, nstd=None):
+        """BOBE/gp.py:578-585."""
+        rng = rng if rng is not None else get_numpy_rng()
+        return rng.uniform(0, 1, size=self.train_x.shape[1])
+
+    # ------------------------------------------------------------------ state (gp.py:587-750)
+    def state_dict(self):
+        """Same keys as BOBE/gp.py:597-634 (npz-interchangeable)."""
+        return {
+            "train_x": np.array(self.train_x),
+            "train_y": np.array(self.train_y * self.y_std + self.y_mean),
+            "lengthscales": np.array(self.lengthscales),
+            "kernel_variance": float(self.kernel_variance),
+            "noise": float(self.noise),
+            "tausq": float(self.tausq),
+            "y_mean": float(self.y_mean),
+            "y_std": float(self.y_std),
+            "kernel_name": self.kernel_name,
+            "lengthscale_prior_spec": self.lengthscale_prior_spec,
+            "kernel_variance_prior_spec": self.kernel_variance_prior_spec,
+            "fixed_kernel_variance": self.fixed_kernel_variance,
+            "optimizer_method": self.optimizer_method,
+            "optimizer_options": self.optimizer_options,
+            "lengthscale_bounds": self.lengthscale_bounds,
+            "kernel_variance_bounds": self.kernel_variance_bounds,
+            "tausq_bounds": self.tausq_bounds,
+            "cholesky": np.array(self.cholesky),
+            "alphas": np.array(self.alphas),
+            "ndim": self.ndim,
+            "gp_class": "GP",
+        }
+
+    @classmethod
+    def from_state_dict(cls, state, device: int = 0):
+        """BOBE/gp.py:638-677 — L and alpha are restored on the GPU without refactorising."""
+        def plain(v):
+            return v.item() if isinstance(v, np.ndarray) and v.shape == () else v
+        gp = cls(train_x=state["train_x"], train_y=state["train_y"], noise=plain(state["noise"]),
+                 kernel=plain(state["kernel_name"]), optimizer=plain(state["optimizer_method"]),
+                 optimizer_options=plain(state["optimizer_options"]), lengthscales=state["lengthscales"],
+                 kernel_variance=plain(state["kernel_variance"]),
+                 lengthscale_bounds=list(np.asarray(state["lengthscale_bounds"]).tolist()),
+                 kernel_variance_bounds=list(np.asarray(state["kernel_variance_bounds"]).tolist()),
+                 kernel_variance_prior=plain(state.get("kernel_variance_prior_spec")),
+                 lengthscale_prior=plain(state.get("lengthscale_prior_spec")),
+                 tausq=plain(state.get("tausq", 1.0)),
+                 tausq_bounds=list(np.asarray(state.get("tausq_bounds", [1e-4, 1e4])).tolist()), device=device)
+        L, a = state.get("cholesky"), state.get("alphas")
+        if L is not None and a is not None and np.all(np.isfinite(np.asarray(L, dtype=np.float64))):
+            L = _lib.as_f64(L)
+            a = _lib.as_f64(a).reshape(-1)
+            _lib.check(gp._lib.bobe_gp_set_chol(gp._h, _lib.ptr(L), _lib.ptr(a)), "bobe_gp_set_chol")
+            gp._chol_cache, gp._alpha_cache = None, None
+        return gp
+
+    @classmethod
+    def load(cls, filename, **kwargs):
+        """BOBE/gp.py:679-721."""
+        if not filename.endswith(".npz"):
+            filename += ".npz"
+        data = np.load(filename, allow_pickle=True)
+        state = {}
+        for key in data.files:
+            value = data[key]
+            state[key] = value.item() if isinstance(value, np.ndarray) and value.shape == () else value
+        state.update(kwargs)
+        return cls.from_state_dict(state)
+
+    def save(self, filename="gp"):
+        """BOBE/gp.py:723-737."""
+        if not filename.endswith(".npz"):
+            filename += ".npz"
+        np.savez(filename, **self.state_dict())
+
+    def copy(self):
+        """BOBE/gp.py:740-750."""
+        return self.__class__.from_state_dict(self.state_dict(), device=self.device)
+
+    @property
+    def npoints(self):
+        return self.train_x.shape[0]
+
+    def get_hyperparams(self):
+        """BOBE/gp.py:756-762."""
+        hp = np.array(self.lengthscales, dtype=np.float64)
+        if not self.fixed_kernel_variance:
+            hp = np.hstack([hp, self.kernel_variance])
+        if self.lengthscale_prior_spec == "SAAS":
+            hp = np.hstack([hp, self.tausq])
+        return hp
+
+    def hyperparams_dict(self):
+        """BOBE/gp.py:764-772."""
+        ls_str = {name: f"{float(val):.4f}" for name, val in zip(self.param_names, self.lengthscales)}
+        out = {"lengthscales": ls_str, "kernel_variance": f"{float(self.kernel_variance):.4f}"}
+        if "tausq" in self.hyperparam_names:
+            out["tausq"] = f"{float(self.tausq):.4f}"
+        return out

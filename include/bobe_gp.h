@@ -1,0 +1,134 @@
+/* bobe_gp.h — C ABI of libbobe_gp.so, the MI355X (gfx950) GP-surrogate engine for BOBE.
+ *
+ * Drop-in boundary for the hot path of Ameek94/BOBE (BOBE/gp.py + the integrated-variance half of
+ * BOBE/acquisition.py).  The reference has no FFI of its own (it is pure Python on jax); the boundary
+ * it would bind is the method set of its `GP` class, so every entry point below names the reference
+ * method(s) it replaces (file:line relative to the reference tree).  bobe_amd/gp.py is the ctypes
+ * binding that presents those methods again; INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions
+ *   - all arrays are C-contiguous fp64 (int64 for indices); matrices are row-major;
+ *   - every data pointer may be HOST memory (NumPy) or DEVICE memory (hipMalloc / torch.cuda
+ *     tensor); the library detects which and copies only when needed;
+ *   - y / alpha / mean / var are in STANDARDISED units (the wrapper applies y_mean, y_std exactly
+ *     where gp.py does: gp.py:456, 466, 576);
+ *   - return value: 0 ok; > 0 numerical condition (BOBE_NOT_PD: outputs are NaN, like XLA's
+ *     Cholesky, so np.isfinite filters such as optim.py:328,341 keep working); < 0 usage / HIP error,
+ *     text in bobe_last_error().  Nothing throws or aborts across this boundary;
+ *   - a handle is not thread-safe; distinct handles are independent (own stream).
+ *   - limits: d <= 32.
+ */
+#ifndef BOBE_GP_H
+#define BOBE_GP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bobe_gp bobe_gp_t;
+
+#define BOBE_OK 0
+#define BOBE_NOT_PD 1
+#define BOBE_ERR_ARG (-1)
+#define BOBE_ERR_HIP (-2)
+#define BOBE_ERR_STATE (-3)
+
+#define BOBE_KERNEL_RBF 0    /* gp.py:124-154 */
+#define BOBE_KERNEL_MATERN 1 /* gp.py:156-168 */
+
+/* version / build info ("bobe_gp <ver> gfx950") */
+const char* bobe_version(void);
+/* thread-local text of the last error on this thread */
+const char* bobe_last_error(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int bobe_device_count(void);
+
+/* GP.__init__ (gp.py:201-281): handle for one GP on one GPU.  kernel = BOBE_KERNEL_*; d = ndim. */
+int bobe_gp_create(bobe_gp_t** out, int device, int kernel, int d);
+void bobe_gp_destroy(bobe_gp_t* gp);
+
+/* The HIP stream all work of this handle is issued on (void* = hipStream_t).  set: adopt a caller
+ * stream (e.g. torch.cuda.current_stream().cuda_stream) so caller-side events see the kernels. */
+void* bobe_gp_get_stream(bobe_gp_t* gp);
+int bobe_gp_set_stream(bobe_gp_t* gp, void* hip_stream);
+/* block until everything issued on the handle's stream has finished */
+int bobe_gp_sync(bobe_gp_t* gp);
+
+/* GP._setup_training_data / GP.update data part (gp.py:283-307, 529-539): X is N x d, y is the
+ * already-standardised target vector (N).  Invalidates the factorisation. */
+int bobe_gp_set_data(bobe_gp_t* gp, const double* X, const double* y_standardised, int64_t N);
+
+/* GP.lengthscales / kernel_variance / noise assignment (gp.py:253-255, 444-447).  Does NOT refactor. */
+int bobe_gp_set_hyper(bobe_gp_t* gp, const double* lengthscales, double kernel_variance, double noise);
+
+/* GP.recompute_cholesky (gp.py:544-550): K = k(X,X)+noise I, L = chol(K), alpha = K^-1 y, and the
+ * inverse factor used by every later call.  BOBE_NOT_PD -> L, alpha are NaN. */
+int bobe_gp_factor(bobe_gp_t* gp);
+
+/* gp_mll (gp.py:170-178) + its gradient, i.e. the data term of GP.neg_mll (gp.py:385-398) and of the
+ * jax.value_and_grad closure of optim.py:306-309, at the given hyper-parameters (noise from
+ * set_hyper).  *mll = -1/2 y^T K^-1 y - sum log L_ii - N/2 log 2 pi.  grad (may be NULL) has d+1
+ * entries: d mll / d log ls_j (j < d), d mll / d log kernel_variance.  Does not disturb the state
+ * left by bobe_gp_factor.  BOBE_NOT_PD -> *mll and grad are NaN. */
+int bobe_gp_mll(bobe_gp_t* gp, const double* lengthscales, double kernel_variance, double* mll, double* grad);
+
+/* GP.predict_mean_batched / predict_var_batched / predict_batched (gp.py:450-493) for C query points
+ * Xq (C x d).  mean[c] = k_c^T alpha; var[c] = kvar + noise - |L^-1 k_c|^2 with
+ *   nan_policy 0: clip(var, 1e-12) keeps NaN (predict_var_single, gp.py:465)
+ *   nan_policy 1: NaN and < 1e-12 -> 1e-12     (predict_single,     gp.py:487-488)
+ * either output may be NULL. */
+int bobe_gp_predict(bobe_gp_t* gp, const double* Xq, int64_t C, double* mean, double* var, int nan_policy);
+
+/* WeightedIntegratedPosteriorBase.get_next_point sweep (acquisition.py:385-398) with WIPV.fun /
+ * WIPStd.fun (acquisition.py:438-440, 463-465) over GP.fantasy_var (gp.py:552-576), evaluated for
+ * EVERY candidate (C x d) against the integration points Z (M x d) in the algebraically identical
+ * rank-1 form.  wipv[c] = mean_z var+(z|c) * y_std^2, wipstd[c] = mean_z sqrt(var+ * y_std^2).
+ * argmin_* / min_* follow jnp.argmin (first occurrence).  mean / var: as bobe_gp_predict with
+ * nan_policy 1.  Any output pointer may be NULL. */
+int bobe_gp_wip_sweep(bobe_gp_t* gp, const double* cand, int64_t C, const double* Z, int64_t M, double y_std,
+                      double* wipv, double* wipstd, double* mean, double* var, int64_t* argmin_v, double* min_v,
+                      int64_t* argmin_s, double* min_s);
+
+/* GP.fantasy_var (gp.py:552-576) for C candidates at once: out is C x M, out[c][z] = var+(z|c)*y_std^2. */
+int bobe_gp_fantasy_var(bobe_gp_t* gp, const double* cand, int64_t C, const double* Z, int64_t M, double y_std,
+                        double* out);
+
+/* EI.fun / LogEI.fun (acquisition.py:226-253, 318-330) for C points: out[c] = +EI (mode 0) or
+ * +log EI (mode 1); best_y, zeta in standardised units. */
+int bobe_gp_acq_ei(bobe_gp_t* gp, const double* Xq, int64_t C, double best_y, double zeta, int mode, double* out);
+
+/* GP.kernel(xa, xb, ls, kvar, noise, include_noise) (gp.py:124-168; call site acquisition.py:388).
+ * lengthscales == NULL uses the handle's current hyper-parameters (kernel_variance / noise arguments
+ * are then ignored).  The factorised state is not touched.  out is nA x nB. */
+int bobe_gp_kernel(bobe_gp_t* gp, const double* A, int64_t nA, const double* B, int64_t nB,
+                   const double* lengthscales, double kernel_variance, double noise, int include_noise, double* out);
+
+/* GP.cholesky / GP.alphas (gp.py:259-260; state_dict keys gp.py:626-627): L is N x N lower with
+ * zeros above the diagonal, alpha has N entries.  Either may be NULL. */
+int bobe_gp_get_chol(bobe_gp_t* gp, double* L, double* alpha);
+/* GP.from_state_dict restore without refactorisation (gp.py:671-675). */
+int bobe_gp_set_chol(bobe_gp_t* gp, const double* L, const double* alpha);
+
+/* number of training points / padded leading dimension currently held */
+int64_t bobe_gp_npoints(bobe_gp_t* gp);
+
+/* test / bench hooks (not part of the reference surface) -------------------------------------- */
+/* C[M x N] = sum_k A(m,k) B(n,k) through the fp64 MFMA tile core.  layout 0: element (r,k) at
+ * p[r*ld+k]; layout 1: at p[k*ld+r].  M, N multiples of 128, K multiple of 16.  Device or host ptrs. */
+int bobe_debug_gemm(int device, int layoutA, int layoutB, int64_t M, int64_t N, int64_t K, const double* A,
+                    int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc);
+/* K^-1 (N x N, full symmetric) from the current factorisation — used by the parity tests */
+int bobe_debug_kinv(bobe_gp_t* gp, double* Kinv);
+/* L^-1 (N x N lower) from the current factorisation */
+int bobe_debug_linv(bobe_gp_t* gp, double* Linv);
+/* run only the Cholesky factorisation of the current K `reps` times and return the mean device
+ * time per factorisation in milliseconds (HIP events on the handle's stream) */
+int bobe_debug_time_potrf(bobe_gp_t* gp, int reps, double* ms);
+/* candidate chunk size of the sweep (multiple of 128); 0 keeps the default */
+int bobe_gp_set_chunk(bobe_gp_t* gp, int64_t chunk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
