@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Headline benchmark: GP fit + acquisition cycles/sec at N=4096, d=8, 65 536 candidates (BASELINE.json).
+
+One *cycle* (SURVEY.md 8d / BASELINE.md section 2) =
+    20 x [K(X,X) assembly + Cholesky + alpha + log-marginal-likelihood + analytic gradient]
+       at the fixed theta schedule  (bobe_gp_mll)
+  + 1 x refactor at the last theta    (bobe_gp_factor)
+  + 1 x sweep: posterior mean & variance of all C candidates, WIPV and WIPStd scores against the
+        M = 512 integration points, argmin of both  (bobe_gp_wip_sweep)
+All inputs are resident in HBM before the timed region; outputs stay in HBM (only the d+2 MLL
+scalars and the two argmins cross PCIe, as they do in the BO loop).
+
+Multi-GPU (one process per GPU, torch.distributed / RCCL): weak scaling.  Every rank holds the full
+factor and runs the 20 evaluations of its own restart (the reference shards restarts over ranks,
+BOBE/pool.py:298-326), sweeps its own shard of the N_gpus x C candidate set, and the ranks exchange
+(min score, global index) with one all-gather; value = cycles completed by all ranks / wall time.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD spec; = 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="headline", choices=["tiny", "small", "headline"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-class", default="trimul", help="kernel class timed with HIP events for the roofline")
+    return ap.parse_args()
+
+
+def cpu_baseline(X, y, cand, Z, thetas, noise, sample_c=2048):
+    """Oracle ("port") timed on the host cores on a bounded sample of the same cycle; extrapolated linearly."""
+    from oracle import bobe_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        nthreads = os.cpu_count() or 1
+    d = X.shape[1]
+    t0 = time.perf_counter()
+    O.cycle_value_and_grad(X, y, np.exp(thetas[0, :d]), float(np.exp(thetas[0, d])), noise)
+    t_vg = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gp = O.OracleGP(X, y, noise=noise, kernel="rbf", lengthscales=np.exp(thetas[-1, :d]),
+                    kernel_variance=float(np.exp(thetas[-1, d])))
+    t_fac = time.perf_counter() - t0
+    sc = min(sample_c, cand.shape[0])
+    t0 = time.perf_counter()
+    O.wip_sweep(gp, cand[:sc], Z, chunk=sc)
+    t_sw = time.perf_counter() - t0
+    cyc = len(thetas) * t_vg + t_fac + t_sw * (cand.shape[0] / sc)
+    return {"value": 1.0 / cyc, "unit": "cycles/s", "cores": int(nthreads), "kind": "port",
+            "sample": f"1 of {len(thetas)} value+grad ({t_vg:.2f}s), 1 refactor ({t_fac:.2f}s), "
+                      f"{sc} of {cand.shape[0]} candidates ({t_sw:.2f}s); extrapolated linearly; "
+                      f"NumPy/SciPy-OpenBLAS fp64"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from bobe_amd import _lib
+    from bobe_amd.gp import GP
+    from bobe_amd.synthetic import CONFIGS, synthetic_problem, theta_schedule
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    N, d, Cn, M = CONFIGS[args.config]
+    noise = 1e-6
+    X, y, cand, Z = synthetic_problem(N, d, Cn, M, noise=noise, cand_offset=rank * Cn)
+    thetas = theta_schedule(d)
+    gp = GP(X, y, noise=noise, kernel="rbf", lengthscales=np.full(d, 0.6), kernel_variance=1.0, device=local)
+    lib, h = gp._lib, gp._h
+    # inputs resident in HBM; outputs stay in HBM
+    cand_d = torch.from_numpy(cand).to(dev)
+    Z_d = torch.from_numpy(Z).to(dev)
+    out_mean = torch.empty(Cn, dtype=torch.float64, device=dev)
+    out_var = torch.empty_like(out_mean)
+    out_wipv = torch.empty_like(out_mean)
+    out_wipstd = torch.empty_like(out_mean)
+    torch.cuda.synchronize()
+
+    ls_last = np.ascontiguousarray(np.exp(thetas[-1, :d]))
+    kv_last = float(np.exp(thetas[-1, d]))
+    grad = np.empty(d + 1)
+    mll = C.c_double()
+    av, asd, mv, ms = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+    last = {}
+
+    def cycle():
+        best = (-np.inf, None)
+        for th in thetas:
+            ls = np.ascontiguousarray(np.exp(th[:d]))
+            _lib.check(lib.bobe_gp_mll(h, _lib.ptr(ls), float(np.exp(th[d])), C.byref(mll), _lib.ptr(grad)), "mll")
+            if mll.value > best[0]:
+                best = (mll.value, th)
+        _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")
+        _lib.check(lib.bobe_gp_factor(h), "factor")
+        _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
+                                         _lib.ptr(out_wipstd), _lib.ptr(out_mean), _lib.ptr(out_var),
+                                         C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
+        gidx, gmin = rank * Cn + asd.value, ms.value
+        if world > 1:   # the path's one exchange step: all-gather of (min score, global index, best mll)
+            mine = torch.tensor([ms.value, float(rank * Cn + asd.value), best[0]], dtype=torch.float64, device=dev)
+            allv = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            allv = torch.stack(allv).cpu().numpy()
+            # argmin with lowest-global-index tie-break (jnp.argmin first-occurrence semantics)
+            order = np.lexsort((allv[:, 1], allv[:, 0]))
+            gmin, gidx = float(allv[order[0], 0]), int(allv[order[0], 1])
+        last.update(mll=mll.value, argmin=int(gidx), min_wipstd=float(gmin))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lib.bobe_gp_sync(h)
+
+    for _ in range(args.warmup):
+        cycle()
+    prof_tag = _lib.PROF[args.profile_class]
+    lib.bobe_gp_profile_select(h, prof_tag)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cycle()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tot_ms, launches = C.c_double(), C.c_int64()
+    lib.bobe_gp_profile_read(h, C.byref(tot_ms), C.byref(launches))
+    lib.bobe_gp_profile_select(h, 0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        # Cholesky GF/s: mean device time of the factorisation alone (HIP events on the handle's stream)
+        potrf_ms = C.c_double()
+        lib.bobe_debug_time_potrf(h, 3, C.byref(potrf_ms))
+        Np = (N + 127) // 128 * 128
+        chunk = 2048
+        flops_per_launch = {"trimul": float(N) * N * min(chunk, Cn),          # TRSM-equivalent N^2 per candidate
+                            "cross": 2.0 * min(chunk, Cn) * M * N,
+                            "syrk": None, "lauum": 2.0 * N ** 3 / 3.0}.get(args.profile_class)
+        roof = None
+        if flops_per_launch and launches.value:
+            avg_s = tot_ms.value * 1e-3 / launches.value
+            ach = flops_per_launch / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": "k_" + args.profile_class, "achieved": ach,
+                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_ms": avg_s * 1e3, "launches": int(launches.value),
+                    "flops_per_launch": flops_per_launch}
+        out = {
+            "metric": "GP fit+acquisition cycles/sec at N=4096 d=8, 65536 cands; Cholesky GF/s",
+            "value": world * args.steps / elapsed, "unit": "cycles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic RBF GP N={N} d={d}, {Cn} candidates per GPU, M={M}, fp64 "
+                                   f"(BASELINE.json configs[{2 if args.config == 'headline' else 1}])",
+                       "N": N, "d": d, "candidates_per_gpu": Cn, "M": M, "evals_per_cycle": len(thetas),
+                       "parallelism": f"candidate-sharded x{world}"},
+            "cholesky_gflops": (N ** 3 / 3.0) / (potrf_ms.value * 1e-3) / 1e9,
+            "cholesky_ms": potrf_ms.value,
+            "check": last,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(X, y, cand, Z, thetas, noise)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libbobe_gp.so")
 
 BOBE_OK = 0
 BOBE_NOT_PD = 1
+PROF = {"potf2": 1, "trsm": 2, "syrk": 3, "trtri": 4, "lauum": 5, "trimul": 6, "cross": 7, "kxx": 8}
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
@@ -56,6 +57,9 @@ SIGNATURES = [
     ("bobe_debug_linv", C.c_int, [C.c_void_p, C.c_void_p]),
     ("bobe_debug_time_potrf", C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     ("bobe_gp_set_chunk", C.c_int, [C.c_void_p, C.c_int64]),
+    ("bobe_gp_profile_select", C.c_int, [C.c_void_p, C.c_int]),
+    ("bobe_gp_profile_read", C.c_int, [C.c_void_p, c_double_p, c_int64_p]),
+    ("bobe_debug_mfma_peak", C.c_int, [C.c_int, C.c_int, c_double_p]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -139,6 +139,26 @@ struct bobe_gp {
   std::vector<Depth> depths;
   double* h_res = nullptr;  // pinned, 128 doubles
 
+  // optional per-kernel-class timing with HIP events on the handle's stream (bobe_gp_profile_*)
+  int prof_tag = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  void prof_begin(int tag) {
+    if (tag != prof_tag) return;
+    if (prof_used == prof_events.size()) {
+      hipEvent_t a, b;
+      HIPCHK(hipEventCreate(&a));
+      HIPCHK(hipEventCreate(&b));
+      prof_events.emplace_back(a, b);
+    }
+    HIPCHK(hipEventRecord(prof_events[prof_used].first, stream));
+  }
+  void prof_end(int tag) {
+    if (tag != prof_tag) return;
+    HIPCHK(hipEventRecord(prof_events[prof_used].second, stream));
+    ++prof_used;
+  }
+
   void use() {
     HIPCHK(hipSetDevice(device));
     configure_kernels_once();
@@ -256,21 +276,29 @@ void bobe_gp::kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int
 void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a) {
   const dim3 grid((unsigned)(nb * (nb + 1) / 2));
   const size_t sm = (size_t)2 * h.d * TILE * sizeof(double);
+  prof_begin(BOBE_PROF_KXX);
   if (h.kern == 0)
     hipLaunchKernelGGL((k_kernel_matrix<0, true>), grid, dim3(256), sm, stream, xst, Np, N, xst, Np, N, h, a, Np);
   else
     hipLaunchKernelGGL((k_kernel_matrix<1, true>), grid, dim3(256), sm, stream, xst, Np, N, xst, Np, N, h, a, Np);
+  prof_end(BOBE_PROF_KXX);
   LAUNCH_CHECK();
 }
 
 void bobe_gp::potrf(double* a, double* linv) {
   for (int k = 0; k < nb; ++k) {
+    prof_begin(BOBE_PROF_POTF2);
     hipLaunchKernelGGL(k_potf2_inv<true>, dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
                        static_cast<int*>(info.p));
+    prof_end(BOBE_PROF_POTF2);
     const int rem = nb - k - 1;
     if (rem > 0) {
-      hipLaunchKernelGGL(k_trsm_panel, dim3(rem), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np, k);
-      hipLaunchKernelGGL(k_syrk_trail, dim3(rem * (rem + 1) / 2), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, k);
+      prof_begin(BOBE_PROF_TRSM);
+    hipLaunchKernelGGL(k_trsm_panel, dim3(rem), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np, k);
+    prof_end(BOBE_PROF_TRSM);
+      prof_begin(BOBE_PROF_SYRK);
+    hipLaunchKernelGGL(k_syrk_trail, dim3(rem * (rem + 1) / 2), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, k);
+    prof_end(BOBE_PROF_SYRK);
     }
   }
   LAUNCH_CHECK();
@@ -280,10 +308,12 @@ void bobe_gp::trtri(const double* a, double* linv) {
   for (int dd = (int)depths.size() - 1; dd >= 0; --dd) {
     const Depth& D = depths[dd];
     const TriProb* pr = static_cast<const TriProb*>(probs.p) + D.first;
+    prof_begin(BOBE_PROF_TRTRI);
     hipLaunchKernelGGL(k_trtri_T, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np,
                        Tmp.d(), Np, pr, D.count);
     hipLaunchKernelGGL(k_trtri_R, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, linv, Np, (const double*)Tmp.d(),
                        Np, pr, D.count);
+    prof_end(BOBE_PROF_TRTRI);
   }
   LAUNCH_CHECK();
 }
@@ -388,9 +418,11 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
       hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                          (const double*)part.d(), CH, nb, 0, nc, d_mean + c0);
     }
+    prof_begin(BOBE_PROF_TRIMUL);
     hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
                        (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, (double*)nullptr, (int64_t)0,
                        qpart.d(), CH);
+    prof_end(BOBE_PROF_TRIMUL);
     // s_c for the whole padded chunk (scoring reads padded columns), var only for valid columns
     hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((ncp + 255) / 256)), dim3(256), 0, stream,
                        (const double*)qpart.d(), CH, nb, ncp, kself, policy, sc.d(), (double*)nullptr);
@@ -400,6 +432,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
     if (do_wip) {
       const dim3 grid((unsigned)nzt, (unsigned)(ncp / TILE));
       double* vo = d_fant ? d_fant + c0 * Mp : nullptr;
+      prof_begin(BOBE_PROF_CROSS);
       if (hyp.kern == 0)
         hipLaunchKernelGGL(k_cross_score<0>, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)kXC.d(), CH, nb,
                            (const double*)WZ.d(), Mp, (const double*)CsT.d(), CH, (const double*)ZsT.d(), Mp, M,
@@ -410,6 +443,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
                            (const double*)WZ.d(), Mp, (const double*)CsT.d(), CH, (const double*)ZsT.d(), Mp, M,
                            (const double*)sc.d(), (const double*)basez.d(), hyp, y_std * y_std, pv.d(), ps.d(),
                            (int64_t)nzt, vo, Mp);
+      prof_end(BOBE_PROF_CROSS);
       hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                          (const double*)pv.d(), (const double*)ps.d(), (int64_t)nzt, nzt, M, nc,
                          d_wipv ? d_wipv + c0 : nullptr, d_wipstd ? d_wipstd + c0 : nullptr);
@@ -528,6 +562,10 @@ void bobe_gp_destroy(bobe_gp_t* g) {
                   &g->CsT, &g->ZsT, &g->kXC, &g->kXZ, &g->VZ, &g->WZ, &g->basez, &g->sc, &g->qpart, &g->pv, &g->ps,
                   &g->o_mean, &g->o_var, &g->o_wipv, &g->o_wipstd, &g->o_misc, &g->kin_a, &g->kin_b, &g->kout};
   for (DBuf* b : bufs) b->release();
+  for (auto& pr : g->prof_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
   if (g->h_res) (void)hipHostFree(g->h_res);
   if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
@@ -649,12 +687,14 @@ int bobe_gp_mll(bobe_gp_t* g, const double* ls, double kvar, double* mll, double
   hipLaunchKernelGGL((k_lauum_grad<KE, DC>), dim3(ntiles), dim3(256), GEMM_SMEM_BYTES, g->stream,                   \
                      (const double*)g->Linv2.d(), g->Np, g->nb, g->N, (const double*)g->alpha2.d(),                  \
                      (const double*)g->XsT2.d(), g->Np, h, g->gpart.d(), (double*)nullptr, (int64_t)0)
+    g->prof_begin(BOBE_PROF_LAUUM);
     if (h.kern == 0) {
       if (dcap == 8) LG(0, 8); else if (dcap == 16) LG(0, 16); else LG(0, 32);
     } else {
       if (dcap == 8) LG(1, 8); else if (dcap == 16) LG(1, 16); else LG(1, 32);
     }
 #undef LG
+    g->prof_end(BOBE_PROF_LAUUM);
     hipLaunchKernelGGL(k_grad_reduce, dim3(1), dim3(64), 0, g->stream, (const double*)g->gpart.d(), ntiles, dcap + 1, d,
                        dcap, g->res.d() + 2);
   }
@@ -873,6 +913,78 @@ int bobe_debug_linv(bobe_gp_t* g, double* Linv) {
   g->use();
   copy_out_matrix(g, g->Linv.d(), Linv, 1);
   g->sync();
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_profile_select(bobe_gp_t* g, int tag) {
+  API_BEGIN
+  if (!g) throw Err(BOBE_ERR_ARG, "gp is NULL");
+  g->use();
+  g->sync();
+  g->prof_tag = tag;
+  g->prof_used = 0;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_profile_read(bobe_gp_t* g, double* total_ms, int64_t* launches) {
+  API_BEGIN
+  if (!g || !total_ms || !launches) throw Err(BOBE_ERR_ARG, "NULL argument");
+  g->use();
+  g->sync();
+  double tot = 0.0;
+  for (size_t i = 0; i < g->prof_used; ++i) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, g->prof_events[i].first, g->prof_events[i].second));
+    tot += t;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)g->prof_used;
+  g->prof_used = 0;
+  return BOBE_OK;
+  API_END
+}
+
+// back-to-back v_mfma_f64_16x16x4_f64 on every CU: the ceiling the GEMM-shaped kernels are priced against
+__global__ __launch_bounds__(256) void k_mfma_peak(double* out, int iters) {
+  v4d acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+int bobe_debug_mfma_peak(int device, int waves_per_simd, double* tflops) {
+  API_BEGIN
+  if (!tflops || waves_per_simd < 1 || waves_per_simd > 2) throw Err(BOBE_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  const int blocks = 256 * waves_per_simd, iters = 4000;
+  DBuf o;
+  o.ensure((size_t)blocks * 256 * 8);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, o.d(), 10);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, o.d(), iters);
+  HIPCHK(hipEventRecord(e1, 0));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 8 * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  o.release();
   return BOBE_OK;
   API_END
 }

@@ -125,6 +125,21 @@ int bobe_debug_linv(bobe_gp_t* gp, double* Linv);
 /* run only the Cholesky factorisation of the current K `reps` times and return the mean device
  * time per factorisation in milliseconds (HIP events on the handle's stream) */
 int bobe_debug_time_potrf(bobe_gp_t* gp, int reps, double* ms);
+/* Per-kernel-class device timing with HIP events recorded on the handle's stream around every launch
+ * of the selected class (0 = off).  read() synchronises, returns the summed milliseconds and the
+ * number of launches since the last select()/read(), and resets the counters. */
+#define BOBE_PROF_POTF2 1  /* diagonal-block Cholesky + inverse */
+#define BOBE_PROF_TRSM 2   /* panel solve (GEMM with the inverted diagonal block) */
+#define BOBE_PROF_SYRK 3   /* trailing update of the blocked Cholesky */
+#define BOBE_PROF_TRTRI 4  /* one level of the recursive triangular inverse (two launches) */
+#define BOBE_PROF_LAUUM 5  /* K^-1 = Linv^T Linv fused with the gradient reduction */
+#define BOBE_PROF_TRIMUL 6 /* sweep: V = Linv * K(X, C_chunk) with column sum of squares */
+#define BOBE_PROF_CROSS 7  /* sweep: cross-covariance GEMM + WIPV / WIPStd scoring */
+#define BOBE_PROF_KXX 8    /* K(X,X) assembly */
+int bobe_gp_profile_select(bobe_gp_t* gp, int kernel_class);
+int bobe_gp_profile_read(bobe_gp_t* gp, double* total_ms, int64_t* launches);
+/* back-to-back v_mfma_f64_16x16x4_f64 issue rate on all CUs (1 or 2 waves per SIMD), in TFLOP/s */
+int bobe_debug_mfma_peak(int device, int waves_per_simd, double* tflops);
 /* candidate chunk size of the sweep (multiple of 128); 0 keeps the default */
 int bobe_gp_set_chunk(bobe_gp_t* gp, int64_t chunk);
 

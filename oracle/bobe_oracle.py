@@ -668,26 +668,27 @@ def get_mc_points(mc_samples_x: np.ndarray, mc_points_size: int, rng) -> np.ndar
 
 
 # --------------------------------------------------------------------------------------
-# the benchmark "cycle" on the CPU — used as bench.py's cpu_baseline
+# the benchmark "cycle" on the CPU — bench.py's cpu_baseline leg
 # --------------------------------------------------------------------------------------
-def theta_schedule(d: int, ls_star: float = 0.6, n: int = 20) -> np.ndarray:
-    """theta_k = log ls* + 0.05 k (-1)^k, k = 0..n-1 (all dims equal); log kvar = 0."""
-    th = np.empty((n, d + 1))
-    for k in range(n):
-        th[k, :d] = math.log(ls_star) + 0.05 * k * (-1) ** k
-        th[k, d] = 0.0
-    return th
-
-
-def synthetic_problem(N: int, d: int, C: int, M: int = 512, ls_star: float = 0.6, noise: float = 1e-6):
-    """SURVEY section 8(d) seeded synthetic inputs (shared by bench.py and the parity tests)."""
-    from scipy.stats import qmc
-    rng = np.random.default_rng(1234)
-    X = rng.uniform(0.0, 1.0, (N, d))
-    K = rbf_kernel(X, X, np.full(d, ls_star), 1.0, noise, include_noise=True)
-    L = cholesky(K, lower=True, check_finite=False)
-    y = L @ rng.standard_normal(N)
-    y = (y - y.mean()) / y.std()
-    cand = qmc.Sobol(d, scramble=True, seed=5678).random(C)
-    Z = qmc.Sobol(d, scramble=True, seed=9012).random(M)
-    return X, y, cand, Z
+def cycle_value_and_grad(X, y, ls, kvar, noise):
+    """One value+grad evaluation of the RBF data-term MLL the way a NumPy/LAPACK port does it:
+    dpotrf + dpotrs + dpotri (N^3 flops) and d+1 fused N^2 reductions."""
+    from scipy.linalg import lapack
+    n, d = X.shape
+    Xs = X / ls
+    Kt = kvar * np.exp(-0.5 * dist_sq(Xs, Xs))
+    K = Kt + noise * np.eye(n)
+    L, info = lapack.dpotrf(K, lower=1, clean=1, overwrite_a=0)
+    if info != 0:
+        return float("nan"), np.full(d + 1, np.nan)
+    alpha, _ = lapack.dpotrs(L, y, lower=1)
+    mll = float(-0.5 * y @ alpha - np.sum(np.log(np.diag(L))) - 0.5 * n * LOG_2PI)
+    Kinv, _ = lapack.dpotri(L, lower=1)
+    Kinv = np.tril(Kinv) + np.tril(Kinv, -1).T
+    WK = (np.outer(alpha, alpha) - Kinv) * Kt
+    g = np.empty(d + 1)
+    for j in range(d):
+        diff = Xs[:, j][:, None] - Xs[:, j][None, :]
+        g[j] = 0.5 * np.sum(WK * diff * diff)
+    g[d] = 0.5 * np.sum(WK)
+    return mll, g

@@ -1,0 +1,83 @@
+"""world_size-2 gloo test of the candidate-sharded sweep exchange (bobe_amd/dist_sweep.py).
+The per-shard scorer here is the CPU oracle (test infrastructure) — the exchange / tie-break /
+shard arithmetic under test is the product code that runs over RCCL on the GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bobe_amd.dist_sweep import merge_argmin, merge_best_fit, shard_bounds, sharded_wip_sweep
+
+
+def test_shard_bounds_cover_everything():
+    for n in (1, 7, 64, 65537):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            ref = np.array_split(np.arange(n), w)
+            assert [hi - lo for lo, hi in spans] == [len(x) for x in ref]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import bobe_oracle as O
+        rng = np.random.default_rng(11)
+        n, d, c, m = 80, 3, 101, 24
+        X = rng.uniform(size=(n, d))
+        y = np.sin(4 * X[:, 0]) - X[:, 1] * X[:, 2]
+        gp = O.OracleGP(X, y, noise=1e-6, lengthscales=[0.3, 0.4, 0.5])
+        cand, Z = rng.uniform(size=(c, d)), rng.uniform(size=(m, d))
+        cand[70] = cand[5]          # duplicate candidate -> tie across shards, lowest index must win
+
+        def score(shard):
+            r = O.wip_sweep(gp, shard, Z)
+            return r["wipstd"], r["argmin_s"]
+        scores, gmin, gidx = sharded_wip_sweep(score, cand, device=None)
+        full = O.wip_sweep(gp, cand, Z)
+        ok = (gidx == full["argmin_s"]) and abs(gmin - full["wipstd"].min()) < 1e-15
+        # forced tie
+        tmin, tidx = merge_argmin(0.5, 10 if rank == 1 else 40)
+        ok = ok and (tmin == 0.5 and tidx == 10)
+        # NaN beats numbers (argmin propagates NaN)
+        nmin, nidx = merge_argmin(float("nan") if rank == 1 else 0.1, 7 + rank)
+        ok = ok and np.isnan(nmin) and nidx == 8
+        mll, par = merge_best_fit(1.0 + rank if rank == 0 else float("nan"), np.array([rank, 2.0 * rank]))
+        ok = ok and mll == 1.0 and np.array_equal(par, [0.0, 0.0])
+        mll, par = merge_best_fit(-3.0 + 5 * rank, np.array([rank, 2.0 * rank]))
+        ok = ok and mll == 2.0 and np.array_equal(par, [1.0, 2.0])
+        q.put((rank, bool(ok), int(gidx), int(full["argmin_s"])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_sweep_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, gidx, want in res:
+        assert ok, (rank, gidx, want)

@@ -1,0 +1,403 @@
+"""GPU parity tests proper: the HIP path (through the C ABI / ctypes wrapper) against the CPU oracle
+on identical seeded inputs, against the committed golden vectors, and — at BASELINE.json's full
+sizes — through size-independent properties.
+
+Tolerances (fp64): |dLML|/|LML| <= 1e-10, |dgrad|_inf/|grad|_inf <= 1e-8,
+|dmu| <= 1e-8 max|y| (standardised y: max|y| ~ 3), |dvar| <= 1e-9 sigma^2 + 1e-7 var_ref,
+identical argmin (unless the two best scores are closer than 1e-9 relative).
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+from scipy.linalg import solve_triangular
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bobe_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bobe_amd import _lib
+    lib = _lib.load()
+    assert lib.bobe_device_count() >= 1, "native library loaded but no HIP device"
+    return lib
+
+
+def GP(*a, **k):
+    from bobe_amd import GP as _GP
+    return _GP(*a, **k)
+
+
+def ref_data(n, d, seed=42):
+    rng = np.random.RandomState(seed)           # reference tests/test_gp.py:21-27
+    X = rng.uniform(0, 1, size=(n, d))
+    y = -np.sum((X - 0.5) ** 2, axis=1).reshape(-1, 1)
+    return X, y
+
+
+def smooth_data(n, d, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X[:, 0]) + np.cos(2 * X[:, -1]) * X[:, d // 2]
+    return X, y
+
+
+def both(X, y, **kw):
+    return GP(X, y, **kw), O.OracleGP(X, y, **kw)
+
+
+def assert_var_close(v, ref, kself):
+    assert np.all(np.abs(v - ref) <= 1e-9 * kself + 1e-7 * np.abs(ref)), np.max(np.abs(v - ref))
+
+
+def assert_argmin(idx, scores_ref):
+    best = int(np.argmin(scores_ref))
+    if idx != best:
+        s = np.sort(scores_ref)
+        assert abs(scores_ref[idx] - s[0]) <= 1e-9 * abs(s[0]), (idx, best)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_mfma_gemm_core_exact(lib):
+    from bobe_amd import _lib
+    rng = np.random.default_rng(0)
+    M, N, K = 256, 384, 176
+    for la in (0, 1):
+        for lb in (0, 1):
+            A = rng.integers(-8, 9, size=(M, K)).astype(np.float64)
+            B = rng.integers(-8, 9, size=(N, K)).astype(np.float64)     # asymmetric integer data: exact in fp64
+            Aa = np.ascontiguousarray(A if la == 0 else A.T)
+            Ba = np.ascontiguousarray(B if lb == 0 else B.T)
+            Cc = np.full((M, N), np.nan)
+            st = lib.bobe_debug_gemm(0, la, lb, M, N, K, _lib.ptr(Aa), Aa.shape[1], _lib.ptr(Ba), Ba.shape[1],
+                                     _lib.ptr(Cc), N)
+            assert st == 0, lib.bobe_last_error()
+            assert np.array_equal(Cc, A @ B.T), (la, lb)
+    assert lib.bobe_debug_gemm(0, 0, 0, 100, 128, 16, None, 16, None, 16, None, 128) < 0   # bad shape -> error code
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern"])
+def test_kernel_matrix(kernel):
+    rng = np.random.default_rng(1)
+    A, B = rng.uniform(size=(150, 4)), rng.uniform(size=(37, 4))
+    ls = np.array([0.2, 0.5, 1.0, 3.0])
+    gp = GP(A, np.zeros(150), noise=1e-3, kernel=kernel, lengthscales=ls, kernel_variance=2.5)
+    kf = O.get_kernel(kernel)
+    assert np.allclose(gp.kernel(A, B, include_noise=False), kf(A, B, ls, 2.5, 1e-3, include_noise=False), rtol=1e-14, atol=1e-15)
+    Kxx = gp.kernel(A, A, include_noise=True)
+    assert np.allclose(Kxx, kf(A, A, ls, 2.5, 1e-3, include_noise=True), rtol=1e-14, atol=1e-15)
+    assert np.all(np.diag(Kxx) == pytest.approx(2.5 + 1e-3, rel=1e-14))
+    ls2 = np.array([1.0, 0.3, 0.3, 0.9])        # explicit hyper-parameters (acquisition.py:388 call form)
+    assert np.allclose(gp.kernel(A, B, ls2, 0.7, 0.0, include_noise=False), kf(A, B, ls2, 0.7, 0.0, include_noise=False), rtol=1e-14, atol=1e-15)
+    with pytest.raises(Exception):
+        gp.kernel(A, B, include_noise=True)     # noise*eye needs a square matrix (gp.py:153)
+
+
+@pytest.mark.parametrize("n,d", [(1, 1), (2, 2), (50, 2), (128, 3), (129, 3), (300, 6), (641, 8)])
+def test_factor_ragged_sizes(lib, n, d):
+    from bobe_amd import _lib
+    X, y = smooth_data(n, d, seed=n)
+    ls = np.full(d, 0.5)
+    gp, og = both(X, y, noise=1e-6, lengthscales=ls, kernel_variance=1.2)
+    assert not gp.not_pd
+    L = gp.cholesky
+    assert np.all(np.triu(L, 1) == 0)
+    K = og.kernel(X, X, ls, 1.2, 1e-6, include_noise=True)
+    assert np.max(np.abs(L @ L.T - K)) <= 1e-13
+    assert np.allclose(L, og.cholesky, rtol=0, atol=1e-10)
+    Li = np.empty((n, n))
+    assert lib.bobe_debug_linv(gp._h, _lib.ptr(Li)) == 0
+    assert np.max(np.abs(Li @ og.cholesky - np.eye(n))) <= 1e-8
+    a, ao = gp.alphas.ravel(), og.alphas.ravel()
+    assert np.max(np.abs(a - ao)) <= 1e-7 * np.max(np.abs(ao))
+    assert np.allclose(gp.predict_mean_batched(X[:5]), og.predict_mean_batched(X[:5]), atol=1e-8 * max(1.0, np.max(np.abs(y))))
+
+
+def test_not_positive_definite_gives_nan_not_exception():
+    X = np.array([[0.1, 0.2], [0.1, 0.2], [0.7, 0.3]])           # duplicated point, zero noise -> singular K
+    y = np.array([1.0, 2.0, 3.0])
+    gp = GP(X, y, noise=0.0, lengthscales=[0.5, 0.5])
+    assert gp.not_pd
+    assert np.all(np.isnan(gp.cholesky)) and np.all(np.isnan(gp.alphas))
+    f, g = gp.neg_mll_value_and_grad(np.log([0.5, 0.5, 1.0]))
+    assert np.isnan(f) and np.all(np.isnan(g))                   # np.isfinite filter of optim.py:328,341 keeps working
+    og = O.OracleGP(X, y, noise=0.0, lengthscales=[0.5, 0.5])
+    assert np.isnan(og.neg_mll(np.log([0.5, 0.5, 1.0])))
+
+
+@pytest.mark.parametrize("kernel,prior,n,d", [("rbf", None, 200, 3), ("matern", None, 333, 4), ("rbf", "DSLP", 150, 2),
+                                               ("rbf", "SAAS", 260, 9), ("matern", "SAAS", 140, 17)])
+def test_mll_and_gradient(kernel, prior, n, d):
+    X, y = smooth_data(n, d, seed=5)
+    ls = 0.4 + 0.05 * np.arange(d)
+    gp, og = both(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.4, lengthscale_prior=prior)
+    for shift in (0.0, 0.08, -0.11):
+        th = np.log(gp.get_hyperparams()) + shift * np.cos(np.arange(gp.num_hyperparams))
+        f, g = gp.neg_mll_value_and_grad(th)
+        fo, go = og.neg_mll_value_and_grad(th)
+        assert abs(f - fo) <= 1e-10 * abs(fo)
+        assert np.max(np.abs(g - go)) <= 1e-8 * np.max(np.abs(go)) + 1e-6 * (prior is not None)  # oracle prior grad is FD
+        assert gp.neg_mll(th) == f
+    # the factored state is not disturbed by mll evaluations
+    assert np.allclose(gp.cholesky, og.cholesky, atol=1e-10)
+
+
+def test_fixed_kernel_variance_parameterisation():
+    X, y = smooth_data(120, 3, seed=2)
+    gp, og = both(X, y, noise=1e-6, lengthscales=[0.5, 0.6, 0.7], kernel_variance=2.0, kernel_variance_prior="fixed")
+    assert gp.num_hyperparams == 3 and gp.hyperparam_bounds.shape == (2, 3)
+    th = np.log([0.45, 0.66, 0.71])
+    f, g = gp.neg_mll_value_and_grad(th)
+    fo, go = og.neg_mll_value_and_grad(th)
+    assert abs(f - fo) <= 1e-10 * abs(fo) and np.max(np.abs(g - go)) <= 1e-8 * np.max(np.abs(go))
+
+
+def test_fit_follows_oracle_trajectory():
+    X, y = ref_data(60, 2)
+    gp, og = both(X, y, noise=1e-6, lengthscale_bounds=[0.01, 10], kernel_variance_bounds=[1e-4, 1e4])
+    rng = np.random.default_rng(3)
+    x0 = O.restart_points(np.log(og.get_hyperparams()), og.hyperparam_bounds, 3, rng)     # pool.py:277-286
+    r, ro = gp.fit(x0=x0, maxiter=60), og.fit(x0=x0, maxiter=60)
+    assert r["mll"] is not None and np.isfinite(r["mll"])                                 # tests/test_gp.py:88
+    assert r["mll"] == pytest.approx(ro["mll"], rel=1e-6)
+    assert np.allclose(r["params"], ro["params"], atol=1e-4)
+    gp.update_hyperparams(r["params"])
+    og.update_hyperparams(ro["params"])
+    q = np.random.default_rng(0).uniform(size=(20, 2))
+    assert np.allclose(gp.predict_mean_batched(q), og.predict_mean_batched(q), atol=1e-6)
+
+
+def test_predict_family_and_reference_invariants():
+    X, y = ref_data(25, 2)
+    gp, og = both(X, y, noise=1e-6)                       # default ls=1, kvar=1 (tests/test_gp.py:129-139)
+    assert gp.predict_var_single(X[0]) < 1e-3
+    q = np.random.default_rng(1).uniform(size=(64, 2))
+    m, v = gp.predict_batched(q)
+    mo, vo = og.predict_batched(q)
+    assert m.shape == (64,) and v.shape == (64,) and np.all(v > 0)
+    assert np.allclose(m, mo, atol=1e-8 * 3) and np.all(np.abs(v - vo) <= 1e-9 + 1e-7 * vo)
+    assert np.allclose(gp.predict_mean_batched(q), og.predict_mean_batched(q), atol=1e-8 * np.max(np.abs(y)) + 1e-9)
+    assert np.all(np.abs(gp.predict_var_batched(q) - og.predict_var_batched(q)) <= og.y_std ** 2 * (1e-9 + 1e-7 * vo))
+    ms, vs = gp.predict_single(q[0])
+    assert ms == m[0] and vs[0] == v[0]
+    g1 = GP(X, y, noise=1e-6, kernel="rbf", lengthscales=[0.2, 0.2])
+    g2 = GP(X, y, noise=1e-6, kernel="matern", lengthscales=[0.2, 0.2])
+    a, b = g1.predict_mean_single([0.5, 0.5]), g2.predict_mean_single([0.5, 0.5])
+    assert abs(a - b) > 1e-6                                # tests/test_gp.py:295 — kernels really differ
+
+
+def test_update_state_dict_copy(tmp_path):
+    X, y = ref_data(30, 2)
+    gp, og = both(X, y, noise=1e-6, lengthscales=[0.4, 0.6])
+    new_x = np.array([[0.11, 0.93], [0.87, 0.07]])
+    new_y = np.array([[-0.3], [-0.2]])
+    gp.update(new_x, new_y)
+    og.update(new_x, new_y)
+    assert gp.npoints == 32
+    gp.update(X[:1], y[:1])                                  # duplicate rejected (tests/test_gp.py:165-169)
+    assert gp.npoints == 32
+    assert gp.y_mean == pytest.approx(og.y_mean) and gp.y_std == pytest.approx(og.y_std)
+    q = np.random.default_rng(2).uniform(size=(10, 2))
+    assert np.allclose(gp.predict_mean_batched(q), og.predict_mean_batched(q), atol=1e-8)
+    sd = gp.state_dict()
+    assert set(sd) >= {"train_x", "train_y", "lengthscales", "kernel_variance", "noise", "tausq", "y_mean", "y_std",
+                       "kernel_name", "cholesky", "alphas", "ndim", "gp_class", "lengthscale_bounds"}
+    fn = str(tmp_path / "gp_state")
+    gp.save(fn)
+    from bobe_amd import GP as GPcls
+    gp2 = GPcls.load(fn)
+    assert np.allclose(gp2.predict_mean_batched(q), gp.predict_mean_batched(q), rtol=1e-6)     # tests/test_gp.py:228-244
+    assert np.allclose(gp2.predict_var_batched(q), gp.predict_var_batched(q), rtol=1e-6, atol=1e-12)
+    assert np.allclose(gp2.cholesky, gp.cholesky, atol=1e-12)
+    gp3 = gp.copy()
+    gp3.update(np.array([[0.5, 0.5]]), np.array([[0.0]]))
+    assert gp3.npoints == 33 and gp.npoints == 32                                             # copy independence
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern"])
+def test_sweep_against_oracle_and_literal(kernel):
+    X, y = smooth_data(300, 4, seed=8)
+    ls = [0.3, 0.5, 0.4, 0.6]
+    gp, og = both(X, y * 3 + 1, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.1)
+    rng = np.random.default_rng(9)
+    cand, Z = rng.uniform(size=(500, 4)), rng.uniform(size=(70, 4))
+    cand[0] = X[3]                                           # on top of a training point: s_c ~ noise
+    r = gp.wip_sweep(cand, Z, want_mean_var=True)
+    ro = O.wip_sweep(og, cand, Z)
+    kself = 1.1 + 1e-6
+    assert np.allclose(r["mean"], ro["mean"], atol=1e-8 * 3)
+    assert_var_close(r["var"], ro["var"], kself)
+    assert np.all(np.abs(r["wipv"] - ro["wipv"]) <= og.y_std ** 2 * (1e-9 * kself + 1e-7 * ro["wipv"] / og.y_std ** 2))
+    assert np.all(np.abs(r["wipstd"] - ro["wipstd"]) <= 1e-7 * ro["wipstd"] + 1e-9 * og.y_std)
+    assert_argmin(r["argmin_v"], ro["wipv"])
+    assert_argmin(r["argmin_s"], ro["wipstd"])
+    assert r["min_s"] == r["wipstd"][r["argmin_s"]] and r["min_v"] == r["wipv"][r["argmin_v"]]
+    # literal (N+1)-factor fantasy variance of the reference (gp.py:552-576) for a few candidates
+    fv = gp.fantasy_var(cand[:4], Z)
+    lit = np.array([og.fantasy_var(c, Z, og._k12(Z)) for c in cand[:4]])
+    assert np.all(np.abs(fv - lit) <= og.y_std ** 2 * (1e-9 * kself + 1e-6 * lit / og.y_std ** 2))
+    assert np.allclose(gp.fantasy_var(cand[2], Z, None), lit[2], rtol=1e-6, atol=1e-9 * og.y_std ** 2)
+
+
+def test_sweep_candidates_equal_integration_points_and_chunking(lib):
+    """acquisition.py:394 maps over mc_points themselves; chunk size must not change any bit."""
+    X, y = smooth_data(200, 3, seed=4)
+    gp, og = both(X, y, noise=1e-6, lengthscales=[0.4, 0.4, 0.4])
+    Z = np.random.default_rng(5).uniform(size=(300, 3))
+    r1 = gp.wip_sweep(Z, Z)
+    ro = O.wip_sweep(og, Z, Z)
+    assert_argmin(r1["argmin_s"], ro["wipstd"])
+    assert lib.bobe_gp_set_chunk(gp._h, 128) == 0
+    r2 = gp.wip_sweep(Z, Z)
+    assert np.array_equal(r1["wipv"], r2["wipv"]) and np.array_equal(r1["wipstd"], r2["wipstd"])
+    assert r1["argmin_s"] == r2["argmin_s"]
+    assert lib.bobe_gp_set_chunk(gp._h, 100) < 0
+
+
+def test_device_pointers_equal_host_pointers():
+    import torch
+    X, y = smooth_data(150, 3, seed=6)
+    gp = GP(X, y, noise=1e-6, lengthscales=[0.4, 0.5, 0.6])
+    rng = np.random.default_rng(7)
+    cand, Z = rng.uniform(size=(260, 3)), rng.uniform(size=(40, 3))
+    rh = gp.wip_sweep(cand, Z)
+    rd = gp.wip_sweep(torch.from_numpy(cand).cuda(), torch.from_numpy(Z).cuda())
+    assert np.array_equal(rh["wipv"], rd["wipv"]) and rh["argmin_v"] == rd["argmin_v"]
+
+
+def test_ei_and_log_ei_scorers():
+    X, y = ref_data(30, 2)                                   # tests/test_acquisition.py:21-37 recipe
+    y = -np.sum((X - 0.7) ** 2, axis=1, keepdims=True)
+    gp, og = both(X, y, noise=1e-6, lengthscales=[0.3, 0.3], kernel_variance=1.0)
+    q = np.random.default_rng(3).uniform(size=(100, 2))
+    best = float(np.max(og.train_y))
+    m, v = og.predict_batched(q)
+    ei = gp.acq_ei(q, best)
+    assert np.all(ei >= 0)                                    # tests/test_acquisition.py:92-95
+    assert np.allclose(ei, O.ei_score(m, v, best), rtol=1e-6, atol=1e-12)
+    le, leo = gp.acq_ei(q, best, log_ei=True), O.log_ei_score(m, v, best)
+    assert np.all(np.isfinite(le))
+    assert np.allclose(le, leo, rtol=1e-6, atol=1e-6)
+
+
+def test_acquisition_classes_next_point_and_batch():
+    from bobe_amd import WIPStd, WIPV, EI, get_mc_samples
+    X, y = ref_data(40, 2)
+    gp = GP(X, y, noise=1e-6, lengthscales=[0.3, 0.3])
+    rng = np.random.default_rng(0)
+    mc = get_mc_samples(gp, num_samples=256, method="uniform", np_rng=1)
+    for cls in (WIPV, WIPStd):
+        x, val = cls().get_next_point(gp, acq_kwargs={"mc_samples": mc, "mc_points_size": 64}, rng=rng, maxiter=20)
+        assert np.shape(x) == (2,) and np.all(x >= 0) and np.all(x <= 1) and np.isfinite(val)
+    xb, vb = WIPStd().get_next_batch(gp, n_batch=3, acq_kwargs={"mc_samples": mc, "mc_points_size": 64}, rng=rng, maxiter=10)
+    assert xb.shape == (3, 2) and vb.shape == (3,)             # tests/test_acquisition.py:233-235
+    x, val = EI().get_next_point(gp, acq_kwargs={}, n_restarts=4, maxiter=30, rng=rng)
+    assert np.shape(x) == (2,) and val >= 0                    # tests/test_acquisition.py:156-158
+
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_hip_path_matches_golden_vectors(path):
+    g = dict(np.load(path, allow_pickle=False))
+    prior = None if str(g["prior"]) == "none" else str(g["prior"])
+    gp = GP(g["X"], g["y"], noise=float(g["noise"]), kernel=str(g["kernel"]), lengthscales=g["lengthscales"],
+            kernel_variance=float(g["kernel_variance"]), lengthscale_prior=prior)
+    f, gr = gp.neg_mll_value_and_grad(g["theta"])
+    assert abs(f - float(g["neg_mll"])) <= 1e-10 * abs(float(g["neg_mll"]))
+    assert np.max(np.abs(gr - g["neg_mll_grad"])) <= 1e-6 * np.max(np.abs(g["neg_mll_grad"]))
+    assert np.allclose(gp.cholesky, g["cholesky"], atol=1e-10)
+    r = gp.wip_sweep(g["cand"], g["Z"], want_mean_var=True)
+    kself = float(g["kernel_variance"]) + float(g["noise"])
+    ys = float(g["y_std"])
+    assert np.allclose(r["mean"], g["mean"], atol=3e-8)
+    assert_var_close(r["var"], g["var"], kself)
+    assert np.all(np.abs(r["wipv"] - g["wipv"]) <= ys ** 2 * 1e-9 * kself + 1e-7 * g["wipv"])
+    assert np.all(np.abs(r["wipstd"] - g["wipstd"]) <= 1e-9 * ys + 1e-7 * g["wipstd"])
+    assert_argmin(r["argmin_v"], g["wipv"])
+    assert_argmin(r["argmin_s"], g["wipstd"])
+    fv = gp.fantasy_var(g["cand"][:6], g["Z"])
+    assert np.all(np.abs(fv - g["fantasy"]) <= ys ** 2 * 1e-9 * kself + 1e-6 * g["fantasy"])
+    assert np.allclose(gp.predict_mean_batched(g["cand"]), g["pred_mean"], atol=1e-8 * np.max(np.abs(g["y"])) + 1e-9)
+    assert np.allclose(gp.acq_ei(g["cand"], float(g["best_y"])), g["ei"], rtol=1e-5, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json sizes: oracle where it finishes in seconds (config 2), properties at config 3
+# ------------------------------------------------------------------------------------------------
+def test_small_config_against_oracle():
+    from bobe_amd.synthetic import synthetic_problem, theta_schedule
+    N, d, Cn, M = 1024, 6, 8192, 512
+    X, y, cand, Z = synthetic_problem(N, d, Cn, M)
+    th = theta_schedule(d)
+    ls, kv = np.exp(th[-1, :d]), float(np.exp(th[-1, d]))
+    gp, og = both(X, y, noise=1e-6, lengthscales=ls, kernel_variance=kv)
+    for k in (0, 7, 19):
+        f, g = gp.neg_mll_value_and_grad(th[k])
+        fo, go = og.neg_mll_value_and_grad(th[k])
+        assert abs(f - fo) <= 1e-10 * abs(fo)
+        assert np.max(np.abs(g - go)) <= 1e-8 * np.max(np.abs(go))
+    r = gp.wip_sweep(cand, Z, want_mean_var=True)
+    ro = O.wip_sweep(og, cand, Z)
+    assert np.max(np.abs(r["mean"] - ro["mean"])) <= 1e-8 * np.max(np.abs(y))
+    assert_var_close(r["var"], ro["var"], kv + 1e-6)
+    assert np.all(np.abs(r["wipv"] - ro["wipv"]) <= 1e-9 * (kv + 1e-6) + 1e-7 * ro["wipv"])
+    assert np.all(np.abs(r["wipstd"] - ro["wipstd"]) <= 1e-9 + 1e-7 * ro["wipstd"])
+    assert_argmin(r["argmin_v"], ro["wipv"])
+    assert_argmin(r["argmin_s"], ro["wipstd"])
+
+
+def test_headline_config_properties(lib):
+    """N=4096, d=8, C=65536, M=512: size-independent properties (the oracle is only used for an O(N^3/3)
+    Cholesky and O(N^2) checks here)."""
+    from bobe_amd import _lib
+    from bobe_amd.synthetic import synthetic_problem, theta_schedule
+    N, d, Cn, M = 4096, 8, 65536, 512
+    X, y, cand, Z = synthetic_problem(N, d, Cn, M)
+    th = theta_schedule(d)
+    ls, kv = np.exp(th[-1, :d]), float(np.exp(th[-1, d]))
+    gp = GP(X, y, noise=1e-6, lengthscales=ls, kernel_variance=kv)
+    assert not gp.not_pd
+    # (1) L L^T = K and L matches LAPACK
+    K = O.rbf_kernel(X, X, ls, kv, 1e-6, include_noise=True)
+    L = gp.cholesky
+    assert np.max(np.abs(L @ L.T - K)) <= 1e-12
+    Lo = O.chol_nan(K)
+    assert np.max(np.abs(L - Lo)) <= 1e-9
+    # (2) MLL value against the LAPACK factor; gradient against a central difference of the GPU value
+    alpha_o = solve_triangular(Lo, solve_triangular(Lo, y, lower=True), lower=True, trans="T")
+    mll_o = -0.5 * y @ alpha_o - np.sum(np.log(np.diag(Lo))) - 0.5 * N * np.log(2 * np.pi)
+    f, g = gp.neg_mll_value_and_grad(th[-1])
+    assert abs(-f - mll_o) <= 1e-10 * abs(mll_o)
+    e = 1e-4
+    for j in (0, d):
+        tp, tm = th[-1].copy(), th[-1].copy()
+        tp[j] += e
+        tm[j] -= e
+        fd = (gp.neg_mll(tp) - gp.neg_mll(tm)) / (2 * e)
+        assert g[j] == pytest.approx(fd, rel=1e-5)
+    # (3) sweep properties
+    r = gp.wip_sweep(cand, Z, want_mean_var=True)
+    assert np.all(np.isfinite(r["wipv"])) and np.all(r["wipv"] > 0) and np.all(r["wipstd"] > 0)
+    assert r["argmin_v"] == int(np.argmin(r["wipv"])) and r["argmin_s"] == int(np.argmin(r["wipstd"]))
+    base = np.mean(gp.predict_batched(Z)[1])                 # current integrated variance
+    assert np.all(r["wipv"] <= base * (1 + 1e-9))            # a fantasy point never increases posterior variance
+    assert np.all(r["wipstd"] ** 2 <= r["wipv"] * (1 + 1e-12))   # Jensen: mean(sqrt(v))^2 <= mean(v)
+    assert np.all(r["var"] <= kv + 1e-6 + 1e-12) and np.all(r["var"] >= 1e-12)
+    # (4) spot-check 64 candidates against the oracle's triangular solves with the LAPACK factor
+    idx = np.random.default_rng(0).choice(Cn, 64, replace=False)
+    kc = O.rbf_kernel(X, cand[idx], ls, kv, 1e-6, include_noise=False)
+    vc = solve_triangular(Lo, kc, lower=True)
+    assert np.max(np.abs(r["mean"][idx] - kc.T @ alpha_o)) <= 1e-8 * np.max(np.abs(y))
+    assert_var_close(r["var"][idx], np.maximum(kv + 1e-6 - np.sum(vc * vc, axis=0), 1e-12), kv + 1e-6)
+    # (5) interpolation at training points and linearity of the mean in y
+    m_tr = gp.predict_batched(X[:256])[0]
+    assert np.max(np.abs(m_tr - y[:256])) <= 5e-3
+    gp2 = GP(X, 2.0 * y + 1.0, noise=1e-6, lengthscales=ls, kernel_variance=kv)   # standardisation removes scale/shift
+    assert np.allclose(gp2.predict_batched(cand[:512])[0], r["mean"][:512], atol=1e-9)
+    assert np.allclose(gp2.predict_mean_batched(cand[:512]), 2.0 * (r["mean"][:512] * gp.y_std + gp.y_mean) + 1.0, atol=1e-8)

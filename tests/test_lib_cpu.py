@@ -1,0 +1,114 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/bobe_gp.h declares,
+and fails loudly (no CPU fallback) when there is no HIP device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bobe_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "bobe_gp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bobe_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from bobe_amd import _lib
+    declared = header_symbols()
+    assert len(declared) >= 25
+    bound = {name for name, _, _ in _lib.SIGNATURES}
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/bobe_gp.h but not exported"
+        assert name in bound, f"{name} has no ctypes signature in bobe_amd/_lib.py"
+    assert bound <= set(declared)
+    assert b"gfx950" in lib.bobe_version()
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.bobe_device_count() == 0
+    h = C.c_void_p(0)
+    st = lib.bobe_gp_create(C.byref(h), 0, 0, 2)
+    assert st < 0 and not h.value
+    assert lib.bobe_last_error()
+    from bobe_amd import GP, BobeLibraryError
+    with pytest.raises(BobeLibraryError):
+        GP(np.random.rand(5, 2), np.random.rand(5))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bobe_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f"{f} references the oracle"
+
+
+def test_priors_match_oracle_and_gradients():
+    from bobe_amd import priors as P
+    from oracle import bobe_oracle as O
+    x = np.array([0.05, 0.7, 3.0])
+    pairs = [(P.Uniform(0.01, 5), lambda v: O._logpdf_uniform(v, 0.01, 5)),
+             (P.LogNormal(0.3, 1.7), lambda v: O._logpdf_lognormal(v, 0.3, 1.7)),
+             (P.HalfCauchy(0.1), lambda v: O._logpdf_halfcauchy(v, 0.1)),
+             (P.Normal(0.2, 0.9), lambda v: O._logpdf_normal(v, 0.2, 0.9)),
+             (P.HalfNormal(1.3), lambda v: O._logpdf_halfnormal(v, 1.3)),
+             (P.Gamma(2.0, 3.0), lambda v: O._logpdf_gamma(v, 2.0, 3.0)),
+             (P.dslp(4), lambda v: O._logpdf_lognormal(v, np.sqrt(2) + 0.5 * np.log(4), np.sqrt(3)))]
+    for dist, ref in pairs:
+        assert np.allclose(dist.log_prob(x), ref(x), rtol=1e-14, atol=1e-14)
+        fd = (ref(x + 1e-6) - ref(x - 1e-6)) / 2e-6
+        assert np.allclose(dist.dlog_prob(x), fd, rtol=1e-6, atol=1e-8)
+    ls = np.array([0.2, 1.5, 0.7])
+    lp, g_ls, g_kv, g_tau = P.saas_logprob_and_grad(ls, 2.0, 0.5)
+    assert lp == pytest.approx(O.saas_prior_logprob(ls, 2.0, 0.5), rel=1e-14)
+    e = 1e-6
+    assert g_kv == pytest.approx((O.saas_prior_logprob(ls, 2.0 + e, 0.5) - O.saas_prior_logprob(ls, 2.0 - e, 0.5)) / (2 * e), rel=1e-6)
+    assert g_tau == pytest.approx((O.saas_prior_logprob(ls, 2.0, 0.5 + e) - O.saas_prior_logprob(ls, 2.0, 0.5 - e)) / (2 * e), rel=1e-6)
+    for j in range(3):
+        lp_, lm_ = ls.copy(), ls.copy()
+        lp_[j] += e
+        lm_[j] -= e
+        assert g_ls[j] == pytest.approx((O.saas_prior_logprob(lp_, 2.0, 0.5) - O.saas_prior_logprob(lm_, 2.0, 0.5)) / (2 * e), rel=1e-6)
+
+
+def test_optimize_scipy_matches_oracle_driver():
+    from bobe_amd.optim import optimize_scipy
+    from oracle import bobe_oracle as O
+
+    def vg(x):
+        x = np.asarray(x)
+        return float(np.sum((x - 0.3) ** 4) + np.sum(x ** 2)), 4 * (x - 0.3) ** 3 + 2 * x
+    x0 = np.array([[0.9, -0.5], [0.1, 0.2], [2.0, 2.0]])
+    a = optimize_scipy(vg, num_params=2, bounds=[-1, 3], x0=x0, maxiter=50, n_restarts=3, optimizer_options={})
+    b = O.optimize_scipy(vg, 2, [-1, 3], x0, maxiter=50, n_restarts=3, optimizer_options={})
+    assert np.allclose(a[0], b[0]) and a[1] == pytest.approx(b[1])
+    with pytest.raises(ValueError):
+        optimize_scipy(vg, num_params=2, bounds=[-1, 3], x0=x0[:1], n_restarts=2)
+
+
+def test_synthetic_problem_is_seeded():
+    from bobe_amd.synthetic import synthetic_problem, theta_schedule
+    a = synthetic_problem(64, 3, 32, 16)
+    b = synthetic_problem(64, 3, 32, 16)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    c = synthetic_problem(64, 3, 16, 16, cand_offset=16)
+    assert np.array_equal(c[2], a[2][16:32])
+    th = theta_schedule(3)
+    assert th.shape == (20, 4) and th[0, 0] == pytest.approx(np.log(0.6)) and th[1, 0] == pytest.approx(np.log(0.6) - 0.05)
