@@ -129,7 +129,7 @@ struct bobe_gp {
   int64_t N = 0, Np = 0;
   int nb = 0;
   Hyper hyp;
-  bool have_data = false, factored = false;
+  bool have_data = false, factored = false, not_pd = false;
   int64_t chunk = 2048;
 
   DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs;
@@ -653,7 +653,8 @@ int bobe_gp_factor(bobe_gp_t* g) {
   g->factor_into(g->hyp, g->XsT.d(), g->A.d(), g->Linv.d(), g->w.d(), g->alpha.d());
   const int inf = g->read_info();
   g->factored = true;
-  if (inf != 0x7f7f7f7f) {
+  g->not_pd = (inf != 0x7f7f7f7f);
+  if (g->not_pd) {
     const double nan = std::nan("");
     const int64_t nn = g->Np * g->Np;
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, g->stream, g->A.d(), nn, nan);
@@ -823,7 +824,7 @@ int bobe_gp_get_chol(bobe_gp_t* g, double* L, double* alpha) {
   if (!g) throw Err(BOBE_ERR_ARG, "gp is NULL");
   if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
   g->use();
-  if (L) copy_out_matrix(g, g->A.d(), L, 1);
+  if (L) copy_out_matrix(g, g->A.d(), L, g->not_pd ? 0 : 1);   // not PD: all-NaN, like jnp.linalg.cholesky
   if (alpha)
     HIPCHK(hipMemcpyAsync(alpha, g->alpha.p, (size_t)g->N * sizeof(double),
                           is_device_ptr(alpha) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, g->stream));
@@ -852,6 +853,7 @@ int bobe_gp_set_chol(bobe_gp_t* g, const double* L, const double* alpha) {
   g->trtri(g->A.d(), g->Linv.d());
   g->sync();
   g->factored = true;
+  g->not_pd = false;
   return BOBE_OK;
   API_END
 }

@@ -293,7 +293,8 @@ def test_acquisition_classes_next_point_and_batch():
     for cls in (WIPV, WIPStd):
         x, val = cls().get_next_point(gp, acq_kwargs={"mc_samples": mc, "mc_points_size": 64}, rng=rng, maxiter=20)
         assert np.shape(x) == (2,) and np.all(x >= 0) and np.all(x <= 1) and np.isfinite(val)
-    xb, vb = WIPStd().get_next_batch(gp, n_batch=3, acq_kwargs={"mc_samples": mc, "mc_points_size": 64}, rng=rng, maxiter=10)
+    xb, vb = WIPStd().get_next_batch(gp, n_batch=3, acq_kwargs={"mc_samples": mc, "mc_points_size": 64}, rng=rng, maxiter=10,
+                                     n_restarts=1)      # bo.py:1274 calls with n_restarts=1
     assert xb.shape == (3, 2) and vb.shape == (3,)             # tests/test_acquisition.py:233-235
     x, val = EI().get_next_point(gp, acq_kwargs={}, n_restarts=4, maxiter=30, rng=rng)
     assert np.shape(x) == (2,) and val >= 0                    # tests/test_acquisition.py:156-158
@@ -373,7 +374,9 @@ def test_headline_config_properties(lib):
     alpha_o = solve_triangular(Lo, solve_triangular(Lo, y, lower=True), lower=True, trans="T")
     mll_o = -0.5 * y @ alpha_o - np.sum(np.log(np.diag(Lo))) - 0.5 * N * np.log(2 * np.pi)
     f, g = gp.neg_mll_value_and_grad(th[-1])
-    assert abs(-f - mll_o) <= 1e-10 * abs(mll_o)
+    mll_gpu, _ = gp.mll_data(ls, kv, want_grad=False)          # data term only (the default priors are constants)
+    assert abs(mll_gpu - mll_o) <= 1e-10 * abs(mll_o)
+    assert -f == pytest.approx(mll_gpu + gp.prior_func(ls, kv, 1.0), rel=1e-14)
     e = 1e-4
     for j in (0, d):
         tp, tm = th[-1].copy(), th[-1].copy()
