@@ -167,8 +167,9 @@ def main():
         lib.bobe_debug_time_potrf(h, 3, C.byref(potrf_ms))
         Np = (N + 127) // 128 * 128
         chunk = 2048
-        flops_per_launch = {"trimul": float(N) * N * min(chunk, Cn),          # TRSM-equivalent N^2 per candidate
-                            "cross": 2.0 * min(chunk, Cn) * M * N,
+        # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 per candidate, triangular) fused with
+        # the cross-covariance rows W_Z^T K(X,C) (2 N M per candidate)
+        flops_per_launch = {"trimul": (float(N) * N + 2.0 * N * M) * min(chunk, Cn),
                             "syrk": None, "lauum": 2.0 * N ** 3 / 3.0}.get(args.profile_class)
         roof = None
         if flops_per_launch and launches.value:

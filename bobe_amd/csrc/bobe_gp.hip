@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -74,7 +75,7 @@ void allow_big_lds(K kernel, int bytes) {
 }
 
 template <int LA, int LB>
-__global__ __launch_bounds__(256) void k_debug_gemm(const double* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, 2) void k_debug_gemm(const double* __restrict__ A, int64_t lda,
                                                     const double* __restrict__ B, int64_t ldb, double* __restrict__ C,
                                                     int64_t ldc, int64_t K) {
   extern __shared__ double smem[];
@@ -97,8 +98,6 @@ void configure_kernels_once() {
   allow_big_lds(k_trtri_R, GEMM_SMEM_BYTES);
   allow_big_lds(k_trimul, GEMM_SMEM_BYTES);
   allow_big_lds(k_trimul_t, GEMM_SMEM_BYTES);
-  allow_big_lds(k_cross_score<0>, GEMM_SMEM_BYTES);
-  allow_big_lds(k_cross_score<1>, GEMM_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 8>, GEMM_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 16>, GEMM_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 32>, GEMM_SMEM_BYTES);
@@ -355,7 +354,8 @@ void bobe_gp::prepare_z(const double* Z, int64_t M, int64_t Mp) {
   scale(zin, M, Mp, hyp, ZsT.d(), Mp);
   kernel_matrix_cross(XsT.d(), Np, N, Np, ZsT.d(), Mp, M, Mp, hyp, kXZ.d(), Mp);
   hipLaunchKernelGGL(k_trimul, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
-                     (const double*)Linv.d(), Np, nb, (const double*)kXZ.d(), Mp, VZ.d(), Mp, qpart.d(), Mp);
+                     (const double*)Linv.d(), Np, nb, (const double*)kXZ.d(), Mp, VZ.d(), Mp, qpart.d(), Mp,
+                     (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
   hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, stream,
                      (const double*)qpart.d(), Mp, nb, Mp, hyp.kvar + hyp.noise, 0, basez.d(), (double*)nullptr);
   hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
@@ -378,15 +378,14 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   const double* cin = fetch(cand, (size_t)C * d, in_stage);
   if (do_wip) prepare_z(Z, M, Mp);
   const int64_t CH = chunk;
-  CsT.ensure((size_t)d * CH * sizeof(double));
+  // scoring runs once per super-chunk of SC candidates (bounded crossT workspace: Mp x SC doubles)
+  const int64_t SC = round_up(std::min<int64_t>(C, std::max<int64_t>(CH, 65536)), CH);
+  CsT.ensure((size_t)d * SC * sizeof(double));
   kXC.ensure((size_t)Np * CH * sizeof(double));
-  sc.ensure((size_t)CH * sizeof(double));
+  sc.ensure((size_t)SC * sizeof(double));
   qpart.ensure((size_t)nb * (Mp > CH ? Mp : CH) * sizeof(double));
   part.ensure((size_t)nb * (Np > CH ? Np : CH) * sizeof(double));
-  if (do_wip) {
-    pv.ensure((size_t)CH * nzt * sizeof(double));
-    ps.ensure((size_t)CH * nzt * sizeof(double));
-  }
+  if (do_wip) pv.ensure((size_t)Mp * SC * sizeof(double));   // crossT
   double* d_mean = out_dev(mean, C, o_mean);
   double* d_var = out_dev(var, C, o_var);
   double* d_wipv = nullptr;
@@ -402,53 +401,54 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
     }
   }
   double* d_fant = nullptr;
-  if (fantasy_out) {
-    // dumped with leading dimension Mp, compacted afterwards
-    kout.ensure((size_t)round_up(C, TILE) * Mp * sizeof(double));
-    d_fant = kout.d();
+  if (fantasy_out) {   // dumped with leading dimension M (dense), C x M
+    d_fant = is_device_ptr(fantasy_out) ? fantasy_out : (kout.ensure((size_t)C * M * sizeof(double)), kout.d());
   }
-  for (int64_t c0 = 0; c0 < C; c0 += CH) {
-    const int64_t nc = (C - c0 < CH) ? (C - c0) : CH;
-    const int64_t ncp = round_up(nc, TILE);
-    scale(cin + c0 * d, nc, ncp, hyp, CsT.d(), CH);
-    kernel_matrix_cross(XsT.d(), Np, N, Np, CsT.d(), CH, nc, ncp, hyp, kXC.d(), CH);
-    if (d_mean) {
-      hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(ncp / 64), (unsigned)nb), dim3(256), 0, stream,
-                         (const double*)kXC.d(), CH, 0, (const double*)alpha.d(), part.d(), CH);
-      hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
-                         (const double*)part.d(), CH, nb, 0, nc, d_mean + c0);
-    }
-    prof_begin(BOBE_PROF_TRIMUL);
-    hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
-                       (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, (double*)nullptr, (int64_t)0,
-                       qpart.d(), CH);
-    prof_end(BOBE_PROF_TRIMUL);
-    // s_c for the whole padded chunk (scoring reads padded columns), var only for valid columns
-    hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((ncp + 255) / 256)), dim3(256), 0, stream,
-                       (const double*)qpart.d(), CH, nb, ncp, kself, policy, sc.d(), (double*)nullptr);
-    if (d_var)
+  const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+  for (int64_t s0 = 0; s0 < C; s0 += SC) {
+    const int64_t ns = (C - s0 < SC) ? (C - s0) : SC;
+    const int64_t nsp = round_up(ns, TILE);
+    scale(cin + s0 * d, ns, nsp, hyp, CsT.d(), SC);
+    for (int64_t c0 = 0; c0 < ns; c0 += CH) {
+      const int64_t nc = (ns - c0 < CH) ? (ns - c0) : CH;
+      const int64_t ncp = round_up(nc, TILE);
+      kernel_matrix_cross(XsT.d(), Np, N, Np, CsT.d() + c0, SC, nc, ncp, hyp, kXC.d(), CH);
+      if (d_mean) {
+        hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(ncp / 64), (unsigned)nb), dim3(256), 0, stream,
+                           (const double*)kXC.d(), CH, 0, (const double*)alpha.d(), part.d(), CH);
+        hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
+                           (const double*)part.d(), CH, nb, 0, nc, d_mean + s0 + c0);
+      }
+      prof_begin(BOBE_PROF_TRIMUL);
+      hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)(nb + nzt)), dim3(256), GEMM_SMEM_BYTES,
+                         stream, (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, (double*)nullptr,
+                         (int64_t)0, qpart.d(), CH, (const double*)WZ.d(), Mp, nzt, do_wip ? pv.d() + c0 : nullptr, SC);
+      prof_end(BOBE_PROF_TRIMUL);
+      // s_c for the scorer, var for the caller
       hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
-                         (const double*)qpart.d(), CH, nb, nc, kself, policy, (double*)nullptr, d_var + c0);
-    if (do_wip) {
-      const dim3 grid((unsigned)nzt, (unsigned)(ncp / TILE));
-      double* vo = d_fant ? d_fant + c0 * Mp : nullptr;
-      prof_begin(BOBE_PROF_CROSS);
-      if (hyp.kern == 0)
-        hipLaunchKernelGGL(k_cross_score<0>, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)kXC.d(), CH, nb,
-                           (const double*)WZ.d(), Mp, (const double*)CsT.d(), CH, (const double*)ZsT.d(), Mp, M,
-                           (const double*)sc.d(), (const double*)basez.d(), hyp, y_std * y_std, pv.d(), ps.d(),
-                           (int64_t)nzt, vo, Mp);
-      else
-        hipLaunchKernelGGL(k_cross_score<1>, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)kXC.d(), CH, nb,
-                           (const double*)WZ.d(), Mp, (const double*)CsT.d(), CH, (const double*)ZsT.d(), Mp, M,
-                           (const double*)sc.d(), (const double*)basez.d(), hyp, y_std * y_std, pv.d(), ps.d(),
-                           (int64_t)nzt, vo, Mp);
-      prof_end(BOBE_PROF_CROSS);
-      hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
-                         (const double*)pv.d(), (const double*)ps.d(), (int64_t)nzt, nzt, M, nc,
-                         d_wipv ? d_wipv + c0 : nullptr, d_wipstd ? d_wipstd + c0 : nullptr);
+                         (const double*)qpart.d(), CH, nb, nc, kself, policy, sc.d() + c0,
+                         d_var ? d_var + s0 + c0 : nullptr);
+      LAUNCH_CHECK();
     }
-    LAUNCH_CHECK();
+    if (do_wip) {
+      const dim3 grid((unsigned)((ns + 63) / 64));
+      const size_t sm = (size_t)(d + 1) * 128 * sizeof(double);
+      double* vo = d_fant ? d_fant + s0 * M : nullptr;
+      prof_begin(BOBE_PROF_CROSS);
+#define WS(KE, DC)                                                                                              \
+  hipLaunchKernelGGL((k_wip_score<KE, DC>), grid, dim3(256), sm, stream, (const double*)pv.d(), SC,             \
+                     (const double*)CsT.d(), SC, (const double*)ZsT.d(), Mp, M, (const double*)sc.d(),          \
+                     (const double*)basez.d(), ns, hyp, y_std * y_std, d_wipv ? d_wipv + s0 : nullptr,          \
+                     d_wipstd ? d_wipstd + s0 : nullptr, vo, M)
+      if (hyp.kern == 0) {
+        if (dcap == 8) WS(0, 8); else if (dcap == 16) WS(0, 16); else WS(0, 32);
+      } else {
+        if (dcap == 8) WS(1, 8); else if (dcap == 16) WS(1, 16); else WS(1, 32);
+      }
+#undef WS
+      prof_end(BOBE_PROF_CROSS);
+      LAUNCH_CHECK();
+    }
   }
   o_misc.ensure(8 * sizeof(double));
   double* m_val = o_misc.d();                                        // [0],[1]
@@ -465,12 +465,8 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
     out_finish(wipv, C, o_wipv);
     out_finish(wipstd, C, o_wipstd);
   }
-  if (fantasy_out) {
-    const bool dev = is_device_ptr(fantasy_out);
-    HIPCHK(hipMemcpy2DAsync(fantasy_out, (size_t)M * sizeof(double), d_fant, (size_t)Mp * sizeof(double),
-                            (size_t)M * sizeof(double), (size_t)C, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                            stream));
-  }
+  if (fantasy_out && !is_device_ptr(fantasy_out))
+    HIPCHK(hipMemcpyAsync(fantasy_out, d_fant, (size_t)C * M * sizeof(double), hipMemcpyDeviceToHost, stream));
   if (want_v || want_s) {
     HIPCHK(hipMemcpyAsync(h_res, o_misc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
@@ -696,7 +692,7 @@ int bobe_gp_mll(bobe_gp_t* g, const double* ls, double kvar, double* mll, double
     }
 #undef LG
     g->prof_end(BOBE_PROF_LAUUM);
-    hipLaunchKernelGGL(k_grad_reduce, dim3(1), dim3(64), 0, g->stream, (const double*)g->gpart.d(), ntiles, dcap + 1, d,
+    hipLaunchKernelGGL(k_grad_reduce, dim3(d + 1), dim3(64), 0, g->stream, (const double*)g->gpart.d(), ntiles, dcap + 1, d,
                        dcap, g->res.d() + 2);
   }
   LAUNCH_CHECK();

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ A, int64
 
 // ---- blocked Cholesky pieces ---------------------------------------------------------------
 // panel: A[i][k] <- A[i][k] * invL_kk^T for block rows i = k+1 .. nb-1   (grid = nb-k-1)
-__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int64_t lda, const double* __restrict__ Linv,
+__global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ A, int64_t lda, const double* __restrict__ Linv,
                                                     int64_t ldl, int k) {
   extern __shared__ double smem[];
   const int i = k + 1 + blockIdx.x;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
 }
 
 // trailing update: A[i][j] -= L[i][k] L[j][k]^T for k < j <= i < nb  (grid = n(n+1)/2, n = nb-k-1)
-__global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k) {
+__global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k) {
   extern __shared__ double smem[];
   int a, b;
   tri_decode(blockIdx.x, a, b);
@@ -318,7 +318,7 @@ __device__ __forceinline__ bool tri_find(const TriProb* __restrict__ probs, int 
   return false;
 }
 
-__global__ __launch_bounds__(256) void k_trtri_T(const double* __restrict__ L, int64_t ldl, const double* __restrict__ Linv,
+__global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L, int64_t ldl, const double* __restrict__ Linv,
                                                  int64_t ldi, double* __restrict__ Tmp, int64_t ldt,
                                                  const TriProb* __restrict__ probs, int nprob) {
   extern __shared__ double smem[];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_trtri_T(const double* __restrict__ L, i
   store_tile(acc, Tmp, ldt, (int64_t)i * TILE, (int64_t)j * TILE, 1.0, 0.0);
 }
 
-__global__ __launch_bounds__(256) void k_trtri_R(double* __restrict__ Linv, int64_t ldi, const double* __restrict__ Tmp,
+__global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, int64_t ldi, const double* __restrict__ Tmp,
                                                  int64_t ldt, const TriProb* __restrict__ probs, int nprob) {
   extern __shared__ double smem[];
   TriProb p;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_trtri_R(double* __restrict__ Linv, int6
 // partial[(blockIdx.x)*(DCAP+1) + j] = sum_ab W_ab dK_ab/dlog ls_j (j < d), [DCAP] = sum_ab W_ab Kt_ab,
 // off-diagonal tiles weighted x2.  Optionally stores Kinv (lower tiles) for tests.
 template <int KERN, int DCAP>
-__global__ __launch_bounds__(256) void k_lauum_grad(const double* __restrict__ Linv, int64_t ldi, int nb, int64_t n,
+__global__ __launch_bounds__(256, 2) void k_lauum_grad(const double* __restrict__ Linv, int64_t ldi, int nb, int64_t n,
                                                     const double* __restrict__ alpha, const double* __restrict__ XsT,
                                                     int64_t ldx, Hyper h, double* __restrict__ partial,
                                                     double* __restrict__ Kinv, int64_t ldk) {
@@ -429,17 +429,28 @@ __global__ __launch_bounds__(256) void k_lauum_grad(const double* __restrict__ L
   }
 }
 
-// ---- V = Linv * B  (lower-triangular times dense), optional store, optional column sum of squares
-// grid.x = column tile, grid.y = row tile (heavy rows first).  B is [Np x ncols] row-major (RC).
-// qpart[(row tile)*ldq + col] = sum over the tile's 128 rows of V^2.
-__global__ __launch_bounds__(256) void k_trimul(const double* __restrict__ Linv, int64_t ldi, int nb,
-                                                const double* __restrict__ B, int64_t ldb, double* __restrict__ V,
-                                                int64_t ldv, double* __restrict__ qpart, int64_t ldq) {
+// ---- the sweep's one big GEMM launch ------------------------------------------------------------
+// grid.x = column (candidate) tile; grid.y enumerates row tiles, heaviest first:
+//   y <  nzt : cross tile   G[z][c]  = sum_n  WZ[n][z] B[n][c]      (full K)   -> crossT (optional, nzt may be 0)
+//   y >= nzt : V tile       V[i][c]  = sum_{k<=i} Linv[i][k] B[k][c] (lower-triangular K range), row tile
+//              ti = nb-1-(y-nzt); optional store to V, optional qpart[ti*ldq + c] = sum over the tile's rows of V^2
+// B is [Np x ncols] row-major (RC).
+__global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Linv, int64_t ldi, int nb,
+                                                   const double* __restrict__ B, int64_t ldb, double* __restrict__ V,
+                                                   int64_t ldv, double* __restrict__ qpart, int64_t ldq,
+                                                   const double* __restrict__ WZ, int64_t ldw, int nzt,
+                                                   double* __restrict__ crossT, int64_t ldx) {
   extern __shared__ double smem[];
-  const int ti = nb - 1 - blockIdx.y;
   const int tc = blockIdx.x;
   v4d acc[4][4];
   acc_zero(acc);
+  if ((int)blockIdx.y < nzt) {
+    const int tz = blockIdx.y;
+    gemm_tile<RC, RC>(acc, WZ, ldw, (int64_t)tz * TILE, B, ldb, (int64_t)tc * TILE, 0, (int64_t)nb * TILE, smem);
+    store_tile(acc, crossT, ldx, (int64_t)tz * TILE, (int64_t)tc * TILE, 1.0, 0.0);
+    return;
+  }
+  const int ti = nb - 1 - ((int)blockIdx.y - nzt);
   gemm_tile<KC, RC>(acc, Linv, ldi, (int64_t)ti * TILE, B, ldb, (int64_t)tc * TILE, 0, (int64_t)(ti + 1) * TILE, smem);
   if (V) store_tile(acc, V, ldv, (int64_t)ti * TILE, (int64_t)tc * TILE, 1.0, 0.0);
   if (qpart) {
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(256) void k_trimul(const double* __restrict__ Linv,
 }
 
 // ---- W = Linv^T * V  (upper-triangular times dense):  W[m][z] = sum_{k >= m} Linv[k][m] V[k][z]
-__global__ __launch_bounds__(256) void k_trimul_t(const double* __restrict__ Linv, int64_t ldi, int nb,
+__global__ __launch_bounds__(256, 2) void k_trimul_t(const double* __restrict__ Linv, int64_t ldi, int nb,
                                                   const double* __restrict__ V, int64_t ldv, double* __restrict__ W,
                                                   int64_t ldw) {
   extern __shared__ double smem[];
@@ -475,83 +486,68 @@ __global__ __launch_bounds__(256) void k_trimul_t(const double* __restrict__ Lin
   store_tile(acc, W, ldw, (int64_t)ti * TILE, (int64_t)tc * TILE, 1.0, 0.0);
 }
 
-// ---- cross-covariance GEMM fused with the WIPV / WIPStd scoring epilogue ------------------------
-// tile (tc, tz): acc = sum_n kXC[n][c] WZ[n][z];  cross = k(x_c, z) - acc
-// var+(z|c) = base_z - cross^2 / s_c -> NaN / < 1e-12 -> 1e-12 -> * ystd2      (BOBE/gp.py:552-576)
-// pv[c*ldp + tz] = sum_z var+, ps[c*ldp + tz] = sum_z sqrt(var+)  over the tile's valid z.
-template <int KERN>
-__global__ __launch_bounds__(256) void k_cross_score(const double* __restrict__ kXC, int64_t ldk, int nb,
-                                                     const double* __restrict__ WZ, int64_t ldw,
-                                                     const double* __restrict__ CsT, int64_t ldc,
-                                                     const double* __restrict__ ZsT, int64_t ldz, int64_t mvalid,
-                                                     const double* __restrict__ sc, const double* __restrict__ basez,
-                                                     Hyper h, double ystd2, double* __restrict__ pv,
-                                                     double* __restrict__ ps, int64_t ldp,
-                                                     double* __restrict__ var_out, int64_t ldvo) {
-  extern __shared__ double smem[];
-  const int tc = blockIdx.y, tz = blockIdx.x;
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_tile<RC, RC>(acc, kXC, ldk, (int64_t)tc * TILE, WZ, ldw, (int64_t)tz * TILE, 0, (int64_t)nb * TILE, smem);
-  double* xc = smem;                      // [d][128]
-  double* xz = smem + MAX_D * TILE;       // [d][128]
-  double* s_c = smem + 2 * MAX_D * TILE;  // [128]
-  double* b_z = s_c + TILE;               // [128]
-  double* red = b_z + TILE;               // [2][2][128]
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int e = t; e < h.d * TILE; e += 256) {
-    const int j = e >> 7, c = e & 127;
-    xc[j * TILE + c] = CsT[j * ldc + (int64_t)tc * TILE + c];
-    xz[j * TILE + c] = ZsT[j * ldz + (int64_t)tz * TILE + c];
-  }
-  if (t < TILE) {
-    s_c[t] = sc[(int64_t)tc * TILE + t];
-    b_z[t] = basez[(int64_t)tz * TILE + t];
-  }
-  __syncthreads();
+// ---- WIPV / WIPStd scoring of every candidate (BOBE/gp.py:552-576, acquisition.py:438-465) -------
+// crossT[z*ldx + c] = sum_n WZ[n][z] kXC[n][c] (from k_trimul).  For candidate c and integration point z:
+//   cross = k(x_c, z) - crossT;  var+ = base_z - cross^2 / s_c  -> NaN / < 1e-12 -> 1e-12 -> * ystd2
+// wipv[c] = mean_z var+, wipstd[c] = mean_z sqrt(var+).  One workgroup = 64 candidates x 4 interleaved
+// z-slices; per-candidate sums are combined in a fixed order, so results do not depend on chunking.
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_wip_score(const double* __restrict__ crossT, int64_t ldx,
+                                                   const double* __restrict__ CsT, int64_t ldc,
+                                                   const double* __restrict__ ZsT, int64_t ldz, int64_t m,
+                                                   const double* __restrict__ sc, const double* __restrict__ basez,
+                                                   int64_t ncols, Hyper h, double ystd2, double* __restrict__ wipv,
+                                                   double* __restrict__ wipstd, double* __restrict__ var_out,
+                                                   int64_t ldvo) {
+  extern __shared__ double zsm[];          // [d][ZT] + base[ZT]
+  constexpr int ZT = 128;
+  __shared__ double red[2][4][64];
+  const int t = threadIdx.x, cx = t & 63, sl = t >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
+  const bool live = c < ncols;
+  double xc[DCAP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int a = acc_row(i, r);
-      const double s = s_c[a];
-      double sv = 0.0, ss = 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int b = acc_col(j);
-        const int64_t gz = (int64_t)tz * TILE + b;
+  for (int j = 0; j < DCAP; ++j) xc[j] = (live && j < h.d) ? CsT[j * ldc + c] : 0.0;
+  const double s = live ? sc[c] : 1.0;
+  const bool sbad = !(s >= 0.0);           // sqrt(negative) = NaN in fast_update_cholesky (gp.py:187)
+  double sv = 0.0, ss = 0.0;
+  for (int64_t z0 = 0; z0 < m; z0 += ZT) {
+    __syncthreads();
+    for (int e = t; e < h.d * ZT; e += 256) {
+      const int j = e / ZT, zz = e % ZT;
+      zsm[j * ZT + zz] = (z0 + zz < m) ? ZsT[j * ldz + z0 + zz] : 0.0;
+    }
+    if (t < ZT) zsm[h.d * ZT + t] = (z0 + t < m) ? basez[z0 + t] : 0.0;
+    __syncthreads();
+    const int zn = (m - z0 < ZT) ? (int)(m - z0) : ZT;
+    if (live) {
+      for (int zz = sl; zz < zn; zz += 4) {
         double r2 = 0.0;
-        for (int q = 0; q < h.d; ++q) {
-          const double df = xc[q * TILE + a] - xz[q * TILE + b];
-          r2 += df * df;
+#pragma unroll
+        for (int j = 0; j < DCAP; ++j) {
+          if (j < h.d) {
+            const double df = xc[j] - zsm[j * ZT + zz];
+            r2 += df * df;
+          }
         }
-        const double cross = kern_eval<KERN>(r2, h.kvar) - acc[i][j][r];
-        double v = b_z[b] - (cross * cross) / s;
-        if (!(s >= 0.0)) v = NOISE_FLOOR;      // sqrt(negative) = NaN in fast_update_cholesky (gp.py:187)
+        const double cross = kern_eval<KERN>(r2, h.kvar) - crossT[(z0 + zz) * ldx + c];
+        double v = zsm[h.d * ZT + zz] - (cross * cross) / s;
+        if (sbad) v = NOISE_FLOOR;
         if (v != v) v = NOISE_FLOOR;           // gp.py:574
         if (v < NOISE_FLOOR) v = NOISE_FLOOR;  // gp.py:575
         v *= ystd2;                            // gp.py:576
-        if (gz < mvalid) {
-          sv += v;
-          ss += sqrt(v);
-          if (var_out) var_out[((int64_t)tc * TILE + a) * ldvo + gz] = v;
-        }
-      }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        sv += __shfl_xor(sv, o, 64);
-        ss += __shfl_xor(ss, o, 64);
-      }
-      if ((lane & 15) == 0) {
-        red[((wave & 1) * 2 + 0) * TILE + a] = sv;
-        red[((wave & 1) * 2 + 1) * TILE + a] = ss;
+        sv += v;
+        ss += sqrt(v);
+        if (var_out) var_out[c * ldvo + z0 + zz] = v;
       }
     }
+  }
+  red[0][sl][cx] = sv;
+  red[1][sl][cx] = ss;
   __syncthreads();
-  if (t < TILE) {
-    const int64_t gc = (int64_t)tc * TILE + t;
-    pv[gc * ldp + tz] = red[0 * TILE + t] + red[2 * TILE + t];
-    ps[gc * ldp + tz] = red[1 * TILE + t] + red[3 * TILE + t];
+  if (sl == 0 && live) {
+    if (wipv) wipv[c] = ((red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx])) / (double)m;
+    if (wipstd) wipstd[c] = ((red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx])) / (double)m;
   }
 }
 
@@ -621,15 +617,16 @@ __global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w,
   }
 }
 
-// res[j] = 0.5 * sum_tiles partial[tile*stride + j]   (one thread per component, fixed order)
-__global__ void k_grad_reduce(const double* __restrict__ partial, int ntiles, int stride, int d, int dcap,
-                              double* __restrict__ res) {
-  const int j = threadIdx.x;
-  if (j > d) return;
+// res[j] = 0.5 * sum_tiles partial[tile*stride + src(j)]: one wave per component, lane-strided partial
+// sums combined by a fixed butterfly (deterministic).  grid = d+1 blocks of 64 threads.
+__global__ __launch_bounds__(64) void k_grad_reduce(const double* __restrict__ partial, int ntiles, int stride, int d,
+                                                    int dcap, double* __restrict__ res) {
+  const int j = blockIdx.x;
   const int src = (j == d) ? dcap : j;
   double s = 0.0;
-  for (int q = 0; q < ntiles; ++q) s += partial[(int64_t)q * stride + src];
-  res[j] = 0.5 * s;
+  for (int q = threadIdx.x; q < ntiles; q += 64) s += partial[(int64_t)q * stride + src];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) res[j] = 0.5 * s;
 }
 
 // ---- sweep finalisers -------------------------------------------------------------------------------
@@ -649,19 +646,6 @@ __global__ void k_predict_finalize(const double* __restrict__ qpart, int64_t ldq
     if (v < NOISE_FLOOR) v = NOISE_FLOOR;
     var_out[c] = v;
   }
-}
-
-__global__ void k_score_finalize(const double* __restrict__ pv, const double* __restrict__ ps, int64_t ldp, int nzt,
-                                 int64_t m, int64_t ncols, double* __restrict__ wipv, double* __restrict__ wipstd) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
-  double a = 0.0, b = 0.0;
-  for (int z = 0; z < nzt; ++z) {
-    a += pv[c * ldp + z];
-    b += ps[c * ldp + z];
-  }
-  if (wipv) wipv[c] = a / (double)m;
-  if (wipstd) wipstd[c] = b / (double)m;
 }
 
 // argmin with first-occurrence tie-break (jnp.argmin, acquisition.py:397); NaN counts as minimal.
