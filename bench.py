@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--config", default="headline", choices=["tiny", "small", "headline"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-class", default="trimul", help="kernel class timed with HIP events for the roofline")
+    ap.add_argument("--chunk", type=int, default=0, help="candidate chunk of the sweep (0 = library default)")
     return ap.parse_args()
 
 
@@ -98,6 +99,8 @@ def main():
     thetas = theta_schedule(d)
     gp = GP(X, y, noise=noise, kernel="rbf", lengthscales=np.full(d, 0.6), kernel_variance=1.0, device=local)
     lib, h = gp._lib, gp._h
+    if args.chunk:
+        _lib.check(lib.bobe_gp_set_chunk(h, args.chunk), "set_chunk")
     # inputs resident in HBM; outputs stay in HBM
     cand_d = torch.from_numpy(cand).to(dev)
     Z_d = torch.from_numpy(Z).to(dev)
@@ -166,7 +169,7 @@ def main():
         potrf_ms = C.c_double()
         lib.bobe_debug_time_potrf(h, 3, C.byref(potrf_ms))
         Np = (N + 127) // 128 * 128
-        chunk = 2048
+        chunk = args.chunk or 8192
         # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 per candidate, triangular) fused with
         # the cross-covariance rows W_Z^T K(X,C) (2 N M per candidate)
         flops_per_launch = {"trimul": (float(N) * N + 2.0 * N * M) * min(chunk, Cn),

@@ -9,6 +9,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -90,20 +91,30 @@ void configure_kernels_once() {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || done[dev]) return;
-  allow_big_lds(k_potf2_inv<true>, POTF2_SMEM_BYTES);
-  allow_big_lds(k_potf2_inv<false>, POTF2_SMEM_BYTES);
-  allow_big_lds(k_trsm_panel, GEMM_SMEM_BYTES);
-  allow_big_lds(k_syrk_trail, GEMM_SMEM_BYTES);
-  allow_big_lds(k_trtri_T, GEMM_SMEM_BYTES);
-  allow_big_lds(k_trtri_R, GEMM_SMEM_BYTES);
+  allow_big_lds(k_potf2<true, false>, POTF2_SMEM_BYTES);
+  allow_big_lds(k_potf2<false, false>, POTF2_SMEM_BYTES);
+  allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
+  allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
+  allow_big_lds(k_syrk_trail<128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_syrk_trail<64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_trtri_T<64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_trtri_R<64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 8, 64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 16, 64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 32, 64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 8, 64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 16, 64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 32, 64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_trimul, GEMM_SMEM_BYTES);
   allow_big_lds(k_trimul_t, GEMM_SMEM_BYTES);
-  allow_big_lds(k_lauum_grad<0, 8>, GEMM_SMEM_BYTES);
-  allow_big_lds(k_lauum_grad<0, 16>, GEMM_SMEM_BYTES);
-  allow_big_lds(k_lauum_grad<0, 32>, GEMM_SMEM_BYTES);
-  allow_big_lds(k_lauum_grad<1, 8>, GEMM_SMEM_BYTES);
-  allow_big_lds(k_lauum_grad<1, 16>, GEMM_SMEM_BYTES);
-  allow_big_lds(k_lauum_grad<1, 32>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 8, 128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 16, 128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<0, 32, 128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 8, 128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 16, 128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_lauum_grad<1, 32, 128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_kernel_matrix<0, true>, 2 * MAX_D * TILE * 8);
   allow_big_lds(k_kernel_matrix<0, false>, 2 * MAX_D * TILE * 8);
   allow_big_lds(k_kernel_matrix<1, true>, 2 * MAX_D * TILE * 8);
@@ -117,6 +128,22 @@ void configure_kernels_once() {
 
 struct Depth { int first, count, nblocks; };
 
+// tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
+// overridable through the environment for tuning runs
+struct Tuning { int syrk64_below, trtri64_below, lauum64_below, lookahead, reserve_cus; };
+const Tuning& tuning() {
+  static Tuning t = [] {
+    Tuning v{600, 600, 1200, 0, 32};   // lookahead off: cross-stream event cost exceeds the overlap gain
+    if (const char* e = std::getenv("BOBE_SYRK64")) v.syrk64_below = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_LOOKAHEAD")) v.lookahead = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_RESERVE_CUS")) v.reserve_cus = std::atoi(e);
+    return v;
+  }();
+  return t;
+}
+
 }  // namespace
 
 struct bobe_gp {
@@ -129,7 +156,7 @@ struct bobe_gp {
   int nb = 0;
   Hyper hyp;
   bool have_data = false, factored = false, not_pd = false;
-  int64_t chunk = 2048;
+  int64_t chunk = 8192;
 
   DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs;
   // sweep / predict workspace
@@ -137,6 +164,8 @@ struct bobe_gp {
       o_misc, kin_a, kin_b, kout;
   std::vector<Depth> depths;
   double* h_res = nullptr;  // pinned, 128 doubles
+  hipStream_t upd_stream = nullptr;   // trailing updates of the lookahead Cholesky (CU-masked)
+  hipEvent_t ev_panel = nullptr, ev_update = nullptr;
 
   // optional per-kernel-class timing with HIP events on the handle's stream (bobe_gp_profile_*)
   int prof_tag = 0;
@@ -189,8 +218,10 @@ struct bobe_gp {
   void kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT, int64_t ldb,
                            int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo);
   void assemble_kxx(const Hyper& h, const double* xst, double* a);
+  void syrk(double* a, int k, int first, int colmode, hipStream_t st);
   void potrf(double* a, double* linv);
   void trtri(const double* a, double* linv);
+  int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap);
   void solve_alpha(const double* linv, double* wv, double* al);
   void factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al);
   int read_info();
@@ -250,7 +281,7 @@ void bobe_gp::alloc_for_n() {
   XsT2.ensure((size_t)d * vec);
   const int64_t pw = Np > chunk ? Np : chunk;
   part.ensure((size_t)nb * pw * sizeof(double));
-  gpart.ensure((size_t)nb * (nb + 1) / 2 * (MAX_D + 1) * sizeof(double));
+  gpart.ensure((size_t)(2 * nb) * (2 * nb + 1) / 2 * (MAX_D + 1) * sizeof(double));
   res.ensure(128 * sizeof(double));
   info.ensure(sizeof(int));
   build_probs();
@@ -284,37 +315,109 @@ void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a) {
   LAUNCH_CHECK();
 }
 
+void bobe_gp::syrk(double* a, int k, int first, int colmode, hipStream_t st) {
+  const Tuning& tu = tuning();
+  const int rem = nb - first;                 // 128-blocks in the trailing matrix
+  if (rem <= 0) return;
+  const bool small = rem * (rem + 1) / 2 < tu.syrk64_below;
+  if (small) {
+    const int n = 2 * rem;
+    const int grid = colmode ? 2 * n - 1 : n * (n + 1) / 2;
+    hipLaunchKernelGGL(k_syrk_trail<64>, dim3(grid), dim3(256), GEMM64_SMEM_BYTES, st, a, Np, k, first, colmode, n);
+  } else {
+    const int grid = colmode ? rem : rem * (rem + 1) / 2;
+    hipLaunchKernelGGL(k_syrk_trail<128>, dim3(grid), dim3(256), GEMM_SMEM_BYTES, st, a, Np, k, first, colmode, rem);
+  }
+}
+
+// Right-looking blocked Cholesky.  With lookahead the panel chain potf2(k) -> trsm(k) -> update of block
+// column k+1 stays on the handle's stream while the update of the columns >= k+2 runs on a second stream
+// whose CU mask leaves a few CUs free, so the single-workgroup potf2 never waits for an LDS slot.
 void bobe_gp::potrf(double* a, double* linv) {
+  const Tuning& tu = tuning();
+  const bool la = tu.lookahead && upd_stream && nb > 2;
   for (int k = 0; k < nb; ++k) {
     prof_begin(BOBE_PROF_POTF2);
-    hipLaunchKernelGGL(k_potf2_inv<true>, dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
-                       static_cast<int*>(info.p));
+    hipLaunchKernelGGL((k_potf2<true, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
+                       static_cast<int*>(info.p), (unsigned long long*)nullptr);
     prof_end(BOBE_PROF_POTF2);
     const int rem = nb - k - 1;
     if (rem > 0) {
       prof_begin(BOBE_PROF_TRSM);
-    hipLaunchKernelGGL(k_trsm_panel, dim3(rem), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np, k);
-    prof_end(BOBE_PROF_TRSM);
-      prof_begin(BOBE_PROF_SYRK);
-    hipLaunchKernelGGL(k_syrk_trail, dim3(rem * (rem + 1) / 2), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, k);
-    prof_end(BOBE_PROF_SYRK);
+      hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rem), dim3(256), TRSM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np, k,
+                         (unsigned long long*)nullptr);
+      prof_end(BOBE_PROF_TRSM);
+      if (!la) {
+        prof_begin(BOBE_PROF_SYRK);
+        syrk(a, k, k + 1, 0, stream);
+        prof_end(BOBE_PROF_SYRK);
+      } else {
+        HIPCHK(hipEventRecord(ev_panel, stream));                 // panel k is final
+        HIPCHK(hipStreamWaitEvent(upd_stream, ev_panel, 0));
+        if (k > 0) HIPCHK(hipStreamWaitEvent(stream, ev_update, 0));   // update k-1 touched block column k+1 too
+        syrk(a, k, k + 1, 1, stream);                             // next panel's column: critical path
+        if (rem > 1) {
+          syrk(a, k, k + 2, 0, upd_stream);                       // the rest, overlapped with panel k+1
+          HIPCHK(hipEventRecord(ev_update, upd_stream));
+        }
+      }
     }
   }
+  if (la) HIPCHK(hipStreamWaitEvent(stream, ev_update, 0));
   LAUNCH_CHECK();
 }
 
+// Linv = L^-1: diagonal 128-blocks in one batched launch, then recursive doubling (two GEMM launches per level)
 void bobe_gp::trtri(const double* a, double* linv) {
+  const Tuning& tu = tuning();
+  prof_begin(BOBE_PROF_TRTRI);
+  hipLaunchKernelGGL(k_trti_diag, dim3(nb), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np);
+  prof_end(BOBE_PROF_TRTRI);
   for (int dd = (int)depths.size() - 1; dd >= 0; --dd) {
     const Depth& D = depths[dd];
     const TriProb* pr = static_cast<const TriProb*>(probs.p) + D.first;
     prof_begin(BOBE_PROF_TRTRI);
-    hipLaunchKernelGGL(k_trtri_T, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np,
-                       Tmp.d(), Np, pr, D.count);
-    hipLaunchKernelGGL(k_trtri_R, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, linv, Np, (const double*)Tmp.d(),
-                       Np, pr, D.count);
+    if (D.nblocks < tu.trtri64_below) {
+      hipLaunchKernelGGL(k_trtri_T<64>, dim3(2 * D.nblocks), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
+                         (const double*)linv, Np, Tmp.d(), Np, pr, D.count);
+      hipLaunchKernelGGL(k_trtri_R<64>, dim3(2 * D.nblocks), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
+                         (const double*)Tmp.d(), Np, pr, D.count);
+    } else {
+      hipLaunchKernelGGL(k_trtri_T<128>, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, a, Np,
+                         (const double*)linv, Np, Tmp.d(), Np, pr, D.count);
+      hipLaunchKernelGGL(k_trtri_R<128>, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, linv, Np,
+                         (const double*)Tmp.d(), Np, pr, D.count);
+    }
     prof_end(BOBE_PROF_TRTRI);
   }
   LAUNCH_CHECK();
+}
+
+// K^-1 tiles fused with the gradient partial sums (optionally stores K^-1's lower tiles); returns #partials
+int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap) {
+  const Tuning& tu = tuning();
+  const bool small = nb * (nb + 1) / 2 < tu.lauum64_below;
+  const int nt = small ? 2 * nb : nb;
+  const int ntiles = nt * (nt + 1) / 2;
+#define LG(KE, DC, TT)                                                                                          \
+  hipLaunchKernelGGL((k_lauum_grad<KE, DC, TT>), dim3(ntiles), dim3(256),                                       \
+                     (TT == 128 ? GEMM_SMEM_BYTES : GEMM64_SMEM_BYTES), stream, linv, Np, Np, N, al, xst, Np, h, \
+                     gpart.d(), kinv_out, Np)
+#define LGD(KE, TT)                                                                 \
+  do {                                                                              \
+    if (dcap == 8) LG(KE, 8, TT); else if (dcap == 16) LG(KE, 16, TT); else LG(KE, 32, TT); \
+  } while (0)
+  prof_begin(BOBE_PROF_LAUUM);
+  if (h.kern == 0) {
+    if (small) LGD(0, 64); else LGD(0, 128);
+  } else {
+    if (small) LGD(1, 64); else LGD(1, 128);
+  }
+  prof_end(BOBE_PROF_LAUUM);
+#undef LGD
+#undef LG
+  LAUNCH_CHECK();
+  return ntiles;
 }
 
 void bobe_gp::solve_alpha(const double* linv, double* wv, double* al) {
@@ -540,6 +643,27 @@ int bobe_gp_create(bobe_gp_t** out, int device, int kernel, int d) {
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     g->own_stream = true;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->h_res), 128 * sizeof(double), hipHostMallocDefault));
+    if (tuning().lookahead) {
+      // second stream for the bulk trailing updates; its CU mask leaves `reserve_cus` CUs to the panel chain
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, device));
+      const int ncu = prop.multiProcessorCount;
+      const int keep = std::max(0, std::min(tuning().reserve_cus, ncu / 2));
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      // CUs are numbered round-robin over the shader engines, so taking every (ncu/keep)-th CU out keeps the
+      // reserved set spread over the chip
+      const int stride = keep > 0 ? ncu / keep : 0;
+      for (int c = 0; c < ncu; ++c) {
+        const bool reserved = keep > 0 && (c % stride == 0) && (c / stride < keep);
+        if (!reserved) mask[c / 32] |= (1u << (c % 32));
+      }
+      if (hipExtStreamCreateWithCUMask(&g->upd_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipStreamCreateWithFlags(&g->upd_stream, hipStreamNonBlocking));
+      }
+      HIPCHK(hipEventCreateWithFlags(&g->ev_panel, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&g->ev_update, hipEventDisableTiming));
+    }
   } catch (...) {
     delete g;
     throw;
@@ -563,6 +687,12 @@ void bobe_gp_destroy(bobe_gp_t* g) {
     (void)hipEventDestroy(pr.second);
   }
   if (g->h_res) (void)hipHostFree(g->h_res);
+  if (g->upd_stream) {
+    (void)hipStreamSynchronize(g->upd_stream);
+    (void)hipStreamDestroy(g->upd_stream);
+  }
+  if (g->ev_panel) (void)hipEventDestroy(g->ev_panel);
+  if (g->ev_update) (void)hipEventDestroy(g->ev_update);
   if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -593,7 +723,7 @@ int bobe_gp_sync(bobe_gp_t* g) {
 int bobe_gp_set_chunk(bobe_gp_t* g, int64_t chunk) {
   API_BEGIN
   if (!g) throw Err(BOBE_ERR_ARG, "gp is NULL");
-  if (chunk == 0) chunk = 2048;
+  if (chunk == 0) chunk = 8192;
   if (chunk < TILE || chunk % TILE) throw Err(BOBE_ERR_ARG, "chunk must be a positive multiple of 128");
   g->use();
   g->sync();
@@ -678,20 +808,8 @@ int bobe_gp_mll(bobe_gp_t* g, const double* ls, double kvar, double* mll, double
                      g->Np, g->Np, g->res.d());
   const int d = g->d;
   if (grad) {
-    const int ntiles = g->nb * (g->nb + 1) / 2;
     const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
-#define LG(KE, DC)                                                                                                   \
-  hipLaunchKernelGGL((k_lauum_grad<KE, DC>), dim3(ntiles), dim3(256), GEMM_SMEM_BYTES, g->stream,                   \
-                     (const double*)g->Linv2.d(), g->Np, g->nb, g->N, (const double*)g->alpha2.d(),                  \
-                     (const double*)g->XsT2.d(), g->Np, h, g->gpart.d(), (double*)nullptr, (int64_t)0)
-    g->prof_begin(BOBE_PROF_LAUUM);
-    if (h.kern == 0) {
-      if (dcap == 8) LG(0, 8); else if (dcap == 16) LG(0, 16); else LG(0, 32);
-    } else {
-      if (dcap == 8) LG(1, 8); else if (dcap == 16) LG(1, 16); else LG(1, 32);
-    }
-#undef LG
-    g->prof_end(BOBE_PROF_LAUUM);
+    const int ntiles = g->lauum(h, g->Linv2.d(), g->alpha2.d(), g->XsT2.d(), nullptr, dcap);
     hipLaunchKernelGGL(k_grad_reduce, dim3(d + 1), dim3(64), 0, g->stream, (const double*)g->gpart.d(), ntiles, dcap + 1, d,
                        dcap, g->res.d() + 2);
   }
@@ -843,8 +961,8 @@ int bobe_gp_set_chol(bobe_gp_t* g, const double* L, const double* alpha) {
                         is_device_ptr(alpha) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g->stream));
   g->scale(g->X.d(), N, Np, g->hyp, g->XsT.d(), Np);
   for (int k = 0; k < g->nb; ++k)
-    hipLaunchKernelGGL(k_potf2_inv<false>, dim3(1), dim3(256), POTF2_SMEM_BYTES, g->stream, g->A.d(), Np, g->Linv.d(), Np,
-                       k, static_cast<int*>(g->info.p));
+    hipLaunchKernelGGL((k_potf2<false, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, g->stream, g->A.d(), Np, g->Linv.d(), Np,
+                       k, static_cast<int*>(g->info.p), (unsigned long long*)nullptr);
   LAUNCH_CHECK();
   g->trtri(g->A.d(), g->Linv.d());
   g->sync();
@@ -885,11 +1003,7 @@ int bobe_debug_kinv(bobe_gp_t* g, double* Kinv) {
   if (!g || !Kinv) throw Err(BOBE_ERR_ARG, "NULL argument");
   if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
   g->use();
-  const int ntiles = g->nb * (g->nb + 1) / 2;
-  hipLaunchKernelGGL((k_lauum_grad<0, 32>), dim3(ntiles), dim3(256), GEMM_SMEM_BYTES, g->stream,
-                     (const double*)g->Linv.d(), g->Np, g->nb, g->N, (const double*)g->alpha.d(),
-                     (const double*)g->XsT.d(), g->Np, g->hyp, g->gpart.d(), g->Tmp.d(), g->Np);
-  LAUNCH_CHECK();
+  g->lauum(g->hyp, g->Linv.d(), g->alpha.d(), g->XsT.d(), g->Tmp.d(), 32);
   // symmetrise on the host side of the copy
   const int64_t N = g->N;
   std::vector<double> full((size_t)N * N);

@@ -1,0 +1,524 @@
+// Blocked Cholesky, triangular inverse and K^-1/gradient kernels (gfx950).  Included by kernels.hpp.
+//
+// Right-looking blocked Cholesky with NB = 128:
+//   k_potf2        one workgroup factors the 128x128 diagonal block in LDS and leaves the inverses of
+//                  its eight 16x16 diagonal sub-blocks in the diagonal block of Linv
+//   k_trsm_panel   L21 = A21 L11^-T, register resident: each wave keeps 16 rows x 128 columns as eight
+//                  transposed 16x16 MFMA accumulators and substitutes block column by block column
+//   k_syrk_trail   A22 -= L21 L21^T on the lower tiles (128x128 or 64x64 tiles)
+// Triangular inverse (needed by alpha, predictions and the gradient):
+//   k_trti_diag    all diagonal 128x128 blocks at once (one workgroup each)
+//   k_trtri_T/R    recursive doubling over 128-blocks, two GEMM launches per level
+//   k_lauum_grad   K^-1 = Linv^T Linv tile by tile, fused with the d+1 gradient reductions
+#pragma once
+
+namespace bobe {
+
+constexpr int PLD = 130;                          // LDS leading dimension of a 128x128 block (doubles)
+
+// coalesced 128x128 block <-> LDS (16-byte accesses, one row per wave per step)
+__device__ __forceinline__ void block_load(double* S, const double* __restrict__ G, int64_t ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v2d v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = *reinterpret_cast<const v2d*>(G + (int64_t)(4 * i + wave) * ld + 2 * lane);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) *reinterpret_cast<v2d*>(S + (4 * i + wave) * PLD + 2 * lane) = v[i];
+}
+// store the lower triangle (zeros above the diagonal)
+__device__ __forceinline__ void block_store_lower(const double* S, double* __restrict__ G, int64_t ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) {
+    const int r = 4 * i + wave, c = 2 * lane;
+    v2d v = *reinterpret_cast<const v2d*>(S + r * PLD + c);
+    if (c > r) v[0] = 0.0;
+    if (c + 1 > r) v[1] = 0.0;
+    *reinterpret_cast<v2d*>(G + (int64_t)r * ld + c) = v;
+  }
+}
+
+// diagnostic cycle stamps (template-disabled in the production instantiations)
+#define BOBE_STAMP(idx)                                                        \
+  do {                                                                         \
+    if (STAMP && threadIdx.x == 0) stamps[(idx)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+// 1/sqrt(a): hardware estimate + two Newton steps (error ~1 ulp); NaN for a < 0, +inf for a = 0
+__device__ __forceinline__ double rsqrt_nr(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  double e = __builtin_fma(-a * y, y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  e = __builtin_fma(-a * y, y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  return y;
+}
+
+// ---- diagonal block -------------------------------------------------------------------------------
+// FACTOR: Cholesky of A[blk][blk] in place (lower, zeros above).  Always: the inverses of the eight
+// 16x16 diagonal sub-blocks go to the same positions of Linv[blk][blk] (rest of that block untouched).
+// A non-positive pivot makes the result NaN (like XLA) and records the column in *info.
+//
+// Per 16-column step p:
+//   A  wave 0 factors the 16x16 diagonal sub-block right-looking, one matrix row per lane; lanes 16..31
+//      carry the rows of an identity matrix through the same column operations, which multiplies them by
+//      Lpp^-T: the inverse of the sub-block comes for free.  Meanwhile waves 1..3 apply the deferred
+//      (non-urgent) updates of step p-1.
+//   B  rows below: X^T = inv(Lpp) A^T, four MFMAs per 16-row tile.
+//   C  urgent updates: the tiles of block column p+1 (needed by the next A and B); the tiles of the
+//      columns >= p+2 are deferred to the next step's phase A.
+constexpr int POTF2_DLD = 17;
+constexpr int POTF2_SMEM_BYTES = (TILE * PLD + 8 * 16 * POTF2_DLD) * 8;   // 150,528 B
+
+// integer-only lower-triangular decode for small indices (t = i(i+1)/2 + j, i < 8)
+__device__ __forceinline__ void tri_decode_small(int t, int& i, int& j) {
+  int ii = 0;
+#pragma unroll
+  for (int c = 1; c < 8; ++c) ii += (t >= c * (c + 1) / 2) ? 1 : 0;
+  i = ii;
+  j = t - ii * (ii + 1) / 2;
+}
+
+// S[ti][tj] -= L[ti][p] L[tj][p]^T for two 16x16 tiles at once (independent MFMA chains)
+__device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0, int ti1, int tj1, bool two, int lane) {
+  v4d acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc0[r] = S[(16 * ti0 + (lane >> 4) + 4 * r) * PLD + 16 * tj0 + (lane & 15)];
+    acc1[r] = S[(16 * ti1 + (lane >> 4) + 4 * r) * PLD + 16 * tj1 + (lane & 15)];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const double av0 = -S[(16 * ti0 + (lane & 15)) * PLD + o + 4 * ks + (lane >> 4)];
+    const double bv0 = S[(16 * tj0 + (lane & 15)) * PLD + o + 4 * ks + (lane >> 4)];
+    const double av1 = -S[(16 * ti1 + (lane & 15)) * PLD + o + 4 * ks + (lane >> 4)];
+    const double bv1 = S[(16 * tj1 + (lane & 15)) * PLD + o + 4 * ks + (lane >> 4)];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv1, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(16 * ti0 + (lane >> 4) + 4 * r) * PLD + 16 * tj0 + (lane & 15)] = acc0[r];
+  if (two) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(16 * ti1 + (lane >> 4) + 4 * r) * PLD + 16 * tj1 + (lane & 15)] = acc1[r];
+  }
+}
+
+template <bool FACTOR, bool STAMP = false>
+__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
+                                               int64_t ldl, int blk, int* __restrict__ info,
+                                               unsigned long long* __restrict__ stamps = nullptr) {
+  extern __shared__ double S[];
+  double* Dall = S + TILE * PLD;  // [8][16][POTF2_DLD]: inverses of the 16x16 diagonal sub-blocks
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  double* Ab = A + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
+  double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
+  BOBE_STAMP(0);
+  block_load(S, Ab, lda);
+  __syncthreads();
+  BOBE_STAMP(1);
+
+  for (int p = 0; FACTOR && p < 8; ++p) {
+    const int o = 16 * p;
+    double* Dv = Dall + p * 16 * POTF2_DLD;
+    BOBE_STAMP(2 + 3 * p);
+    if (wave == 0) {
+      // ---- phase A, wave 0: 16x16 Cholesky + inverse (upper half-wave idle: EXEC[63:32] = 0) ----
+      if (lane < 32) {
+      const int li = lane & 15;
+      const bool ident = (lane >= 16) && (lane < 32);
+      double r[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) r[c] = ident ? ((c == li) ? 1.0 : 0.0) : S[(o + li) * PLD + o + c];
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double ajj = readlane_f64(r[j], j);
+        if (!(ajj > 0.0)) bad = true;
+        const double inv = rsqrt_nr(ajj);
+        r[j] *= inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+          const double lcj = readlane_f64(r[j], c);
+          r[c] = __builtin_fma(-r[j], lcj, r[c]);
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) S[(o + li) * PLD + o + c] = (c <= li) ? r[c] : 0.0;
+      } else if (ident) {
+        // lane 16+i holds row i of Lpp^-T: r[c] = inv(Lpp)[c][i]
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Dv[c * POTF2_DLD + li] = r[c];
+      }
+      if (bad && lane == 0) atomicMin(info, blk * TILE + o + 1);
+      }
+    } else if (p > 0) {
+      // ---- phase A, waves 1..3: deferred updates of step p-1 (tiles with tj >= p+1) ----
+      const int op = o - 16;
+      const int nt = 7 - p;                 // tiles p+1..7
+      const int ntiles = nt * (nt + 1) / 2;
+      for (int q = wave - 1; q < ntiles; q += 6) {
+        int a0, b0, a1, b1;
+        tri_decode_small(q, a0, b0);
+        const bool two = (q + 3) < ntiles;
+        tri_decode_small(two ? q + 3 : q, a1, b1);
+        potf2_update2(S, op, p + 1 + a0, p + 1 + b0, p + 1 + a1, p + 1 + b1, two, lane);
+      }
+    }
+    __syncthreads();
+    BOBE_STAMP(3 + 3 * p);
+    // ---- phase B: rows below, X^T = inv(Lpp) * A^T per 16-row tile ----
+    for (int tt = p + 1 + wave; tt < 8; tt += 4) {
+      v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double av = Dv[(lane & 15) * POTF2_DLD + (lane >> 4) + 4 * r];
+        const double bv = S[(16 * tt + (lane & 15)) * PLD + o + (lane >> 4) + 4 * r];
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(16 * tt + (lane & 15)) * PLD + o + (lane >> 4) + 4 * r] = y[r];
+    }
+    __syncthreads();
+    BOBE_STAMP(4 + 3 * p);
+    // ---- phase C: urgent updates, block column p+1: tiles (tt, p+1), tt = p+1..7 ----
+    if (p < 7) {
+      const int tt0 = p + 1 + wave, tt1 = tt0 + 4;
+      if (tt0 < 8) potf2_update2(S, o, tt0, p + 1, (tt1 < 8) ? tt1 : tt0, p + 1, tt1 < 8, lane);
+    }
+    __syncthreads();
+  }
+  BOBE_STAMP(26);
+  if (FACTOR) {
+    block_store_lower(S, Ab, lda);
+    // the eight 16x16 inverses: thread t -> sub-block t>>5, row (t>>1)&15, half row t&1
+    const int bb = t >> 5, rr = (t >> 1) & 15, hh = t & 1;
+    const double* src = Dall + (bb * 16 + rr) * POTF2_DLD + 8 * hh;
+    double* dst = Ib + (int64_t)(16 * bb + rr) * ldl + 16 * bb + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dst[c] = src[c];
+  }
+  BOBE_STAMP(27);
+  if (!FACTOR && t < 128) {
+    // given L (restore path): inverses of the eight 16x16 diagonal sub-blocks, one column per thread
+    const int bb = t >> 4, col = t & 15, o = 16 * bb;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double s = (r == col) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) s = __builtin_fma(-S[(o + r) * PLD + o + k], x[k], s);
+      x[r] = s / S[(o + r) * PLD + o + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ib[(int64_t)(o + r) * ldl + o + col] = x[r];
+  }
+  BOBE_STAMP(28);
+}
+
+// ---- inverse of every diagonal 128x128 block (grid = nb) --------------------------------------------
+// in: L[blk][blk] (lower) and the 16x16 diagonal inverses left in Linv[blk][blk] by k_potf2.
+// out: Linv[blk][blk] = L[blk][blk]^-1 (lower, zeros above).
+__global__ __launch_bounds__(256) void k_trti_diag(const double* __restrict__ L, int64_t lda,
+                                                   double* __restrict__ Linv, int64_t ldl) {
+  extern __shared__ double S[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int blk = blockIdx.x;
+  const double* Lb = L + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
+  double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
+  block_load(S, Lb, lda);
+  __syncthreads();
+  if (t < 128) {   // overwrite the diagonal 16x16 sub-blocks with their inverses
+    const int bb = t >> 4, col = t & 15, o = 16 * bb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[(o + r) * PLD + o + col] = Ib[(int64_t)(o + r) * ldl + o + col];
+  }
+  __syncthreads();
+  // block rows 1..7:  inv[i][j] = -inv[i][i] * sum_{k=j}^{i-1} L[i][k] inv[k][j]
+  for (int i = 1; i < 8; ++i) {
+    v4d res0 = (v4d){0.0, 0.0, 0.0, 0.0}, res1 = res0;
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int j = wave + 4 * slot;
+      if (j < i) {
+        v4d tacc = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int k = j; k < i; ++k) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const double av = S[(16 * i + (lane & 15)) * PLD + 16 * k + 4 * ks + (lane >> 4)];
+            const double bv = S[(16 * k + 4 * ks + (lane >> 4)) * PLD + 16 * j + (lane & 15)];
+            tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, tacc, 0, 0, 0);
+          }
+        }
+        // R = -inv[i][i] * T ; T's accumulator register r holds row (lane>>4)+4r, used as the k index
+        v4d racc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double av = -S[(16 * i + (lane & 15)) * PLD + 16 * i + (lane >> 4) + 4 * r];
+          racc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tacc[r], racc, 0, 0, 0);
+        }
+        if (slot == 0) res0 = racc; else res1 = racc;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const int j = wave + 4 * slot;
+      if (j < i) {
+        const v4d racc = slot == 0 ? res0 : res1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(16 * i + (lane >> 4) + 4 * r) * PLD + 16 * j + (lane & 15)] = racc[r];
+      }
+    }
+    __syncthreads();
+  }
+  block_store_lower(S, Ib, ldl);
+}
+
+// ---- panel: A[r][k-block] <- A[r][k-block] * L_kk^-T for rows r >= (k+1)*128 ------------------------
+// grid = rows/64; the workgroup stages L_kk (lower) and the eight 16x16 diagonal inverses in LDS; each
+// wave owns 16 rows and keeps them as eight transposed 16x16 accumulators X^T_p:
+//   X^T_p = invD_p * (A^T_p - sum_{q<p} L_kk[p][q] X^T_q)
+// (an accumulator's register r holds row (lane>>4)+4r, which serves as the k index of the next MFMA).
+constexpr int TRSM_DLD = 17;                                             // leading dim of a staged 16x16 inverse
+constexpr int TRSM_SMEM_BYTES = (TILE * PLD + 8 * 16 * TRSM_DLD) * 8;    // 150,528 B
+template <bool STAMP = false>
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int64_t lda,
+                                                    const double* __restrict__ Dinv, int64_t ldl, int k,
+                                                    unsigned long long* __restrict__ stamps = nullptr) {
+  extern __shared__ double S[];
+  BOBE_STAMP(0);
+  double* D = S + TILE * PLD;   // [8][16][TRSM_DLD]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)blockIdx.x * 64 + wave * 16;
+  const int64_t col0 = (int64_t)k * TILE;
+  const double* Lkk = A + col0 * lda + col0;
+  const double* Dk = Dinv + col0 * ldl + col0;
+  const int g = lane >> 4, li = lane & 15;
+  // this wave's 16 rows -> registers (issued first so the loads overlap the LDS staging)
+  double* Ar = A + (row0 + li) * lda + col0;
+  v4d X[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[p][r] = Ar[16 * p + g + 4 * r];
+  // stage L_kk (one row per wave per step, 16-byte accesses; unpredicated so all loads are in flight together)
+  block_load(S, Lkk, lda);
+  // and the eight diagonal inverses: thread t -> block t>>5, row (t>>1)&15, half t&1 (8 doubles)
+  {
+    const int bb = t >> 5, rr = (t >> 1) & 15, hh = t & 1;
+    const double* src = Dk + (int64_t)(16 * bb + rr) * ldl + 16 * bb + 8 * hh;
+    double* dst = D + (bb * 16 + rr) * TRSM_DLD + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dst[c] = src[c];
+  }
+  __syncthreads();
+  BOBE_STAMP(1);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    v4d x = X[p];
+#pragma unroll
+    for (int q = 0; q < p; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double av = -S[(16 * p + li) * PLD + 16 * q + g + 4 * r];
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[q][r], x, 0, 0, 0);
+      }
+    v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double av = D[(p * 16 + li) * TRSM_DLD + g + 4 * r];
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, x[r], y, 0, 0, 0);
+    }
+    X[p] = y;
+  }
+  BOBE_STAMP(2);
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ar[16 * p + g + 4 * r] = X[p][r];
+  BOBE_STAMP(3);
+}
+
+// ---- trailing update: A[i][j] -= L[i][k] L[j][k]^T over lower T x T tiles of the trailing matrix -------
+// The tiles start at 128-block `first`.  colmode 0: every lower tile (grid = n(n+1)/2, n = (Np-first*128)/T).
+// colmode 1: only the tiles of 128-block column `first` (the next panel; grid = (128/T)*n - (T==64 ? 1 : 0)).
+// The lookahead Cholesky issues colmode 1 for block k+1 on the panel stream and colmode 0 from block k+2
+// on the update stream.
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k, int first,
+                                                       int colmode, int n) {
+  extern __shared__ double smem[];
+  int a, b;
+  if (colmode == 0) {
+    tri_decode(blockIdx.x, a, b);
+  } else if (T == 128 || (int)blockIdx.x < n) {
+    a = blockIdx.x;
+    b = 0;
+  } else {
+    a = blockIdx.x - n + 1;
+    b = 1;
+  }
+  const int64_t base = (int64_t)first * TILE;
+  v4d acc[T / 32][T / 32];
+  acc_zero(acc);
+  gemm_tile<KC, KC, T, T, TileCfg<T>::bk>(acc, A, lda, base + (int64_t)a * T, A, lda, base + (int64_t)b * T,
+                                          (int64_t)k * TILE, (int64_t)(k + 1) * TILE, smem);
+  store_tile<T, T>(acc, A, lda, base + (int64_t)a * T, base + (int64_t)b * T, -1.0, 1.0);
+}
+
+// ---- recursive triangular inverse ------------------------------------------------------------------
+// problem {lo, mid, hi} in 128-block units: with inv[lo:mid) and inv[mid:hi) known,
+//   Tm = L[mid:hi, lo:mid) * inv[lo:mid)            (k_trtri_T, written to Tmp)
+//   inv[mid:hi, lo:mid) = -inv[mid:hi) * Tm          (k_trtri_R)
+// `off` counts T x T tiles: a problem owns (hi-mid)(mid-lo)(128/T)^2 consecutive blocks.
+struct TriProb { int lo, mid, hi, off; };
+
+// Locate the problem of workgroup `bid`.  T = 128: one tile per workgroup.  T = 64: a workgroup owns the
+// two tiles e and nt-1-e of its problem's heavy-first enumeration, whose K lengths are complementary,
+// so every workgroup of a problem does the same amount of work.
+template <int T>
+__device__ __forceinline__ bool tri_find(const TriProb* __restrict__ probs, int nprob, int bid, TriProb& p, int& e0,
+                                         int& e1) {
+  constexpr int S = (TILE / T) * (TILE / T);
+  for (int q = 0; q < nprob; ++q) {
+    const TriProb c = probs[q];
+    const int nt = (c.hi - c.mid) * (c.mid - c.lo) * S;
+    const int nw = (T == 128) ? nt : nt / 2;
+    const int o = (T == 128) ? c.off : c.off * S / 2;
+    if (bid >= o && bid < o + nw) {
+      p = c;
+      e0 = bid - o;
+      e1 = (T == 128) ? -1 : nt - 1 - e0;
+      return true;
+    }
+  }
+  return false;
+}
+
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L, int64_t ldl,
+                                                    const double* __restrict__ Linv, int64_t ldi,
+                                                    double* __restrict__ Tmp, int64_t ldt,
+                                                    const TriProb* __restrict__ probs, int nprob) {
+  extern __shared__ double smem[];
+  TriProb p;
+  int e[2];
+  if (!tri_find<T>(probs, nprob, blockIdx.x, p, e[0], e[1])) return;
+  const int rows = (p.hi - p.mid) * (TILE / T);
+  for (int u = 0; u < 2; ++u) {
+    if (e[u] < 0) continue;
+    const int tj = e[u] / rows, ti = e[u] % rows;          // column-major: small tj (long K) first
+    const int64_t m0 = (int64_t)p.mid * TILE + (int64_t)ti * T, n0 = (int64_t)p.lo * TILE + (int64_t)tj * T;
+    v4d acc[T / 32][T / 32];
+    acc_zero(acc);
+    gemm_tile<KC, RC, T, T, TileCfg<T>::bk>(acc, L, ldl, m0, Linv, ldi, n0, n0, (int64_t)p.mid * TILE, smem);
+    store_tile<T, T>(acc, Tmp, ldt, m0, n0, 1.0, 0.0);
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, int64_t ldi,
+                                                    const double* __restrict__ Tmp, int64_t ldt,
+                                                    const TriProb* __restrict__ probs, int nprob) {
+  extern __shared__ double smem[];
+  TriProb p;
+  int e[2];
+  if (!tri_find<T>(probs, nprob, blockIdx.x, p, e[0], e[1])) return;
+  const int rows = (p.hi - p.mid) * (TILE / T), w = (p.mid - p.lo) * (TILE / T);
+  for (int u = 0; u < 2; ++u) {
+    if (e[u] < 0) continue;
+    const int ti = rows - 1 - e[u] / w, tj = e[u] % w;     // bottom rows (long K) first
+    const int64_t m0 = (int64_t)p.mid * TILE + (int64_t)ti * T, n0 = (int64_t)p.lo * TILE + (int64_t)tj * T;
+    v4d acc[T / 32][T / 32];
+    acc_zero(acc);
+    gemm_tile<KC, RC, T, T, TileCfg<T>::bk>(acc, Linv, ldi, m0, Tmp, ldt, n0, (int64_t)p.mid * TILE, m0 + T, smem);
+    store_tile<T, T>(acc, Linv, ldi, m0, n0, -1.0, 0.0);
+  }
+}
+
+// ---- K^-1 = Linv^T Linv fused with the MLL gradient reduction ------------------------------------------
+// lower T x T tile (ti >= tj): Kinv = sum_{k >= ti*T} Linv[k][ti]^T Linv[k][tj];  W = alpha alpha^T - Kinv.
+// partial[(blockIdx.x)*(DCAP+1) + j] = sum_ab W_ab dK_ab/dlog ls_j (j < d), [DCAP] = sum_ab W_ab Kt_ab,
+// off-diagonal tiles weighted x2.  Optionally stores Kinv (lower tiles) for tests.
+template <int KERN, int DCAP, int T>
+__global__ __launch_bounds__(256, 2) void k_lauum_grad(const double* __restrict__ Linv, int64_t ldi, int64_t np,
+                                                       int64_t n, const double* __restrict__ alpha,
+                                                       const double* __restrict__ XsT, int64_t ldx, Hyper h,
+                                                       double* __restrict__ partial, double* __restrict__ Kinv,
+                                                       int64_t ldk) {
+  extern __shared__ double smem[];
+  int ti, tj;
+  tri_decode(blockIdx.x, ti, tj);
+  v4d acc[T / 32][T / 32];
+  acc_zero(acc);
+  gemm_tile<RC, RC, T, T, TileCfg<T>::bk>(acc, Linv, ldi, (int64_t)ti * T, Linv, ldi, (int64_t)tj * T, (int64_t)ti * T, np,
+                                          smem);
+  if (Kinv) store_tile<T, T>(acc, Kinv, ldk, (int64_t)ti * T, (int64_t)tj * T, 1.0, 0.0);
+  // stage coordinates and alpha in the (now free) GEMM LDS
+  double* xa = smem;                  // [d][T]
+  double* xb = smem + MAX_D * T;      // [d][T]
+  double* aa = smem + 2 * MAX_D * T;  // [T]
+  double* ab = aa + T;                // [T]
+  double* red = ab + T;               // [4][DCAP+1]
+  const int t = threadIdx.x;
+  for (int e = t; e < h.d * T; e += 256) {
+    const int j = e / T, c = e % T;
+    xa[j * T + c] = XsT[j * ldx + (int64_t)ti * T + c];
+    xb[j * T + c] = XsT[j * ldx + (int64_t)tj * T + c];
+  }
+  if (t < T) {
+    aa[t] = alpha[(int64_t)ti * T + t];
+    ab[t] = alpha[(int64_t)tj * T + t];
+  }
+  __syncthreads();
+  double g[DCAP + 1];
+#pragma unroll
+  for (int j = 0; j <= DCAP; ++j) g[j] = 0.0;
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i)
+#pragma unroll
+    for (int jj = 0; jj < T / 32; ++jj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = acc_row<T>(i, r), b = acc_col<T>(jj);
+        const int64_t ga = (int64_t)ti * T + a, gb = (int64_t)tj * T + b;
+        if (ga < n && gb < n) {
+          const double w = aa[a] * ab[b] - acc[i][jj][r];
+          double dsq[DCAP];
+          double r2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) {
+            if (j < h.d) {
+              const double df = xa[j * T + a] - xb[j * T + b];
+              dsq[j] = df * df;
+              r2 += dsq[j];
+            } else {
+              dsq[j] = 0.0;
+            }
+          }
+          const double kv = kern_eval<KERN>(r2, h.kvar);
+          const double wf = w * kern_grad_factor<KERN>(r2, h.kvar, kv);
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) g[j] += wf * dsq[j];
+          g[DCAP] += w * kv;
+        }
+      }
+  const double wt = (ti == tj) ? 1.0 : 2.0;
+  const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int j = 0; j <= DCAP; ++j) {
+    const double s = wave_sum(g[j]);
+    if (lane == 0) red[wave * (DCAP + 1) + j] = s;
+  }
+  __syncthreads();
+  if (t <= DCAP) {
+    const double s = ((red[t] + red[(DCAP + 1) + t]) + red[2 * (DCAP + 1) + t]) + red[3 * (DCAP + 1) + t];
+    partial[(int64_t)blockIdx.x * (DCAP + 1) + t] = wt * s;
+  }
+}
+
+}  // namespace bobe

@@ -1,24 +1,26 @@
 // fp64 MFMA tile GEMM core for gfx950 (MI355X / CDNA4).
 //
-// One workgroup = 256 threads = 4 waves (2x2), output tile 128x128, K-step 16.
-// Each wave owns a 64x64 sub-tile = 4x4 fragments of v_mfma_f64_16x16x4_f64
-// (64 f64 accumulators per lane).  Operands are staged global -> registers -> LDS
-// (double-buffered, one barrier per K-step) and read back as MFMA fragments with
-// conflict-free ds_read_b64:
+// One workgroup = 256 threads = 4 waves (2x2), output tile TM x TN (128 or 64 each), K-step BK (16 or 32).
+// Each wave owns a (TM/2)x(TN/2) sub-tile = (TM/32)x(TN/32) fragments of v_mfma_f64_16x16x4_f64.
+// Operands are staged global -> registers -> LDS (double-buffered, one barrier per K-step) and
+// read back as MFMA fragments with conflict-free ds_read_b64:
 //
-//   layout KC ("k contiguous"):   element (r,k) at p[r*ld + k]   LDS image [128][18]
-//   layout RC ("row contiguous"): element (r,k) at p[k*ld + r]   LDS image [16][144]
+//   layout KC ("k contiguous"):   element (r,k) at p[r*ld + k]   LDS image [R][BK+2]
+//   layout RC ("row contiguous"): element (r,k) at p[k*ld + r]   LDS image [BK][R+16]
 //
-// where r is the m index for the A operand and the n index for the B operand, so
-// C[m][n] = sum_k A(m,k) * B(n,k) in both cases.  Both LDS images take 2304 doubles.
+// where r is the m index for the A operand (R = TM) and the n index for the B operand (R = TN), so
+// C[m][n] = sum_k A(m,k) * B(n,k) in both cases.
 //
 // v_mfma_f64_16x16x4_f64 fragment maps (cdna_hip_programming.md section 3):
 //   A: lane l holds A[l&15][l>>4]        B: lane l holds B[k=l>>4][n=l&15]
 //   D: lane l, reg r holds D[(l>>4)+4r][l&15]
 //
-// All matrices handled by this core are padded to multiples of 128 (rows) and 16 (K)
-// with 16-byte aligned bases and even leading dimensions, so there are no bounds
-// checks in the inner loop.
+// The 128x128 tile has the best arithmetic intensity (16 flop per LDS-staged byte); the 64x64 tile
+// quarters the work per workgroup and is used where a launch has too few or too unequal tiles to
+// fill 256 CUs (one CU delivers only ~0.3 TFLOP/s of fp64 MFMA, so balance beats tile efficiency).
+//
+// All matrices handled by this core are padded to multiples of 128 (rows) and 16 (K) with 16-byte
+// aligned bases and even leading dimensions, so there are no bounds checks in the inner loop.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,138 +30,168 @@ namespace bobe {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int TILE = 128;          // output tile edge
-constexpr int TK = 16;             // K-step
-constexpr int KC_STRIDE = 18;      // doubles per row of a KC LDS image (16 + 2 pad)
-constexpr int RC_STRIDE = 144;     // doubles per k-row of an RC LDS image (128 + 16 pad)
-constexpr int IMG = 2304;          // doubles per LDS operand image
+constexpr int TILE = 128;          // padding granule and default output tile edge
+constexpr int TK = 16;             // K granule (every K range is a multiple of 16)
 constexpr int GEMM_THREADS = 256;
-constexpr int GEMM_SMEM_DOUBLES = 4 * IMG;       // 2 operands x 2 buffers = 73,728 B
-constexpr int GEMM_SMEM_BYTES = GEMM_SMEM_DOUBLES * 8;
 
 enum Layout { KC = 0, RC = 1 };
 
-// ---- global -> register staging (4 x 16 B per thread per operand) --------------------
-template <int L>
-__device__ __forceinline__ void stage_load(v2d (&reg)[4], const double* __restrict__ p, int64_t ld,
+// LDS image of one operand tile: R rows x BK k.  KC rows are padded by 2 doubles (stride = 4 mod 64
+// dwords), RC k-rows by 16 doubles (stride = 32 mod 64 dwords): both make the fragment reads of a
+// 32-lane ds_read_b64 group hit 32 distinct bank pairs.
+template <int L, int R, int BK>
+struct Img {
+  static constexpr int stride = (L == KC) ? (BK + 2) : (R + 16);
+  static constexpr int doubles = (L == KC) ? R * (BK + 2) : BK * (R + 16);
+};
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+// LDS doubles needed by gemm_tile<.,.,TM,TN,BK> (worst case over layouts), two buffers
+template <int TM, int TN, int BK>
+constexpr int gemm_smem_doubles() {
+  return 2 * (imax(Img<KC, TM, BK>::doubles, Img<RC, TM, BK>::doubles) +
+              imax(Img<KC, TN, BK>::doubles, Img<RC, TN, BK>::doubles));
+}
+constexpr int BK128 = 16;   // 128x128 tiles: 73,728 B of LDS -> two workgroups per CU
+constexpr int BK64 = 32;    // 64x64 tiles: deeper K-steps hide the global-load latency (69,632 B -> two per CU)
+constexpr int GEMM_SMEM_DOUBLES = gemm_smem_doubles<128, 128, BK128>();
+constexpr int GEMM_SMEM_BYTES = GEMM_SMEM_DOUBLES * 8;
+constexpr int GEMM64_SMEM_BYTES = gemm_smem_doubles<64, 64, BK64>() * 8;
+template <int T> struct TileCfg { static constexpr int bk = (T == 128) ? BK128 : BK64; };
+
+// ---- global -> register staging (R*BK/512 x 16 B per thread per operand) -----------------------
+template <int L, int R, int BK>
+__device__ __forceinline__ void stage_load(v2d (&reg)[R * BK / 512], const double* __restrict__ p, int64_t ld,
                                            int64_t r0, int64_t k0, int t) {
   if (L == KC) {
-    const int kq = t & 7;
-    const int r = t >> 3;
+    constexpr int VPR = BK / 2;            // 16-byte vectors per row
+    const int kq = t % VPR;
+    const int r = t / VPR;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      reg[i] = *reinterpret_cast<const v2d*>(p + (r0 + r + 32 * i) * ld + k0 + 2 * kq);
+    for (int i = 0; i < R * BK / 512; ++i)
+      reg[i] = *reinterpret_cast<const v2d*>(p + (r0 + r + (256 / VPR) * i) * ld + k0 + 2 * kq);
   } else {
-    const int k = t >> 4;
-    const int c = t & 15;
+    constexpr int VPR = R / 2;             // 16-byte vectors per k-row
+    const int c = t % VPR;
+    const int k = t / VPR;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      reg[i] = *reinterpret_cast<const v2d*>(p + (k0 + k) * ld + r0 + 2 * (c + 16 * i));
+    for (int i = 0; i < R * BK / 512; ++i)
+      reg[i] = *reinterpret_cast<const v2d*>(p + (k0 + k + (256 / VPR) * i) * ld + r0 + 2 * c);
   }
 }
 
-template <int L>
-__device__ __forceinline__ void stage_store(const v2d (&reg)[4], double* img, int t) {
+template <int L, int R, int BK>
+__device__ __forceinline__ void stage_store(const v2d (&reg)[R * BK / 512], double* img, int t) {
   if (L == KC) {
-    const int kq = t & 7;
-    const int r = t >> 3;
+    constexpr int VPR = BK / 2;
+    const int kq = t % VPR;
+    const int r = t / VPR;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(img + (r + 32 * i) * KC_STRIDE + 2 * kq) = reg[i];
+    for (int i = 0; i < R * BK / 512; ++i)
+      *reinterpret_cast<v2d*>(img + (r + (256 / VPR) * i) * (BK + 2) + 2 * kq) = reg[i];
   } else {
-    const int k = t >> 4;
-    const int c = t & 15;
+    constexpr int VPR = R / 2;
+    const int c = t % VPR;
+    const int k = t / VPR;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(img + k * RC_STRIDE + 2 * (c + 16 * i)) = reg[i];
+    for (int i = 0; i < R * BK / 512; ++i)
+      *reinterpret_cast<v2d*>(img + (k + (256 / VPR) * i) * (R + 16) + 2 * c) = reg[i];
   }
 }
 
-// fragment read: sub-tile s (0..3) of the wave's 64 rows starting at w64, k-step ks (0..3)
-template <int L>
-__device__ __forceinline__ double frag_read(const double* img, int w64, int s, int ks, int lane) {
+// fragment read: 16-row sub-tile s of the wave's rows starting at woff, k-step ks (0..BK/4-1)
+template <int L, int R, int BK>
+__device__ __forceinline__ double frag_read(const double* img, int woff, int s, int ks, int lane) {
   if (L == KC)
-    return img[(w64 + 16 * s + (lane & 15)) * KC_STRIDE + 4 * ks + (lane >> 4)];
+    return img[(woff + 16 * s + (lane & 15)) * (BK + 2) + 4 * ks + (lane >> 4)];
   else
-    return img[(4 * ks + (lane >> 4)) * RC_STRIDE + w64 + 16 * s + (lane & 15)];
+    return img[(4 * ks + (lane >> 4)) * (R + 16) + woff + 16 * s + (lane & 15)];
 }
 
-__device__ __forceinline__ void acc_zero(v4d (&acc)[4][4]) {
+template <int FM, int FN>
+__device__ __forceinline__ void acc_zero(v4d (&acc)[FM][FN]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < FN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 }
 
-// acc += A(m0.., k) * B(n0.., k) for k in [kbeg, kend), kbeg/kend multiples of 16.
-// smem: GEMM_SMEM_DOUBLES doubles.  All 256 threads must call.
-template <int LA, int LB>
-__device__ __forceinline__ void gemm_tile(v4d (&acc)[4][4], const double* __restrict__ A, int64_t lda,
+// acc += A(m0.., k) * B(n0.., k) for k in [kbeg, kend); (kend - kbeg) must be a multiple of BK
+// (K ranges are multiples of 128 for the 128x128 callers and of 64 for the 64x64 callers).
+// smem: gemm_smem_doubles<TM,TN,BK>() doubles.  All 256 threads must call.
+template <int LA, int LB, int TM = 128, int TN = 128, int BK = BK128>
+__device__ __forceinline__ void gemm_tile(v4d (&acc)[TM / 32][TN / 32], const double* __restrict__ A, int64_t lda,
                                           int64_t m0, const double* __restrict__ B, int64_t ldb, int64_t n0,
                                           int64_t kbeg, int64_t kend, double* smem) {
+  constexpr int FM = TM / 32, FN = TN / 32;
+  constexpr int IA = imax(Img<KC, TM, BK>::doubles, Img<RC, TM, BK>::doubles);
+  constexpr int IB = imax(Img<KC, TN, BK>::doubles, Img<RC, TN, BK>::doubles);
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
-  const int wm = (wave >> 1) * 64;
-  const int wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (TM / 2);
+  const int wn = (wave & 1) * (TN / 2);
   if (kend <= kbeg) return;
-  v2d ra[4], rb[4];
-  stage_load<LA>(ra, A, lda, m0, kbeg, t);
-  stage_load<LB>(rb, B, ldb, n0, kbeg, t);
-  stage_store<LA>(ra, smem, t);
-  stage_store<LB>(rb, smem + IMG, t);
+  v2d ra[TM * BK / 512], rb[TN * BK / 512];
+  stage_load<LA, TM, BK>(ra, A, lda, m0, kbeg, t);
+  stage_load<LB, TN, BK>(rb, B, ldb, n0, kbeg, t);
+  stage_store<LA, TM, BK>(ra, smem, t);
+  stage_store<LB, TN, BK>(rb, smem + IA, t);
   __syncthreads();
   int buf = 0;
-  for (int64_t k0 = kbeg; k0 < kend; k0 += TK) {
-    const bool more = (k0 + TK) < kend;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = (k0 + BK) < kend;
     if (more) {
-      stage_load<LA>(ra, A, lda, m0, k0 + TK, t);
-      stage_load<LB>(rb, B, ldb, n0, k0 + TK, t);
+      stage_load<LA, TM, BK>(ra, A, lda, m0, k0 + BK, t);
+      stage_load<LB, TN, BK>(rb, B, ldb, n0, k0 + BK, t);
     }
-    const double* ia = smem + buf * 2 * IMG;
-    const double* ib = ia + IMG;
+    const double* ia = smem + buf * (IA + IB);
+    const double* ib = ia + IA;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      double a[4], b[4];
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      double a[FM], b[FN];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        a[s] = frag_read<LA>(ia, wm, s, ks, lane);
-        b[s] = frag_read<LB>(ib, wn, s, ks, lane);
-      }
+      for (int s = 0; s < FM; ++s) a[s] = frag_read<LA, TM, BK>(ia, wm, s, ks, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int s = 0; s < FN; ++s) b[s] = frag_read<LB, TN, BK>(ib, wn, s, ks, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      double* na = smem + (buf ^ 1) * 2 * IMG;
-      stage_store<LA>(ra, na, t);
-      stage_store<LB>(rb, na + IMG, t);
+      double* na = smem + (buf ^ 1) * (IA + IB);
+      stage_store<LA, TM, BK>(ra, na, t);
+      stage_store<LB, TN, BK>(rb, na + IA, t);
     }
     __syncthreads();
     buf ^= 1;
   }
 }
 
-// Coordinates of accumulator element (i, j, r) of this lane inside the 128x128 tile.
+// Coordinates of accumulator element (i, j, r) of this lane inside the TM x TN tile.
+template <int TM = 128>
 __device__ __forceinline__ int acc_row(int i, int r) {
   const int t = threadIdx.x;
-  return ((t >> 6) >> 1) * 64 + 16 * i + ((t & 63) >> 4) + 4 * r;
+  return ((t >> 6) >> 1) * (TM / 2) + 16 * i + ((t & 63) >> 4) + 4 * r;
 }
+template <int TN = 128>
 __device__ __forceinline__ int acc_col(int j) {
   const int t = threadIdx.x;
-  return ((t >> 6) & 1) * 64 + 16 * j + (t & 15);
+  return ((t >> 6) & 1) * (TN / 2) + 16 * j + (t & 15);
 }
 
 // C[m0+row][n0+col] = alpha*acc + beta*C   (row-major C, ldc)
-__device__ __forceinline__ void store_tile(const v4d (&acc)[4][4], double* __restrict__ C, int64_t ldc, int64_t m0,
-                                           int64_t n0, double alpha, double beta) {
+template <int TM = 128, int TN = 128>
+__device__ __forceinline__ void store_tile(const v4d (&acc)[TM / 32][TN / 32], double* __restrict__ C, int64_t ldc,
+                                           int64_t m0, int64_t n0, double alpha, double beta) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM / 32; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TN / 32; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        double* q = C + (m0 + acc_row(i, r)) * ldc + n0 + acc_col(j);
+        double* q = C + (m0 + acc_row<TM>(i, r)) * ldc + n0 + acc_col<TN>(j);
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v += beta * (*q);
         *q = v;

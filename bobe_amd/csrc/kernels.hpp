@@ -115,319 +115,9 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
   }
 }
 
-// ---- diagonal block: Cholesky of a 128x128 block + its triangular inverse ------------------
-constexpr int PLD = 130;                        // LDS leading dimension (doubles)
-constexpr int POTF2_SMEM_BYTES = TILE * PLD * 8;  // 133,120 B
-
-template <bool FACTOR>
-__global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                                   int64_t ldl, int blk, int* __restrict__ info) {
-  extern __shared__ double S[];
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = t >> 6;
-  double* Ab = A + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
-  {
-    const int c = t & 127;
-    for (int r = t >> 7; r < TILE; r += 2) S[r * PLD + c] = Ab[(int64_t)r * lda + c];
-  }
-  __syncthreads();
-
-  for (int p = 0; FACTOR && p < 8; ++p) {
-    const int o = 16 * p;
-    // (a) 16x16 diagonal sub-block, one row per lane (lanes >= 16 mirror lanes 0..15)
-    if (wave == 0) {
-      const int li = lane & 15;
-      double r[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = S[(o + li) * PLD + o + c];
-      bool bad = false;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double ajj = readlane_f64(r[j], j);
-        if (!(ajj > 0.0)) bad = true;
-        const double dj = sqrt(ajj);
-        const double inv = 1.0 / dj;
-        r[j] = (li == j) ? dj : r[j] * inv;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-          const double lcj = readlane_f64(r[j], c);
-          r[c] -= r[j] * lcj;
-        }
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) S[(o + li) * PLD + o + c] = (c <= li) ? r[c] : 0.0;
-      }
-      if (bad && lane == 0) atomicMin(info, blk * TILE + o + 1);
-    }
-    __syncthreads();
-    // (b) rows below: x * Lpp^T = a  (forward substitution, one row per thread)
-    {
-      const int nrows = TILE - o - 16;
-      if (t < nrows) {
-        const int row = o + 16 + t;
-        double x[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = S[row * PLD + o + c];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double s = x[c];
-#pragma unroll
-          for (int k = 0; k < c; ++k) s -= x[k] * S[(o + c) * PLD + o + k];
-          x[c] = s / S[(o + c) * PLD + o + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) S[row * PLD + o + c] = x[c];
-      }
-    }
-    __syncthreads();
-    // (c) trailing update inside the block: A[ti][tj] -= L[ti][p] L[tj][p]^T  (16x16 MFMA tiles)
-    {
-      const int nt = 7 - p;
-      const int ntiles = nt * (nt + 1) / 2;
-      for (int q = wave; q < ntiles; q += 4) {
-        int a, b;
-        tri_decode(q, a, b);
-        const int ti = p + 1 + a, tj = p + 1 + b;
-        v4d acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = S[(16 * ti + (lane >> 4) + 4 * r) * PLD + 16 * tj + (lane & 15)];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const double av = -S[(16 * ti + (lane & 15)) * PLD + o + 4 * ks + (lane >> 4)];
-          const double bv = S[(16 * tj + (lane & 15)) * PLD + o + 4 * ks + (lane >> 4)];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(16 * ti + (lane >> 4) + 4 * r) * PLD + 16 * tj + (lane & 15)] = acc[r];
-      }
-    }
-    __syncthreads();
-  }
-  // write L (lower, zeros above the diagonal)
-  if (FACTOR) {
-    const int c = t & 127;
-    for (int r = t >> 7; r < TILE; r += 2) Ab[(int64_t)r * lda + c] = (c <= r) ? S[r * PLD + c] : 0.0;
-  }
-  __syncthreads();
-  // ---- in-place inverse ----
-  // I1: the eight 16x16 diagonal blocks, one column per thread
-  {
-    double x[16];
-    const int bb = t >> 4, col = t & 15, o = 16 * bb;
-    if (t < 128) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double s = (r == col) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) s -= S[(o + r) * PLD + o + k] * x[k];
-        x[r] = s / S[(o + r) * PLD + o + r];
-      }
-    }
-    __syncthreads();
-    if (t < 128) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S[(o + r) * PLD + o + col] = x[r];
-    }
-    __syncthreads();
-  }
-  // I2: block rows 1..7:  inv[i][j] = -inv[i][i] * sum_{k=j}^{i-1} L[i][k] inv[k][j]
-  for (int i = 1; i < 8; ++i) {
-    v4d res0 = (v4d){0.0, 0.0, 0.0, 0.0}, res1 = res0;
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const int j = wave + 4 * slot;
-      if (j < i) {
-        v4d tacc = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int k = j; k < i; ++k) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const double av = S[(16 * i + (lane & 15)) * PLD + 16 * k + 4 * ks + (lane >> 4)];
-            const double bv = S[(16 * k + 4 * ks + (lane >> 4)) * PLD + 16 * j + (lane & 15)];
-            tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, tacc, 0, 0, 0);
-          }
-        }
-        // R = -inv[i][i] * T ; T's accumulator register r holds row (lane>>4)+4r, used as the k index
-        v4d racc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double av = -S[(16 * i + (lane & 15)) * PLD + 16 * i + (lane >> 4) + 4 * r];
-          racc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tacc[r], racc, 0, 0, 0);
-        }
-        if (slot == 0) res0 = racc; else res1 = racc;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const int j = wave + 4 * slot;
-      if (j < i) {
-        const v4d racc = slot == 0 ? res0 : res1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(16 * i + (lane >> 4) + 4 * r) * PLD + 16 * j + (lane & 15)] = racc[r];
-      }
-    }
-    __syncthreads();
-  }
-  {
-    double* Lb = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
-    const int c = t & 127;
-    for (int r = t >> 7; r < TILE; r += 2) Lb[(int64_t)r * ldl + c] = (c <= r) ? S[r * PLD + c] : 0.0;
-  }
-}
-
-// ---- blocked Cholesky pieces ---------------------------------------------------------------
-// panel: A[i][k] <- A[i][k] * invL_kk^T for block rows i = k+1 .. nb-1   (grid = nb-k-1)
-__global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ A, int64_t lda, const double* __restrict__ Linv,
-                                                    int64_t ldl, int k) {
-  extern __shared__ double smem[];
-  const int i = k + 1 + blockIdx.x;
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_tile<KC, KC>(acc, A, lda, (int64_t)i * TILE, Linv, ldl, (int64_t)k * TILE, (int64_t)k * TILE,
-                    (int64_t)(k + 1) * TILE, smem);
-  store_tile(acc, A, lda, (int64_t)i * TILE, (int64_t)k * TILE, 1.0, 0.0);
-}
-
-// trailing update: A[i][j] -= L[i][k] L[j][k]^T for k < j <= i < nb  (grid = n(n+1)/2, n = nb-k-1)
-__global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k) {
-  extern __shared__ double smem[];
-  int a, b;
-  tri_decode(blockIdx.x, a, b);
-  const int i = k + 1 + a, j = k + 1 + b;
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_tile<KC, KC>(acc, A, lda, (int64_t)i * TILE, A, lda, (int64_t)j * TILE, (int64_t)k * TILE,
-                    (int64_t)(k + 1) * TILE, smem);
-  store_tile(acc, A, lda, (int64_t)i * TILE, (int64_t)j * TILE, -1.0, 1.0);
-}
-
-// ---- recursive triangular inverse ------------------------------------------------------------
-// problem {lo, mid, hi} in tile units: with inv[lo:mid) and inv[mid:hi) known,
-//   T = L[mid:hi, lo:mid) * inv[lo:mid)            (k_trtri_T, written to Tmp)
-//   inv[mid:hi, lo:mid) = -inv[mid:hi) * T          (k_trtri_R)
-struct TriProb { int lo, mid, hi, off; };   // off = first block index of this problem
-
-__device__ __forceinline__ bool tri_find(const TriProb* __restrict__ probs, int nprob, int bid, TriProb& p) {
-  for (int q = 0; q < nprob; ++q) {
-    const TriProb c = probs[q];
-    const int nt = (c.hi - c.mid) * (c.mid - c.lo);
-    if (bid >= c.off && bid < c.off + nt) { p = c; return true; }
-  }
-  return false;
-}
-
-__global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L, int64_t ldl, const double* __restrict__ Linv,
-                                                 int64_t ldi, double* __restrict__ Tmp, int64_t ldt,
-                                                 const TriProb* __restrict__ probs, int nprob) {
-  extern __shared__ double smem[];
-  TriProb p;
-  if (!tri_find(probs, nprob, blockIdx.x, p)) return;
-  const int q = blockIdx.x - p.off;
-  const int w = p.mid - p.lo;
-  const int i = p.mid + q / w, j = p.lo + q % w;
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_tile<KC, RC>(acc, L, ldl, (int64_t)i * TILE, Linv, ldi, (int64_t)j * TILE, (int64_t)j * TILE,
-                    (int64_t)p.mid * TILE, smem);
-  store_tile(acc, Tmp, ldt, (int64_t)i * TILE, (int64_t)j * TILE, 1.0, 0.0);
-}
-
-__global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, int64_t ldi, const double* __restrict__ Tmp,
-                                                 int64_t ldt, const TriProb* __restrict__ probs, int nprob) {
-  extern __shared__ double smem[];
-  TriProb p;
-  if (!tri_find(probs, nprob, blockIdx.x, p)) return;
-  const int q = blockIdx.x - p.off;
-  const int w = p.mid - p.lo;
-  const int i = p.mid + q / w, j = p.lo + q % w;
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_tile<KC, RC>(acc, Linv, ldi, (int64_t)i * TILE, Tmp, ldt, (int64_t)j * TILE, (int64_t)p.mid * TILE,
-                    (int64_t)(i + 1) * TILE, smem);
-  store_tile(acc, Linv, ldi, (int64_t)i * TILE, (int64_t)j * TILE, -1.0, 0.0);
-}
-
-// ---- K^-1 = Linv^T Linv fused with the MLL gradient reduction ---------------------------------
-// tile (ti >= tj): Kinv = sum_{k >= ti} Linv[k][ti]^T Linv[k][tj];  W = alpha alpha^T - Kinv.
-// partial[(blockIdx.x)*(DCAP+1) + j] = sum_ab W_ab dK_ab/dlog ls_j (j < d), [DCAP] = sum_ab W_ab Kt_ab,
-// off-diagonal tiles weighted x2.  Optionally stores Kinv (lower tiles) for tests.
-template <int KERN, int DCAP>
-__global__ __launch_bounds__(256, 2) void k_lauum_grad(const double* __restrict__ Linv, int64_t ldi, int nb, int64_t n,
-                                                    const double* __restrict__ alpha, const double* __restrict__ XsT,
-                                                    int64_t ldx, Hyper h, double* __restrict__ partial,
-                                                    double* __restrict__ Kinv, int64_t ldk) {
-  extern __shared__ double smem[];
-  int ti, tj;
-  tri_decode(blockIdx.x, ti, tj);
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_tile<RC, RC>(acc, Linv, ldi, (int64_t)ti * TILE, Linv, ldi, (int64_t)tj * TILE, (int64_t)ti * TILE,
-                    (int64_t)nb * TILE, smem);
-  if (Kinv) store_tile(acc, Kinv, ldk, (int64_t)ti * TILE, (int64_t)tj * TILE, 1.0, 0.0);
-  // stage coordinates and alpha in the (now free) GEMM LDS
-  double* xa = smem;                   // [d][128]
-  double* xb = smem + MAX_D * TILE;    // [d][128]
-  double* aa = smem + 2 * MAX_D * TILE;  // [128]
-  double* ab = aa + TILE;              // [128]
-  double* red = ab + TILE;             // [4][DCAP+1]
-  const int t = threadIdx.x;
-  for (int e = t; e < h.d * TILE; e += 256) {
-    const int j = e >> 7, c = e & 127;
-    xa[j * TILE + c] = XsT[j * ldx + (int64_t)ti * TILE + c];
-    xb[j * TILE + c] = XsT[j * ldx + (int64_t)tj * TILE + c];
-  }
-  if (t < TILE) {
-    aa[t] = alpha[(int64_t)ti * TILE + t];
-    ab[t] = alpha[(int64_t)tj * TILE + t];
-  }
-  __syncthreads();
-  double g[DCAP + 1];
-#pragma unroll
-  for (int j = 0; j <= DCAP; ++j) g[j] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int a = acc_row(i, r), b = acc_col(jj);
-        const int64_t ga = (int64_t)ti * TILE + a, gb = (int64_t)tj * TILE + b;
-        if (ga < n && gb < n) {
-          const double w = aa[a] * ab[b] - acc[i][jj][r];
-          double dsq[DCAP];
-          double r2 = 0.0;
-#pragma unroll
-          for (int j = 0; j < DCAP; ++j) {
-            if (j < h.d) {
-              const double df = xa[j * TILE + a] - xb[j * TILE + b];
-              dsq[j] = df * df;
-              r2 += dsq[j];
-            } else {
-              dsq[j] = 0.0;
-            }
-          }
-          const double kv = kern_eval<KERN>(r2, h.kvar);
-          const double wf = w * kern_grad_factor<KERN>(r2, h.kvar, kv);
-#pragma unroll
-          for (int j = 0; j < DCAP; ++j) g[j] += wf * dsq[j];
-          g[DCAP] += w * kv;
-        }
-      }
-  const double wt = (ti == tj) ? 1.0 : 2.0;
-  const int lane = t & 63, wave = t >> 6;
-#pragma unroll
-  for (int j = 0; j <= DCAP; ++j) {
-    const double s = wave_sum(g[j]);
-    if (lane == 0) red[wave * (DCAP + 1) + j] = s;
-  }
-  __syncthreads();
-  if (t <= DCAP) {
-    const double s = ((red[t] + red[(DCAP + 1) + t]) + red[2 * (DCAP + 1) + t]) + red[3 * (DCAP + 1) + t];
-    partial[(int64_t)blockIdx.x * (DCAP + 1) + t] = wt * s;
-  }
-}
+}  // namespace bobe
+#include "chol_kernels.hpp"
+namespace bobe {
 
 // ---- the sweep's one big GEMM launch ------------------------------------------------------------
 // grid.x = column (candidate) tile; grid.y enumerates row tiles, heaviest first:
