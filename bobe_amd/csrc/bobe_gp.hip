@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256, 2) void k_debug_gemm(const double* __restrict_
   store_tile(acc, C, ldc, (int64_t)blockIdx.y * TILE, (int64_t)blockIdx.x * TILE, 1.0, 0.0);
 }
 
+constexpr int SYRK64_BK = 64, SYRK128_BK = 32;
+constexpr int SYRK64_SMEM = gemm_smem_doubles<64, 64, SYRK64_BK>() * 8;      // 135,168 B
+constexpr int SYRK128_SMEM = gemm_smem_doubles<128, 128, SYRK128_BK>() * 8;  // 147,456 B
+
 void configure_kernels_once() {
   static bool done[64] = {false};
   int dev = 0;
@@ -95,10 +99,10 @@ void configure_kernels_once() {
   allow_big_lds(k_potf2<false, false>, POTF2_SMEM_BYTES);
   allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
   allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
-  allow_big_lds(k_syrk_trail<128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_syrk_trail<128, SYRK128_BK>, SYRK128_SMEM);
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
-  allow_big_lds(k_syrk_trail<64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_syrk_trail<64, SYRK64_BK>, SYRK64_SMEM);
   allow_big_lds(k_trtri_T<64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_trtri_R<64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 8, 64>, GEMM64_SMEM_BYTES);
@@ -130,14 +134,16 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk64_below, trtri64_below, lauum64_below, lookahead, reserve_cus; };
+struct Tuning { int syrk64_below, trtri64_below, lauum64_below, lookahead, reserve_cus; double syrk_t128_us, syrk_t64_us; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{600, 600, 1200, 0, 32};   // lookahead off: cross-stream event cost exceeds the overlap gain
+    Tuning v{600, 600, 1200, 0, 32, 25.0, 6.5};   // lookahead off: cross-stream event cost exceeds the overlap gain
     if (const char* e = std::getenv("BOBE_SYRK64")) v.syrk64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LOOKAHEAD")) v.lookahead = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_SYRK_T128")) v.syrk_t128_us = std::atof(e);
+    if (const char* e = std::getenv("BOBE_SYRK_T64")) v.syrk_t64_us = std::atof(e);
     if (const char* e = std::getenv("BOBE_RESERVE_CUS")) v.reserve_cus = std::atoi(e);
     return v;
   }();
@@ -315,18 +321,22 @@ void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a) {
   LAUNCH_CHECK();
 }
 
+// The trailing update has K = 128 only, so its tiles are latency-bound unless several K-steps are in
+// flight: 64x64 tiles use BK = 64 (both halves of the panel loaded up front), 128x128 tiles BK = 32.
+// Both variants take one workgroup per CU; the cheaper one by a simple rounds x tile-time estimate wins.
 void bobe_gp::syrk(double* a, int k, int first, int colmode, hipStream_t st) {
   const Tuning& tu = tuning();
   const int rem = nb - first;                 // 128-blocks in the trailing matrix
   if (rem <= 0) return;
-  const bool small = rem * (rem + 1) / 2 < tu.syrk64_below;
-  if (small) {
-    const int n = 2 * rem;
-    const int grid = colmode ? 2 * n - 1 : n * (n + 1) / 2;
-    hipLaunchKernelGGL(k_syrk_trail<64>, dim3(grid), dim3(256), GEMM64_SMEM_BYTES, st, a, Np, k, first, colmode, n);
+  const int t128 = colmode ? rem : rem * (rem + 1) / 2;
+  const int n64 = 2 * rem;
+  const int t64 = colmode ? 2 * n64 - 1 : n64 * (n64 + 1) / 2;
+  const double est128 = std::ceil(t128 / 256.0) * tu.syrk_t128_us, est64 = std::ceil(t64 / 256.0) * tu.syrk_t64_us;
+  if (est64 <= est128) {
+    hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(t64), dim3(256), SYRK64_SMEM, st, a, Np, k, first, colmode, n64);
   } else {
-    const int grid = colmode ? rem : rem * (rem + 1) / 2;
-    hipLaunchKernelGGL(k_syrk_trail<128>, dim3(grid), dim3(256), GEMM_SMEM_BYTES, st, a, Np, k, first, colmode, rem);
+    hipLaunchKernelGGL((k_syrk_trail<128, SYRK128_BK>), dim3(t128), dim3(256), SYRK128_SMEM, st, a, Np, k, first, colmode,
+                       rem);
   }
 }
 

@@ -348,9 +348,9 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
 // colmode 1: only the tiles of 128-block column `first` (the next panel; grid = (128/T)*n - (T==64 ? 1 : 0)).
 // The lookahead Cholesky issues colmode 1 for block k+1 on the panel stream and colmode 0 from block k+2
 // on the update stream.
-template <int T>
-__global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k, int first,
-                                                       int colmode, int n) {
+template <int T, int BK>
+__global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k, int first,
+                                                    int colmode, int n) {
   extern __shared__ double smem[];
   int a, b;
   if (colmode == 0) {
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, i
   const int64_t base = (int64_t)first * TILE;
   v4d acc[T / 32][T / 32];
   acc_zero(acc);
-  gemm_tile<KC, KC, T, T, TileCfg<T>::bk>(acc, A, lda, base + (int64_t)a * T, A, lda, base + (int64_t)b * T,
-                                          (int64_t)k * TILE, (int64_t)(k + 1) * TILE, smem);
+  gemm_tile<KC, KC, T, T, BK>(acc, A, lda, base + (int64_t)a * T, A, lda, base + (int64_t)b * T, (int64_t)k * TILE,
+                              (int64_t)(k + 1) * TILE, smem);
   store_tile<T, T>(acc, A, lda, base + (int64_t)a * T, base + (int64_t)b * T, -1.0, 1.0);
 }
 
