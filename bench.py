@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-class", default="trimul", help="kernel class timed with HIP events for the roofline")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk of the sweep (0 = library default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo only to rehearse the N>1 path on a single GPU")
     return ap.parse_args()
 
 
@@ -85,13 +87,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback)")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()      # rehearsal: several ranks may share one GPU
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = dev if args.backend == "nccl" else None   # where the all-gather payload lives
+    from bobe_amd.dist_sweep import merge_argmin, merge_best_fit
 
     N, d, Cn, M = CONFIGS[args.config]
     noise = 1e-6
@@ -129,16 +138,11 @@ def main():
         _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
                                          _lib.ptr(out_wipstd), _lib.ptr(out_mean), _lib.ptr(out_var),
                                          C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
-        gidx, gmin = rank * Cn + asd.value, ms.value
-        if world > 1:   # the path's one exchange step: all-gather of (min score, global index, best mll)
-            mine = torch.tensor([ms.value, float(rank * Cn + asd.value), best[0]], dtype=torch.float64, device=dev)
-            allv = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allv, mine)
-            allv = torch.stack(allv).cpu().numpy()
-            # argmin with lowest-global-index tie-break (jnp.argmin first-occurrence semantics)
-            order = np.lexsort((allv[:, 1], allv[:, 0]))
-            gmin, gidx = float(allv[order[0], 0]), int(allv[order[0], 1])
-        last.update(mll=mll.value, argmin=int(gidx), min_wipstd=float(gmin))
+        # the path's exchange step: one all-gather of (min score, global index) — lowest global index wins
+        # ties (jnp.argmin) — and one of (best mll, theta) for the restart-sharded fit (pool.py:322-326)
+        gmin, gidx = merge_argmin(ms.value, rank * Cn + asd.value, device=coll_dev)
+        bmll, bth = merge_best_fit(best[0], best[1], device=coll_dev)
+        last.update(mll=mll.value, best_mll=float(bmll), argmin=int(gidx), min_wipstd=float(gmin))
 
     def barrier():
         if world > 1:
@@ -160,7 +164,7 @@ def main():
     lib.bobe_gp_profile_read(h, C.byref(tot_ms), C.byref(launches))
     lib.bobe_gp_profile_select(h, 0)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -174,13 +178,19 @@ def main():
         # the cross-covariance rows W_Z^T K(X,C) (2 N M per candidate)
         flops_per_launch = {"trimul": (float(N) * N + 2.0 * N * M) * min(chunk, Cn),
                             "syrk": None, "lauum": 2.0 * N ** 3 / 3.0}.get(args.profile_class)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_k_%s.json" % args.profile_class)
+        if os.path.exists(tf):      # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
+            tj = json.load(open(tf))
+            if (tj.get("N"), tj.get("C"), tj.get("chunk")) == (N, Cn, chunk):
+                traffic = tj["hbm_bytes_per_launch"]
         roof = None
         if flops_per_launch and launches.value:
             avg_s = tot_ms.value * 1e-3 / launches.value
             ach = flops_per_launch / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": "k_" + args.profile_class, "achieved": ach,
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                    "traffic": None, "avg_launch_ms": avg_s * 1e3, "launches": int(launches.value),
+                    "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(launches.value),
                     "flops_per_launch": flops_per_launch}
         out = {
             "metric": "GP fit+acquisition cycles/sec at N=4096 d=8, 65536 cands; Cholesky GF/s",
