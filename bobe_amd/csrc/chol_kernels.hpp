@@ -16,12 +16,19 @@ namespace bobe {
 
 constexpr int PLD = 130;                          // LDS leading dimension of a 128x128 block (doubles)
 
-// coalesced 128x128 block <-> LDS (16-byte accesses, one row per wave per step)
+// coalesced 128x128 block <-> LDS (16-byte accesses, one row per wave per step).  LOWER: only the lower
+// triangle is needed; lanes right of the diagonal re-read the diagonal's 16-byte granule (same cache line,
+// no branch), which halves the distinct lines fetched.  The strictly upper part of S is then unspecified.
+template <bool LOWER = false>
 __device__ __forceinline__ void block_load(double* S, const double* __restrict__ G, int64_t ld) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   v2d v[32];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) v[i] = *reinterpret_cast<const v2d*>(G + (int64_t)(4 * i + wave) * ld + 2 * lane);
+  for (int i = 0; i < 32; ++i) {
+    const int r = 4 * i + wave;
+    const int c = LOWER ? ((2 * lane <= r) ? 2 * lane : (r & ~1)) : 2 * lane;
+    v[i] = *reinterpret_cast<const v2d*>(G + (int64_t)r * ld + c);
+  }
 #pragma unroll
   for (int i = 0; i < 32; ++i) *reinterpret_cast<v2d*>(S + (4 * i + wave) * PLD + 2 * lane) = v[i];
 }
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t l
   double* Ab = A + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
   double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
   BOBE_STAMP(0);
-  block_load(S, Ab, lda);
+  block_load<true>(S, Ab, lda);
   __syncthreads();
   BOBE_STAMP(1);
 
@@ -298,22 +305,42 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
   const double* Lkk = A + col0 * lda + col0;
   const double* Dk = Dinv + col0 * ldl + col0;
   const int g = lane >> 4, li = lane & 15;
-  // this wave's 16 rows -> registers (issued first so the loads overlap the LDS staging)
-  double* Ar = A + (row0 + li) * lda + col0;
+  double* Aw = A + row0 * lda + col0;          // this wave's 16 rows x 128 columns
+  double* Sw = S + (wave * 16) * PLD;          // and its private 16-row slab of the LDS block
+  // global -> registers, everything in flight at once: the wave's rows (full 1-KiB rows, 16 B per lane),
+  // L_kk (one row per wave per step) and this thread's share of the eight diagonal inverses
+  v2d xr[16], lr[32];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xr[i] = *reinterpret_cast<const v2d*>(Aw + (int64_t)i * lda + 2 * lane);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {   // lower triangle only (lanes right of the diagonal re-read its granule)
+    const int r = 4 * i + wave;
+    const int c = (2 * lane <= r) ? 2 * lane : (r & ~1);
+    lr[i] = *reinterpret_cast<const v2d*>(Lkk + (int64_t)r * lda + c);
+  }
+  double dr[8];
+  {
+    const int bb = t >> 5, rr = (t >> 1) & 15, hh = t & 1;
+    const double* src = Dk + (int64_t)(16 * bb + rr) * ldl + 16 * bb + 8 * hh;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dr[c] = src[c];
+  }
+  // rows -> LDS slab -> transposed MFMA accumulators X^T_p (lane (li,g), reg r = X[row li][16p + g + 4r])
+#pragma unroll
+  for (int i = 0; i < 16; ++i) *reinterpret_cast<v2d*>(Sw + i * PLD + 2 * lane) = xr[i];
   v4d X[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[p][r] = Ar[16 * p + g + 4 * r];
-  // stage L_kk (one row per wave per step, 16-byte accesses; unpredicated so all loads are in flight together)
-  block_load(S, Lkk, lda);
-  // and the eight diagonal inverses: thread t -> block t>>5, row (t>>1)&15, half t&1 (8 doubles)
+    for (int r = 0; r < 4; ++r) X[p][r] = Sw[li * PLD + 16 * p + g + 4 * r];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; ++i) *reinterpret_cast<v2d*>(S + (4 * i + wave) * PLD + 2 * lane) = lr[i];
   {
     const int bb = t >> 5, rr = (t >> 1) & 15, hh = t & 1;
-    const double* src = Dk + (int64_t)(16 * bb + rr) * ldl + 16 * bb + 8 * hh;
     double* dst = D + (bb * 16 + rr) * TRSM_DLD + 8 * hh;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) dst[c] = src[c];
+    for (int c = 0; c < 8; ++c) dst[c] = dr[c];
   }
   __syncthreads();
   BOBE_STAMP(1);
@@ -335,11 +362,15 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
     }
     X[p] = y;
   }
+  __syncthreads();   // every wave is done with L_kk: the block is reused to transpose the results back
   BOBE_STAMP(2);
 #pragma unroll
   for (int p = 0; p < 8; ++p)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ar[16 * p + g + 4 * r] = X[p][r];
+    for (int r = 0; r < 4; ++r) Sw[li * PLD + 16 * p + g + 4 * r] = X[p][r];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    *reinterpret_cast<v2d*>(Aw + (int64_t)i * lda + 2 * lane) = *reinterpret_cast<const v2d*>(Sw + i * PLD + 2 * lane);
   BOBE_STAMP(3);
 }
 
@@ -364,10 +395,10 @@ __global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int6
   }
   const int64_t base = (int64_t)first * TILE;
   v4d acc[T / 32][T / 32];
-  acc_zero(acc);
-  gemm_tile<KC, KC, T, T, BK>(acc, A, lda, base + (int64_t)a * T, A, lda, base + (int64_t)b * T, (int64_t)k * TILE,
-                              (int64_t)(k + 1) * TILE, smem);
-  store_tile<T, T>(acc, A, lda, base + (int64_t)a * T, base + (int64_t)b * T, -1.0, 1.0);
+  load_tile<T, T>(acc, A, lda, base + (int64_t)a * T, base + (int64_t)b * T);   // acc = C, then acc -= A B^T
+  gemm_tile<KC, KC, T, T, BK, true>(acc, A, lda, base + (int64_t)a * T, A, lda, base + (int64_t)b * T,
+                                    (int64_t)k * TILE, (int64_t)(k + 1) * TILE, smem);
+  store_tile<T, T>(acc, A, lda, base + (int64_t)a * T, base + (int64_t)b * T, 1.0, 0.0);
 }
 
 // ---- recursive triangular inverse ------------------------------------------------------------------

@@ -118,7 +118,8 @@ __device__ __forceinline__ void acc_zero(v4d (&acc)[FM][FN]) {
 // acc += A(m0.., k) * B(n0.., k) for k in [kbeg, kend); (kend - kbeg) must be a multiple of BK
 // (K ranges are multiples of 128 for the 128x128 callers and of 64 for the 64x64 callers).
 // smem: gemm_smem_doubles<TM,TN,BK>() doubles.  All 256 threads must call.
-template <int LA, int LB, int TM = 128, int TN = 128, int BK = BK128>
+// NEGA: accumulate -A*B (the A fragment is negated on the way into the MFMA).
+template <int LA, int LB, int TM = 128, int TN = 128, int BK = BK128, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile(v4d (&acc)[TM / 32][TN / 32], const double* __restrict__ A, int64_t lda,
                                           int64_t m0, const double* __restrict__ B, int64_t ldb, int64_t n0,
                                           int64_t kbeg, int64_t kend, double* smem) {
@@ -150,7 +151,10 @@ __device__ __forceinline__ void gemm_tile(v4d (&acc)[TM / 32][TN / 32], const do
     for (int ks = 0; ks < BK / 4; ++ks) {
       double a[FM], b[FN];
 #pragma unroll
-      for (int s = 0; s < FM; ++s) a[s] = frag_read<LA, TM, BK>(ia, wm, s, ks, lane);
+      for (int s = 0; s < FM; ++s) {
+        a[s] = frag_read<LA, TM, BK>(ia, wm, s, ks, lane);
+        if (NEGA) a[s] = -a[s];
+      }
 #pragma unroll
       for (int s = 0; s < FN; ++s) b[s] = frag_read<LB, TN, BK>(ib, wn, s, ks, lane);
 #pragma unroll
@@ -196,6 +200,18 @@ __device__ __forceinline__ void store_tile(const v4d (&acc)[TM / 32][TN / 32], d
         if (beta != 0.0) v += beta * (*q);
         *q = v;
       }
+}
+
+// acc = C[m0+row][n0+col]  (issued early so the loads overlap the operand staging)
+template <int TM = 128, int TN = 128>
+__device__ __forceinline__ void load_tile(v4d (&acc)[TM / 32][TN / 32], const double* __restrict__ C, int64_t ldc,
+                                          int64_t m0, int64_t n0) {
+#pragma unroll
+  for (int i = 0; i < TM / 32; ++i)
+#pragma unroll
+    for (int j = 0; j < TN / 32; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = C[(m0 + acc_row<TM>(i, r)) * ldc + n0 + acc_col<TN>(j)];
 }
 
 // map a linear index to a lower-triangular tile (i >= j), row-major enumeration: t = i(i+1)/2 + j
