@@ -1,0 +1,139 @@
+"""BO-loop counterpart (SURVEY.md 8f "next" row 1) — a compact driver around the GPU GP.
+
+Mirrors the parts of ``BOBE/bo.py`` that *call* the hot path: Sobol initialisation in the unit cube
+(bo.py:505-537, utils/core.py:181-193), the initial multi-restart fit (bo.py:611 -> pool.py:268-293), the
+WIPV / WIPStd / EI iteration (bo.py:1174-1224, 1226-1390: mc points -> get_next_batch -> evaluate ->
+update_gp) and the refit policy of ``update_gp`` (bo.py:620-668, strict ``<`` size classes included).
+
+Not reproduced (out of the GPU hot path): MPI pool, classifier GP, nested-sampling /
+NUTS samplers and therefore the logZ convergence test; the loop stops on ``max_evals``, ``max_gp_size`` or an
+acquisition-value threshold.  Integration points come from the reference's ``'uniform'`` method (scrambled
+Sobol, acquisition.py:476-479).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+from scipy.stats import qmc
+
+from .acquisition import EI, LogEI, WIPStd, WIPV, get_mc_samples
+from .gp import GP
+from .utils import get_logger, scale_from_unit, scale_to_unit
+
+log = get_logger("bo")
+
+_ACQ = {"wipv": WIPV, "wipstd": WIPStd, "ei": EI, "logei": LogEI}
+
+
+def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.random.Generator] = None) -> dict:
+    """Serial branch of ``MPI_Pool.gp_fit`` (pool.py:268-293): x0 row 0 = log(current hp), further rows uniform
+    in the log-bounds; fit; adopt the best hyper-parameters (refactors on the GPU)."""
+    rng = np.random.default_rng() if rng is None else rng
+    n_params = gp.hyperparam_bounds.shape[1]
+    init = np.log(gp.get_hyperparams())
+    if n_restarts > 1:
+        x0 = np.vstack([init, rng.uniform(gp.hyperparam_bounds[0], gp.hyperparam_bounds[1],
+                                          size=(n_restarts - 1, n_params))])
+    else:
+        x0 = np.atleast_2d(init)
+    res = gp.fit(x0=x0, maxiter=maxiters)
+    gp.update_hyperparams(res["params"])
+    return res
+
+
+class BOBE:
+    """``BOBE(loglikelihood, param_list, param_bounds, ...).run(acq=...)`` with the GP on a MI355X."""
+
+    def __init__(self, loglikelihood: Callable[[np.ndarray], float], param_list: Sequence[str],
+                 param_bounds: np.ndarray, n_sobol_init: int = 32, seed: Optional[int] = None,
+                 gp_kwargs: Optional[dict] = None, minus_inf: float = -1e5, device: int = 0):
+        self.loglikelihood = loglikelihood
+        self.param_list = list(param_list)
+        self.param_bounds = np.asarray(param_bounds, dtype=np.float64)      # (2, ndim), like the reference
+        self.ndim = len(self.param_list)
+        self.np_rng = np.random.default_rng(seed)
+        self.minus_inf = float(minus_inf)
+        self.device = device
+        self.timing: Dict[str, float] = {"GP Training": 0.0, "Acquisition Optimization": 0.0,
+                                         "True Objective Evaluations": 0.0}
+        self.n_points_since_last_fit = 0
+        # Sobol initial design (bo.py:521-529)
+        n_sobol = max(2, n_sobol_init)
+        sobol = qmc.Sobol(d=self.ndim, scramble=True, seed=self.np_rng).random(n_sobol)
+        pts = scale_from_unit(sobol, self.param_bounds)
+        vals = self._evaluate(pts)
+        kw = dict(noise=1e-8, kernel="rbf", lengthscale_bounds=[0.01, 10], kernel_variance_bounds=[1e-4, 1e8])
+        kw.update(gp_kwargs or {})
+        t0 = time.time()
+        self.gp = GP(scale_to_unit(pts, self.param_bounds), vals, param_names=self.param_list, device=device, **kw)
+        gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng)        # bo.py:611
+        self.timing["GP Training"] += time.time() - t0
+
+    def _evaluate(self, pts: np.ndarray) -> np.ndarray:
+        """Safe likelihood wrapper (likelihood.py:69-91): NaN / exceptions / -inf -> minus_inf."""
+        t0 = time.time()
+        out = np.empty((pts.shape[0], 1))
+        for i, p in enumerate(pts):
+            try:
+                v = float(self.loglikelihood(np.array(p)))
+            except Exception:
+                v = self.minus_inf
+            out[i, 0] = v if np.isfinite(v) and v > self.minus_inf else self.minus_inf
+        self.timing["True Objective Evaluations"] += time.time() - t0
+        return out
+
+    def update_gp(self, new_pts_u: np.ndarray, new_vals: np.ndarray, fit_n_points: int) -> None:
+        """bo.py:620-668 — refit thresholds by training-set size (strict '<' as in the reference)."""
+        t0 = time.time()
+        self.n_points_since_last_fit += new_pts_u.shape[0]
+        n = self.gp.train_x.shape[0]
+        if n < 200:
+            refit_threshold, maxiter, n_restarts = min(2, fit_n_points), 1000, 8
+        elif 200 < n < 750:
+            refit_threshold, n_restarts, maxiter = fit_n_points, 4, 500
+        else:
+            refit_threshold, n_restarts, maxiter = max(40, fit_n_points), 4, 200
+        refit = self.n_points_since_last_fit >= refit_threshold
+        self.gp.update(new_pts_u, new_vals)
+        if refit:
+            gp_fit(self.gp, n_restarts=n_restarts, maxiters=maxiter, rng=self.np_rng)
+            self.n_points_since_last_fit = 0
+        self.timing["GP Training"] += time.time() - t0
+
+    def run(self, acq: str = "wipstd", max_evals: int = 250, max_gp_size: int = 1200, fit_n_points: int = 10,
+            batch_size: int = 1, mc_points_size: int = 64, num_mc_samples: int = 1024,
+            acq_threshold: Optional[float] = None, zeta_ei: float = 0.01, verbose: bool = False) -> dict:
+        acq_fn = _ACQ[acq.lower()]()
+        is_wip = acq.lower() in ("wipv", "wipstd")
+        acq_hist: List[float] = []
+        while self.gp.npoints < min(max_evals, max_gp_size):
+            t0 = time.time()
+            if is_wip:
+                mc = get_mc_samples(self.gp, num_samples=num_mc_samples, method="uniform", np_rng=self.np_rng)
+                kwargs = {"mc_samples": mc, "mc_points_size": mc_points_size}
+                new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=batch_size, acq_kwargs=kwargs, n_restarts=1,
+                                                    maxiter=100, early_stop_patience=10, rng=self.np_rng)  # bo.py:1274
+            else:
+                kwargs = {"zeta": zeta_ei, "best_y": float(np.max(self.gp.train_y))}
+                new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=1, acq_kwargs=kwargs, n_restarts=20,
+                                                    maxiter=250, rng=self.np_rng)
+            new_u = np.atleast_2d(new_u)
+            self.timing["Acquisition Optimization"] += time.time() - t0
+            acq_hist.append(float(np.mean(vals)))
+            n_before = self.gp.npoints
+            new_vals = self._evaluate(scale_from_unit(new_u, self.param_bounds))
+            self.update_gp(new_u, new_vals, fit_n_points)
+            if verbose:
+                log.info(f"N={self.gp.npoints} acq={acq_hist[-1]:.3e}")
+            if self.gp.npoints == n_before:          # every proposal was a duplicate: nothing left to learn here
+                break
+            if acq_threshold is not None and is_wip and acq_hist[-1] <= acq_threshold:
+                break
+        y = self.gp.train_y * self.gp.y_std + self.gp.y_mean
+        ibest = int(np.argmax(y))
+        return {"gp": self.gp, "best_val": float(y[ibest, 0]),
+                "best_x": scale_from_unit(self.gp.train_x[ibest], self.param_bounds),
+                "n_evals": int(self.gp.npoints), "acq_history": acq_hist, "timing": dict(self.timing),
+                "lengthscales": np.array(self.gp.lengthscales), "kernel_variance": float(self.gp.kernel_variance)}
