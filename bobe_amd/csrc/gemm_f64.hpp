@@ -52,7 +52,10 @@ constexpr int gemm_smem_doubles() {
               imax(Img<KC, TN, BK>::doubles, Img<RC, TN, BK>::doubles));
 }
 constexpr int BK128 = 16;   // 128x128 tiles: 73,728 B of LDS -> two workgroups per CU
-constexpr int BK64 = 32;    // 64x64 tiles: deeper K-steps hide the global-load latency (69,632 B -> two per CU)
+#ifndef BOBE_BK64
+#define BOBE_BK64 32
+#endif
+constexpr int BK64 = BOBE_BK64;   // 64x64 tiles: deeper K-steps hide the global-load latency
 constexpr int GEMM_SMEM_DOUBLES = gemm_smem_doubles<128, 128, BK128>();
 constexpr int GEMM_SMEM_BYTES = GEMM_SMEM_DOUBLES * 8;
 constexpr int GEMM64_SMEM_BYTES = gemm_smem_doubles<64, 64, BK64>() * 8;

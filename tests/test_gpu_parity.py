@@ -404,3 +404,49 @@ def test_headline_config_properties(lib):
     gp2 = GP(X, 2.0 * y + 1.0, noise=1e-6, lengthscales=ls, kernel_variance=kv)   # standardisation removes scale/shift
     assert np.allclose(gp2.predict_batched(cand[:512])[0], r["mean"][:512], atol=1e-9)
     assert np.allclose(gp2.predict_mean_batched(cand[:512]), 2.0 * (r["mean"][:512] * gp.y_std + gp.y_mean) + 1.0, atol=1e-8)
+
+
+def test_negative_fantasy_pivot_floors_everything(lib):
+    """gp.py:187: sqrt(k_self - v.v) is NaN when the pivot is negative, which floors every var+(.|c) at 1e-12.
+    Forced here by restoring a deliberately shrunken factor (L/2 quadruples |L^-1 k|^2)."""
+    from bobe_amd import GP as GPcls
+    X, y = smooth_data(90, 2, seed=12)
+    gp, og = both(X, y, noise=1e-6, lengthscales=[0.4, 0.4])
+    sd = gp.state_dict()
+    sd["cholesky"] = 0.5 * sd["cholesky"]
+    bad = GPcls.from_state_dict(sd)
+    og.cholesky = 0.5 * og.cholesky
+    rng = np.random.default_rng(1)
+    cand, Z = np.vstack([X[:6] + 1e-3, rng.uniform(size=(20, 2))]), rng.uniform(size=(12, 2))
+    r = bad.wip_sweep(cand, Z, want_mean_var=True)
+    ro = O.wip_sweep(og, cand, Z)
+    neg = (1.0 + 1e-6) - np.sum(solve_triangular(og.cholesky, og._k12(cand), lower=True) ** 2, axis=0) < 0
+    assert neg.sum() >= 6                                   # the near-training candidates have s_c < 0
+    assert np.all(r["wipv"][neg] == pytest.approx(1e-12 * og.y_std ** 2, rel=1e-12))
+    assert np.allclose(r["wipv"], ro["wipv"], rtol=1e-7, atol=1e-18)
+    assert np.allclose(r["wipstd"], ro["wipstd"], rtol=1e-7, atol=1e-18)
+    assert np.all(r["var"][neg] == 1e-12)                   # predict_single floor (gp.py:487-488)
+    pv = bad.predict_var_batched(cand)
+    assert np.all(pv[neg] == pytest.approx(1e-12 * og.y_std ** 2))   # clip (gp.py:465)
+
+
+def test_state_dict_interop_with_reference_format(tmp_path):
+    """A reference-format state (the keys of gp.py:597-634, here produced by the oracle) loads into the GPU GP
+    without refactorisation and reproduces its predictions; the GPU GP's own npz has the same keys."""
+    from bobe_amd import GP as GPcls
+    X, y = ref_data(45, 3)
+    og = O.OracleGP(X, y, noise=1e-6, lengthscales=[0.3, 0.5, 0.7], kernel_variance=1.2)
+    state = {"train_x": og.train_x, "train_y": og.train_y * og.y_std + og.y_mean, "lengthscales": og.lengthscales,
+             "kernel_variance": og.kernel_variance, "noise": og.noise, "tausq": 1.0, "y_mean": og.y_mean,
+             "y_std": og.y_std, "kernel_name": "rbf", "lengthscale_prior_spec": None,
+             "kernel_variance_prior_spec": None, "fixed_kernel_variance": False, "optimizer_method": "scipy",
+             "optimizer_options": {}, "lengthscale_bounds": [0.01, 5], "kernel_variance_bounds": [1e-4, 1e8],
+             "tausq_bounds": [1e-4, 1e4], "cholesky": og.cholesky, "alphas": og.alphas, "ndim": 3, "gp_class": "GP"}
+    fn = str(tmp_path / "ref_state.npz")
+    np.savez(fn, **state)
+    gp = GPcls.load(fn)
+    q = np.random.default_rng(4).uniform(size=(30, 3))
+    assert np.allclose(gp.predict_mean_batched(q), og.predict_mean_batched(q), atol=1e-9)
+    assert np.allclose(gp.predict_var_batched(q), og.predict_var_batched(q), rtol=1e-6, atol=1e-12)
+    assert np.array_equal(gp.cholesky, og.cholesky)          # restored bit for bit, not refactorised
+    assert set(gp.state_dict()) == set(state)
