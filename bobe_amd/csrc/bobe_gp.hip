@@ -86,9 +86,10 @@ __global__ __launch_bounds__(256, 2) void k_debug_gemm(const double* __restrict_
   store_tile(acc, C, ldc, (int64_t)blockIdx.y * TILE, (int64_t)blockIdx.x * TILE, 1.0, 0.0);
 }
 
-constexpr int SYRK64_BK = 64, SYRK128_BK = 32;
-constexpr int SYRK64_SMEM = gemm_smem_doubles<64, 64, SYRK64_BK>() * 8;      // 135,168 B
-constexpr int SYRK128_SMEM = gemm_smem_doubles<128, 128, SYRK128_BK>() * 8;  // 147,456 B
+constexpr int SYRK32_BK = 64, SYRK64_BK = 64, SYRK128_BK = 32;
+constexpr int SYRK32_SMEM = gemm_smem_doubles_exact<KC, KC, 32, 32, SYRK32_BK>() * 8;      //  67,584 B
+constexpr int SYRK64_SMEM = gemm_smem_doubles_exact<KC, KC, 64, 64, SYRK64_BK>() * 8;      // 135,168 B
+constexpr int SYRK128_SMEM = gemm_smem_doubles_exact<KC, KC, 128, 128, SYRK128_BK>() * 8;  // 139,264 B
 
 void configure_kernels_once() {
   static bool done[64] = {false};
@@ -103,6 +104,7 @@ void configure_kernels_once() {
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_syrk_trail<64, SYRK64_BK>, SYRK64_SMEM);
+  allow_big_lds(k_syrk_trail<32, SYRK32_BK>, SYRK32_SMEM);
   allow_big_lds(k_trtri_T<64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_trtri_R<64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 8, 64>, GEMM64_SMEM_BYTES);
@@ -134,16 +136,17 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk64_below, trtri64_below, lauum64_below, lookahead, reserve_cus; double syrk_t128_us, syrk_t64_us; };
+struct Tuning { int syrk64_below, trtri64_below, lauum64_below, lookahead, reserve_cus; double syrk_t128_us, syrk_t64_us; int syrk32_max_tiles; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{600, 600, 1200, 0, 32, 25.0, 6.5};   // lookahead off: cross-stream event cost exceeds the overlap gain
+    Tuning v{600, 600, 1200, 0, 32, 25.0, 6.5, 8192};   // lookahead off: cross-stream event cost exceeds the overlap gain
     if (const char* e = std::getenv("BOBE_SYRK64")) v.syrk64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LOOKAHEAD")) v.lookahead = std::atoi(e);
     if (const char* e = std::getenv("BOBE_SYRK_T128")) v.syrk_t128_us = std::atof(e);
     if (const char* e = std::getenv("BOBE_SYRK_T64")) v.syrk_t64_us = std::atof(e);
+    if (const char* e = std::getenv("BOBE_SYRK32_MAX")) v.syrk32_max_tiles = std::atoi(e);
     if (const char* e = std::getenv("BOBE_RESERVE_CUS")) v.reserve_cus = std::atoi(e);
     return v;
   }();
@@ -329,8 +332,15 @@ void bobe_gp::syrk(double* a, int k, int first, int colmode, hipStream_t st) {
   const int rem = nb - first;                 // 128-blocks in the trailing matrix
   if (rem <= 0) return;
   const int t128 = colmode ? rem : rem * (rem + 1) / 2;
-  const int n64 = 2 * rem;
+  const int n64 = 2 * rem, n32 = 4 * rem;
   const int t64 = colmode ? 2 * n64 - 1 : n64 * (n64 + 1) / 2;
+  const int t32 = n32 * (n32 + 1) / 2;
+  // a tile's time is set by its MFMAs per wave (512 / 128 / 32 at K = 128): small trailing matrices take the
+  // smallest tile that still fills the chip, large ones the cheapest by a rounds x tile-time estimate
+  if (!colmode && t32 <= tu.syrk32_max_tiles) {
+    hipLaunchKernelGGL((k_syrk_trail<32, SYRK32_BK>), dim3(t32), dim3(256), SYRK32_SMEM, st, a, Np, k, first, 0, n32);
+    return;
+  }
   const double est128 = std::ceil(t128 / 256.0) * tu.syrk_t128_us, est64 = std::ceil(t64 / 256.0) * tu.syrk_t64_us;
   if (est64 <= est128) {
     hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(t64), dim3(256), SYRK64_SMEM, st, a, Np, k, first, colmode, n64);

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
 
 // ---- trailing update: A[i][j] -= L[i][k] L[j][k]^T over lower T x T tiles of the trailing matrix -------
 // The tiles start at 128-block `first`.  colmode 0: every lower tile (grid = n(n+1)/2, n = (Np-first*128)/T).
-// colmode 1: only the tiles of 128-block column `first` (the next panel; grid = (128/T)*n - (T==64 ? 1 : 0)).
+// colmode 1: only the tiles of 128-block column `first` (the next panel; T = 128 or 64 only).
 // The lookahead Cholesky issues colmode 1 for block k+1 on the panel stream and colmode 0 from block k+2
 // on the update stream.
 template <int T, int BK>

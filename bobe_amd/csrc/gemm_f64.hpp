@@ -51,6 +51,11 @@ constexpr int gemm_smem_doubles() {
   return 2 * (imax(Img<KC, TM, BK>::doubles, Img<RC, TM, BK>::doubles) +
               imax(Img<KC, TN, BK>::doubles, Img<RC, TN, BK>::doubles));
 }
+// exact LDS doubles for a given layout pair (gemm_tile lays the two operand images out back to back)
+template <int LA, int LB, int TM, int TN, int BK>
+constexpr int gemm_smem_doubles_exact() {
+  return 2 * (Img<LA, TM, BK>::doubles + Img<LB, TN, BK>::doubles);
+}
 constexpr int BK128 = 16;   // 128x128 tiles: 73,728 B of LDS -> two workgroups per CU
 #ifndef BOBE_BK64
 #define BOBE_BK64 32
@@ -127,8 +132,8 @@ __device__ __forceinline__ void gemm_tile(v4d (&acc)[TM / 32][TN / 32], const do
                                           int64_t m0, const double* __restrict__ B, int64_t ldb, int64_t n0,
                                           int64_t kbeg, int64_t kend, double* smem) {
   constexpr int FM = TM / 32, FN = TN / 32;
-  constexpr int IA = imax(Img<KC, TM, BK>::doubles, Img<RC, TM, BK>::doubles);
-  constexpr int IB = imax(Img<KC, TN, BK>::doubles, Img<RC, TN, BK>::doubles);
+  constexpr int IA = Img<LA, TM, BK>::doubles;
+  constexpr int IB = Img<LB, TN, BK>::doubles;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
