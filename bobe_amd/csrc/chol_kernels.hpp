@@ -72,8 +72,8 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
 //      Lpp^-T: the inverse of the sub-block comes for free.  Meanwhile waves 1..3 apply the deferred
 //      (non-urgent) updates of step p-1.
 //   B  rows below: X^T = inv(Lpp) A^T, four MFMAs per 16-row tile.
-//   C  urgent updates: the tiles of block column p+1 (needed by the next A and B); the tiles of the
-//      columns >= p+2 are deferred to the next step's phase A.
+//   C  the one urgent update, the next diagonal tile (p+1,p+1), by wave 0 without a barrier; every other
+//      tile of the step's in-block update is deferred to the next step's phase A.
 constexpr int POTF2_DLD = 17;
 constexpr int POTF2_SMEM_BYTES = (TILE * PLD + 8 * 16 * POTF2_DLD) * 8;   // 150,528 B
 
@@ -163,16 +163,17 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t l
       if (bad && lane == 0) atomicMin(info, blk * TILE + o + 1);
       }
     } else if (p > 0) {
-      // ---- phase A, waves 1..3: deferred updates of step p-1 (tiles with tj >= p+1) ----
+      // ---- phase A, waves 1..3: deferred updates of step p-1: every tile (ti, tj), p <= tj <= ti <= 7,
+      //      except the diagonal tile (p, p), which wave 0 updated right after the previous phase B ----
       const int op = o - 16;
-      const int nt = 7 - p;                 // tiles p+1..7
-      const int ntiles = nt * (nt + 1) / 2;
+      const int nt = 8 - p;                 // tiles p..7
+      const int ntiles = nt * (nt + 1) / 2 - 1;
       for (int q = wave - 1; q < ntiles; q += 6) {
         int a0, b0, a1, b1;
-        tri_decode_small(q, a0, b0);
+        tri_decode_small(q + 1, a0, b0);    // index 0 is (p, p): skipped
         const bool two = (q + 3) < ntiles;
-        tri_decode_small(two ? q + 3 : q, a1, b1);
-        potf2_update2(S, op, p + 1 + a0, p + 1 + b0, p + 1 + a1, p + 1 + b1, two, lane);
+        tri_decode_small(two ? q + 4 : q + 1, a1, b1);
+        potf2_update2(S, op, p + a0, p + b0, p + a1, p + b1, two, lane);
       }
     }
     __syncthreads();
@@ -191,13 +192,12 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t l
     }
     __syncthreads();
     BOBE_STAMP(4 + 3 * p);
-    // ---- phase C: urgent updates, block column p+1: tiles (tt, p+1), tt = p+1..7 ----
-    if (p < 7) {
-      const int tt0 = p + 1 + wave, tt1 = tt0 + 4;
-      if (tt0 < 8) potf2_update2(S, o, tt0, p + 1, (tt1 < 8) ? tt1 : tt0, p + 1, tt1 < 8, lane);
-    }
-    __syncthreads();
+    // ---- phase C: the only urgent update is the next diagonal tile (p+1, p+1); wave 0 does it and runs
+    //      straight into the next phase A (same wave: no barrier needed), the other waves go on to the
+    //      deferred tiles ----
+    if (p < 7 && wave == 0) potf2_update2(S, o, p + 1, p + 1, p + 1, p + 1, false, lane);
   }
+  __syncthreads();
   BOBE_STAMP(26);
   if (FACTOR) {
     block_store_lower(S, Ab, lda);
