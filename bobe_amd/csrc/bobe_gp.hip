@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256, 2) void k_debug_gemm(const double* __restrict_
   store_tile(acc, C, ldc, (int64_t)blockIdx.y * TILE, (int64_t)blockIdx.x * TILE, 1.0, 0.0);
 }
 
-constexpr int SYRK32_BK = 64, SYRK64_BK = 64, SYRK128_BK = 32;
-constexpr int SYRK32_SMEM = gemm_smem_doubles_exact<KC, KC, 32, 32, SYRK32_BK>() * 8;      //  67,584 B
+constexpr int SYRK32_BK = 128, SYRK64_BK = 64, SYRK128_BK = 32;   // BK = 128 = the whole panel: one stage, one LDS buffer
+constexpr int SYRK32_SMEM = gemm_smem_doubles_exact<KC, KC, 32, 32, SYRK32_BK>() * 8 / 2;  //  66,560 B (single buffer)
 constexpr int SYRK64_SMEM = gemm_smem_doubles_exact<KC, KC, 64, 64, SYRK64_BK>() * 8;      // 135,168 B
 constexpr int SYRK128_SMEM = gemm_smem_doubles_exact<KC, KC, 128, 128, SYRK128_BK>() * 8;  // 139,264 B
 
