@@ -450,3 +450,50 @@ def test_state_dict_interop_with_reference_format(tmp_path):
     assert np.allclose(gp.predict_var_batched(q), og.predict_var_batched(q), rtol=1e-6, atol=1e-12)
     assert np.array_equal(gp.cholesky, og.cholesky)          # restored bit for bit, not refactorised
     assert set(gp.state_dict()) == set(state)
+
+
+def test_two_handles_are_independent():
+    """Distinct handles own their buffers and streams (SURVEY 8b threading contract)."""
+    X1, y1 = smooth_data(140, 3, seed=21)
+    X2, y2 = smooth_data(260, 5, seed=22)
+    g1, o1 = both(X1, y1, noise=1e-6, lengthscales=[0.4, 0.5, 0.6])
+    g2, o2 = both(X2, y2, noise=1e-6, kernel="matern", lengthscales=[0.5] * 5)
+    q1, q2 = np.random.default_rng(1).uniform(size=(33, 3)), np.random.default_rng(2).uniform(size=(47, 5))
+    for _ in range(2):                                   # interleave calls on the two handles
+        m1 = g1.predict_mean_batched(q1)
+        f2, gr2 = g2.neg_mll_value_and_grad(np.log(g2.get_hyperparams()) + 0.05)
+        m2 = g2.predict_mean_batched(q2)
+        f1, gr1 = g1.neg_mll_value_and_grad(np.log(g1.get_hyperparams()) - 0.05)
+    assert np.allclose(m1, o1.predict_mean_batched(q1), atol=1e-8) and np.allclose(m2, o2.predict_mean_batched(q2), atol=1e-8)
+    assert f1 == pytest.approx(o1.neg_mll_value_and_grad(np.log(o1.get_hyperparams()) - 0.05)[0], rel=1e-10)
+    assert f2 == pytest.approx(o2.neg_mll_value_and_grad(np.log(o2.get_hyperparams()) + 0.05)[0], rel=1e-10)
+
+
+def test_growing_training_set_reallocates_cleanly():
+    """update() across the 128-padding boundary (N = 120 -> 126 -> 132 -> 138) keeps matching the oracle."""
+    X, y = smooth_data(120, 2, seed=30)
+    gp, og = both(X, y, noise=1e-6, lengthscales=[0.4, 0.4])
+    rng = np.random.default_rng(31)
+    for _ in range(3):
+        nx = rng.uniform(size=(6, 2))
+        ny = (np.sin(3 * nx[:, 0]) + np.cos(2 * nx[:, 1]) * nx[:, 1]).reshape(-1, 1)
+        gp.update(nx, ny)
+        og.update(nx, ny)
+        q = rng.uniform(size=(20, 2))
+        assert gp.npoints == og.npoints
+        assert np.allclose(gp.predict_mean_batched(q), og.predict_mean_batched(q), atol=1e-7)
+        assert np.allclose(gp.cholesky, og.cholesky, atol=1e-10)
+
+
+def test_config4_candidate_count_single_gpu():
+    """BASELINE.json config 4 candidate set (262 144) unsharded on one GPU: several scoring super-chunks; the
+    first 65 536 scores must be bit-identical to a sweep over that prefix alone."""
+    from bobe_amd.synthetic import synthetic_problem, theta_schedule
+    N, d, M = 1024, 8, 512
+    X, y, cand, Z = synthetic_problem(N, d, 262144, M)
+    th = theta_schedule(d)[-1]
+    gp = GP(X, y, noise=1e-6, lengthscales=np.exp(th[:d]), kernel_variance=1.0)
+    r = gp.wip_sweep(cand, Z)
+    rp = gp.wip_sweep(cand[:65536], Z)
+    assert np.array_equal(r["wipstd"][:65536], rp["wipstd"]) and np.array_equal(r["wipv"][:65536], rp["wipv"])
+    assert r["argmin_s"] == int(np.argmin(r["wipstd"])) and np.all(np.isfinite(r["wipv"]))
