@@ -167,7 +167,12 @@ def get_mc_samples(gp: GP, warmup_steps=512, num_samples=1024, thinning=4, metho
     NUTS / nested sampling are sampler consumers ('next')."""
     if method == "uniform":
         return {"x": qmc.Sobol(gp.ndim, scramble=True, seed=np_rng).random(num_samples)}
-    raise NotImplementedError(f"mc-sample method {method!r} is outside the GPU hot path (see DESIGN.md)")
+    if method == "NS":                                   # acquisition.py:473-475, batched on the GPU GP
+        from .samplers import nested_sampling
+        rng = np_rng if isinstance(np_rng, np.random.Generator) else np.random.default_rng(np_rng)
+        samples, _, _ = nested_sampling(gp, ndim=gp.ndim, mode="acq", rng=rng)
+        return samples
+    raise NotImplementedError(f"mc-sample method {method!r} is not available (NUTS needs NumPyro; see DESIGN.md)")
 
 
 def get_mc_points(mc_samples, mc_points_size=128, rng=None):

@@ -5,10 +5,10 @@ Mirrors the parts of ``BOBE/bo.py`` that *call* the hot path: Sobol initialisati
 WIPV / WIPStd / EI iteration (bo.py:1174-1224, 1226-1390: mc points -> get_next_batch -> evaluate ->
 update_gp) and the refit policy of ``update_gp`` (bo.py:620-668, strict ``<`` size classes included).
 
-Not reproduced (out of the GPU hot path): MPI pool, classifier GP, nested-sampling /
-NUTS samplers and therefore the logZ convergence test; the loop stops on ``max_evals``, ``max_gp_size`` or an
-acquisition-value threshold.  Integration points come from the reference's ``'uniform'`` method (scrambled
-Sobol, acquisition.py:476-479).
+Not reproduced: MPI pool, classifier GP, NUTS.  The logZ convergence test (bo.py:886-891)
+runs on ``bobe_amd.samplers.nested_sampling`` (batched on the GPU GP) instead of dynesty; the loop also stops
+on ``max_evals``, ``max_gp_size`` or an acquisition-value threshold.  Integration points come from the
+reference's ``'uniform'`` (scrambled Sobol, acquisition.py:476-479) or ``'NS'`` (acquisition.py:473-475) method.
 """
 from __future__ import annotations
 
@@ -102,16 +102,25 @@ class BOBE:
             self.n_points_since_last_fit = 0
         self.timing["GP Training"] += time.time() - t0
 
-    def run(self, acq: str = "wipstd", max_evals: int = 250, max_gp_size: int = 1200, fit_n_points: int = 10,
-            batch_size: int = 1, mc_points_size: int = 64, num_mc_samples: int = 1024,
-            acq_threshold: Optional[float] = None, zeta_ei: float = 0.01, verbose: bool = False) -> dict:
+    def run(self, acq: str = "wipstd", min_evals: int = 0, max_evals: int = 250, max_gp_size: int = 1200,
+            fit_n_points: int = 10, batch_size: int = 1, mc_points_size: int = 64, num_mc_samples: int = 1024,
+            mc_points_method: str = "uniform", logz_threshold: Optional[float] = None, ns_n_points: int = 10,
+            convergence_n_iters: int = 1, do_final_ns: bool = False, acq_threshold: Optional[float] = None,
+            zeta_ei: float = 0.01, verbose: bool = False) -> dict:
+        """BO loop.  With ``logz_threshold`` the run also stops once nested sampling on the surrogate gives
+        (logZ_upper - logZ_lower)/2 < threshold ``convergence_n_iters`` times in a row (bo.py:886-891, 1283-1311);
+        the check runs every ``ns_n_points`` new evaluations after ``min_evals``."""
+        from .samplers import nested_sampling
         acq_fn = _ACQ[acq.lower()]()
         is_wip = acq.lower() in ("wipv", "wipstd")
         acq_hist: List[float] = []
+        logz: Optional[dict] = None
+        converged, n_ok, since_ns = False, 0, 0
+        self.timing.setdefault("Nested Sampling", 0.0)
         while self.gp.npoints < min(max_evals, max_gp_size):
             t0 = time.time()
             if is_wip:
-                mc = get_mc_samples(self.gp, num_samples=num_mc_samples, method="uniform", np_rng=self.np_rng)
+                mc = get_mc_samples(self.gp, num_samples=num_mc_samples, method=mc_points_method, np_rng=self.np_rng)
                 kwargs = {"mc_samples": mc, "mc_points_size": mc_points_size}
                 new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=batch_size, acq_kwargs=kwargs, n_restarts=1,
                                                     maxiter=100, early_stop_patience=10, rng=self.np_rng)  # bo.py:1274
@@ -131,9 +140,25 @@ class BOBE:
                 break
             if acq_threshold is not None and is_wip and acq_hist[-1] <= acq_threshold:
                 break
+            since_ns += self.gp.npoints - n_before
+            if logz_threshold is not None and self.gp.npoints >= min_evals and since_ns >= ns_n_points:
+                t0 = time.time()
+                _, logz, ok = nested_sampling(self.gp, mode="convergence", rng=self.np_rng)
+                self.timing["Nested Sampling"] += time.time() - t0
+                since_ns = 0
+                delta = (logz["upper"] - logz["lower"]) / 2.0                    # bo.py:886-891
+                n_ok = n_ok + 1 if (ok and delta < logz_threshold) else 0
+                if n_ok >= convergence_n_iters:
+                    converged = True
+                    break
+        if do_final_ns or (logz_threshold is not None and logz is None):
+            t0 = time.time()
+            _, logz, _ = nested_sampling(self.gp, mode="convergence", rng=self.np_rng)
+            self.timing["Nested Sampling"] += time.time() - t0
         y = self.gp.train_y * self.gp.y_std + self.gp.y_mean
         ibest = int(np.argmax(y))
         return {"gp": self.gp, "best_val": float(y[ibest, 0]),
                 "best_x": scale_from_unit(self.gp.train_x[ibest], self.param_bounds),
                 "n_evals": int(self.gp.npoints), "acq_history": acq_hist, "timing": dict(self.timing),
-                "lengthscales": np.array(self.gp.lengthscales), "kernel_variance": float(self.gp.kernel_variance)}
+                "lengthscales": np.array(self.gp.lengthscales), "kernel_variance": float(self.gp.kernel_variance),
+                "logz": logz, "converged": converged}

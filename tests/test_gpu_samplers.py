@@ -1,0 +1,55 @@
+"""Evidence consumer on the GPU GP: nested sampling of the surrogate + logZ bounds."""
+import math
+
+import numpy as np
+import pytest
+from scipy.stats import qmc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_compute_integrals_matches_closed_form():
+    from bobe_amd.samplers import compute_integrals
+    # L(X) = 1 everywhere: Z -> 1 - X_last as the volume shrinks
+    n, nlive = 4000, 100
+    logvol = -np.arange(1, n + 1) / nlive
+    z = compute_integrals(logl=np.zeros(n), logvol=logvol)
+    assert np.all(np.diff(z) >= 0)
+    assert math.exp(z[-1]) == pytest.approx(1.0 - math.exp(logvol[-1]), rel=1e-12)
+
+
+def test_nested_sampling_gaussian_evidence_and_bounds():
+    from bobe_amd import GP
+    from bobe_amd.samplers import nested_sampling
+    d, sig = 2, 0.15
+    X = qmc.Sobol(d, scramble=True, seed=3).random(256)
+    y = -0.5 * np.sum(((X - 0.5) / sig) ** 2, axis=1)
+    gp = GP(X, y, noise=1e-8, lengthscales=[0.5, 0.5], kernel_variance=10.0)
+    from bobe_amd.bo import gp_fit
+    gp_fit(gp, maxiters=100, n_restarts=2, rng=np.random.default_rng(0))
+    samples, logz, ok = nested_sampling(gp, mode="convergence", dlogz=0.01, rng=np.random.default_rng(1))
+    analytic = d * 0.5 * math.log(2 * math.pi * sig ** 2)          # tails beyond 3.3 sigma are negligible
+    assert ok and set(logz) >= {"mean", "dlogz_sampler", "upper", "lower", "var", "std"}
+    assert logz["mean"] == pytest.approx(analytic, abs=0.2)
+    assert logz["lower"] <= logz["mean"] <= logz["upper"]
+    assert (logz["upper"] - logz["lower"]) / 2 < 0.5               # bo.py:886-891 convergence quantity is finite and small
+    assert set(samples) == {"x", "weights", "logl", "best", "method"} and samples["method"] == "nested"
+    assert np.all(np.abs(samples["best"] - 0.5) < 0.05)
+    w = samples["weights"]
+    post_mean = (w[:, None] * samples["x"]).sum(0) / w.sum()
+    assert np.all(np.abs(post_mean - 0.5) < 0.03)
+    # 'acq' mode: equal-weight samples usable as mc_samples for WIPV/WIPStd (acquisition.py:473-475)
+    s2, _, _ = nested_sampling(gp, mode="acq", rng=np.random.default_rng(2))
+    assert np.all(s2["weights"] == 1.0) and s2["x"].shape[1] == d
+    assert np.all(np.abs(s2["x"].mean(0) - 0.5) < 0.05)
+
+
+def test_bo_loop_with_logz_convergence():
+    from bobe_amd.bo import BOBE
+    sig = 0.2
+    bounds = np.array([[0.0, 1.0], [0.0, 1.0]]).T
+    bobe = BOBE(lambda x: -0.5 * float(np.sum(((x - 0.5) / sig) ** 2)), ["a", "b"], bounds, n_sobol_init=16, seed=5)
+    res = bobe.run(acq="wipstd", max_evals=80, fit_n_points=4, batch_size=2, mc_points_size=64, mc_points_method="NS",
+                   logz_threshold=0.05, min_evals=24, ns_n_points=8)
+    assert "logz" in res and res["logz"]["mean"] == pytest.approx(2 * 0.5 * math.log(2 * math.pi * sig ** 2), abs=0.25)
+    assert res["n_evals"] <= 80 and (res["converged"] or res["n_evals"] == 80)
