@@ -8,16 +8,6 @@ from scipy.stats import qmc
 pytestmark = pytest.mark.gpu
 
 
-def test_compute_integrals_matches_closed_form():
-    from bobe_amd.samplers import compute_integrals
-    # L(X) = 1 everywhere: Z -> 1 - X_last as the volume shrinks
-    n, nlive = 4000, 100
-    logvol = -np.arange(1, n + 1) / nlive
-    z = compute_integrals(logl=np.zeros(n), logvol=logvol)
-    assert np.all(np.diff(z) >= 0)
-    assert math.exp(z[-1]) == pytest.approx(1.0 - math.exp(logvol[-1]), rel=1e-12)
-
-
 def test_nested_sampling_gaussian_evidence_and_bounds():
     from bobe_amd import GP
     from bobe_amd.samplers import nested_sampling

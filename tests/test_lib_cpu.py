@@ -112,3 +112,22 @@ def test_synthetic_problem_is_seeded():
     assert np.array_equal(c[2], a[2][16:32])
     th = theta_schedule(3)
     assert th.shape == (20, 4) and th[0, 0] == pytest.approx(np.log(0.6)) and th[1, 0] == pytest.approx(np.log(0.6) - 0.05)
+
+
+def test_compute_integrals_closed_form_and_resampling():
+    """bobe_amd.samplers.compute_integrals restates the dynesty trapezoid of BOBE/samplers.py:27-50."""
+    import math
+    from bobe_amd.samplers import compute_integrals, renormalise_log_weights, resample_equal
+    n, nlive = 4000, 100
+    logvol = -np.arange(1, n + 1) / nlive
+    z = compute_integrals(logl=np.zeros(n), logvol=logvol)
+    assert np.all(np.diff(z) >= 0)
+    # L = 1 with a zero-likelihood pad at X = 1: Z = (1 - X_n) - (1 - X_1)/2
+    want = (1.0 - math.exp(logvol[-1])) - 0.5 * (1.0 - math.exp(logvol[0]))
+    assert math.exp(z[-1]) == pytest.approx(want, rel=1e-12)
+    z2 = compute_integrals(logl=np.zeros(n), logvol=logvol, squared=True)
+    assert z2[-1] < z[-1]
+    w = renormalise_log_weights(np.log(np.array([1.0, 3.0, 6.0])))
+    assert np.allclose(w, [0.1, 0.3, 0.6])
+    xs, ls = resample_equal(np.arange(3)[:, None], np.arange(3.0), w, rng=np.random.default_rng(0))
+    assert xs.shape == (3, 1) and set(xs.ravel()) <= {0, 1, 2}
