@@ -1,0 +1,169 @@
+"""``GPwithClassifier`` — counterpart of ``BOBE/clf_gp.py`` on top of the GPU ``GP``.
+
+All GP arithmetic is inherited (``super()`` calls into libbobe_gp.so, as in the reference, clf_gp.py:173-212);
+this class adds what the reference adds: a second, larger data set for a feasibility classifier, the GP
+trained only on points within ``gp_threshold`` of the best value (clf_gp.py:86-93, 238-244), and the gating of
+the predictions — mean -> ``minus_inf`` and variance -> 1e-12 where the classifier says "infeasible"
+(clf_gp.py:173-205).  Only the SVM classifier is provided (scikit-learn ``SVC`` + the RBF decision function of
+clf.py:188-213, evaluated batched in NumPy); the Flax MLP / ellipsoid classifiers are optional extras of the
+reference and are not built.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+from .gp import GP, safe_noise_floor
+from .utils import get_logger, get_numpy_rng
+
+log = get_logger("clf_gp")
+
+
+def train_svm_classifier(X, Y, settings=None):
+    """clf.py:36-69: SVC(kernel='rbf', gamma='scale', C=1e7); returns (params, metrics, predict_fn)."""
+    from sklearn.svm import SVC
+    settings = settings or {}
+    C = settings.get("C", 1e7)
+    clf = SVC(kernel=settings.get("kernel", "rbf"), gamma=settings.get("gamma", "scale"), C=C)
+    clf.fit(np.asarray(X), np.asarray(Y))
+    params = {"support_vectors": np.array(clf.support_vectors_), "dual_coef": np.array(clf.dual_coef_[0]),
+              "intercept": float(clf.intercept_[0]), "gamma_eff": float(clf._gamma)}
+    metrics = {"n_support_vectors": len(params["support_vectors"]), "gamma": f"{params['gamma_eff']:.2e}",
+               "C": f"{C:.2e}", "intercept": f"{params['intercept']:.2e}"}
+    return params, metrics, get_svm_predict_proba_fn(params)
+
+
+def get_svm_predict_proba_fn(params) -> Callable[[np.ndarray], np.ndarray]:
+    """clf.py:71-78, 188-213: decision = sum_i dual_i exp(-gamma |x - sv_i|^2) + b ; proba = 1[decision >= 0]."""
+    sv, dc = np.asarray(params["support_vectors"]), np.asarray(params["dual_coef"])
+    b, gamma = float(params["intercept"]), float(params["gamma_eff"])
+
+    def predict(x):
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        d2 = np.sum(x * x, axis=1)[:, None] - 2.0 * x @ sv.T + np.sum(sv * sv, axis=1)[None, :]
+        decision = np.exp(-gamma * np.maximum(d2, 0.0)) @ dc + b
+        return np.where(decision >= 0, 1.0, 0.0)
+    return predict
+
+
+class GPwithClassifier(GP):
+    def __init__(self, train_x=None, train_y=None, clf_type="svm", clf_settings=None, clf_use_size=10,
+                 clf_update_step=1, probability_threshold=0.5, minus_inf=-1e5, clf_threshold=250.0,
+                 gp_threshold=500.0, noise=1e-8, kernel="rbf", optimizer="scipy", optimizer_options={},
+                 kernel_variance_bounds=[1e-4, 1e8], lengthscale_bounds=[0.01, 5.0], tausq=None,
+                 tausq_bounds=[1e-4, 1e4], kernel_variance_prior=None, lengthscale_prior=None, lengthscales=None,
+                 kernel_variance=1.0, param_names=None, train_clf_on_init=True, device: int = 0):
+        """Same keywords as clf_gp.py:15-30 (+ ``device``)."""
+        if clf_type.lower() != "svm":
+            raise ValueError(f"Unsupported classifier type: {clf_type} (only 'svm' is built)")
+        self.train_x_clf = np.array(train_x, dtype=np.float64)
+        self.train_y_clf = np.array(train_y, dtype=np.float64).reshape(-1, 1)
+        self.clf_use_size, self.clf_update_step = clf_use_size, clf_update_step
+        self.clf_type, self.clf_settings = "svm", (clf_settings or {})
+        self.clf_params, self.clf_metrics = None, {}
+        self.probability_threshold, self.minus_inf = probability_threshold, minus_inf
+        self.clf_threshold, self.gp_threshold = clf_threshold, gp_threshold
+        mask = self.train_y_clf.flatten() > (self.train_y_clf.max() - self.gp_threshold)       # clf_gp.py:86-89
+        super().__init__(train_x=self.train_x_clf[mask], train_y=self.train_y_clf[mask], noise=noise, kernel=kernel,
+                         optimizer=optimizer, optimizer_options=optimizer_options,
+                         kernel_variance_bounds=kernel_variance_bounds, lengthscale_bounds=lengthscale_bounds,
+                         lengthscales=lengthscales, kernel_variance=kernel_variance,
+                         lengthscale_prior=lengthscale_prior if lengthscale_prior is not None else "DSLP",
+                         kernel_variance_prior=kernel_variance_prior, tausq=tausq, tausq_bounds=tausq_bounds,
+                         param_names=param_names, device=device)
+        self.use_clf = self.clf_data_size >= self.clf_use_size
+        self._clf_predict_func: Optional[Callable] = None
+        if self.use_clf and train_clf_on_init:
+            self.train_classifier()
+
+    @property
+    def clf_data_size(self) -> int:
+        return self.train_x_clf.shape[0]
+
+    def train_classifier(self):
+        """clf_gp.py:128-171."""
+        if not self.use_clf and self.clf_data_size >= self.clf_use_size:
+            self.use_clf = True
+        if not self.use_clf:
+            return
+        labels = np.where(self.train_y_clf.flatten() < self.train_y_clf.max() - self.clf_threshold, 0, 1)
+        if np.all(labels == labels[0]):               # one class only: do not use the classifier for the moment
+            self.use_clf = False
+            return
+        self.clf_params, self.clf_metrics, self._clf_predict_func = train_svm_classifier(
+            self.train_x_clf, labels, self.clf_settings)
+
+    def _feasible(self, x) -> Optional[np.ndarray]:
+        if not self.use_clf or self._clf_predict_func is None:
+            return None
+        return self._clf_predict_func(x) >= self.probability_threshold
+
+    # ---- gated predictions (clf_gp.py:173-205) ----
+    def predict_mean_batched(self, x):
+        m = super().predict_mean_batched(x)
+        ok = self._feasible(x)
+        return m if ok is None else np.where(ok, m, self.minus_inf)
+
+    def predict_mean_single(self, x):
+        return self.predict_mean_batched(x)[0]
+
+    def predict_var_batched(self, x):
+        v = super().predict_var_batched(x)
+        ok = self._feasible(x)
+        return v if ok is None else np.where(ok, v, safe_noise_floor)
+
+    def predict_var_single(self, x):
+        return self.predict_var_batched(x)[0]
+
+    def predict_batched(self, x):
+        m, v = super().predict_batched(x)
+        ok = self._feasible(x)
+        if ok is None:
+            return m, v
+        return np.where(ok, m, self.minus_inf), np.where(ok, v, safe_noise_floor)
+
+    def predict_single(self, x):
+        m, v = self.predict_batched(x)
+        return m[0], v[0:1]
+
+    def update(self, new_x, new_y):
+        """clf_gp.py:214-246: extend the classifier set, re-derive the GP subset, refactor."""
+        new_x = np.atleast_2d(np.asarray(new_x, dtype=np.float64))
+        new_y = np.atleast_2d(np.asarray(new_y, dtype=np.float64))
+        pts, vals = [], []
+        for i in range(new_x.shape[0]):
+            if np.any(np.all(np.isclose(self.train_x_clf, new_x[i], atol=1e-6, rtol=1e-4), axis=1)):
+                continue
+            pts.append(new_x[i])
+            vals.append(new_y[i])
+        if pts:
+            self.train_x_clf = np.concatenate([self.train_x_clf, np.atleast_2d(np.array(pts))], axis=0)
+            self.train_y_clf = np.concatenate([self.train_y_clf, np.array(vals).reshape(-1, 1)], axis=0)
+            mask = self.train_y_clf.flatten() > (self.train_y_clf.max() - self.gp_threshold)
+            self.train_x = self.train_x_clf[mask]
+            y = self.train_y_clf[mask].reshape(-1, 1)
+            self.y_std = float(np.std(y)) if y.shape[0] > 1 else 1.0
+            self.y_mean = float(np.mean(y))
+            self.train_y = (y - self.y_mean) / self.y_std
+            self._push_data()
+            self.recompute_cholesky()
+
+    def get_random_point(self, rng=None, nstd=None):
+        """clf_gp.py:254-277 (the nstd -> threshold map of utils/core.py is replaced by clf_threshold)."""
+        rng = rng if rng is not None else get_numpy_rng()
+        if self.use_clf:
+            idx = np.where(self.train_y_clf.flatten() > self.train_y_clf.max() - self.clf_threshold)[0]
+            return self.train_x_clf[rng.choice(idx, size=1)[0]]
+        return super().get_random_point(rng=rng, nstd=nstd)
+
+    def state_dict(self):
+        """clf_gp.py:279-320: base GP state + classifier data / configuration / parameters."""
+        state = super().state_dict()
+        state.update({"train_x_clf": np.array(self.train_x_clf), "train_y_clf": np.array(self.train_y_clf),
+                      "clf_type": self.clf_type, "clf_settings": self.clf_settings, "clf_use_size": self.clf_use_size,
+                      "clf_update_step": self.clf_update_step, "probability_threshold": self.probability_threshold,
+                      "minus_inf": self.minus_inf, "clf_threshold": self.clf_threshold,
+                      "gp_threshold": self.gp_threshold, "use_clf": self.use_clf, "clf_params": self.clf_params,
+                      "clf_metrics": self.clf_metrics, "gp_class": "GPwithClassifier"})
+        return state
