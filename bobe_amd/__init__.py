@@ -7,6 +7,17 @@ from ._lib import BobeLibraryError, load as load_library  # noqa: F401
 from .gp import GP  # noqa: F401
 from .acquisition import EI, LogEI, WIPV, WIPStd, get_mc_points, get_mc_samples  # noqa: F401
 from .optim import optimize_scipy  # noqa: F401
+from .bo import BOBE, gp_fit  # noqa: F401
+from .samplers import compute_integrals, nested_sampling  # noqa: F401
 
-__all__ = ["GP", "EI", "LogEI", "WIPV", "WIPStd", "get_mc_points", "get_mc_samples", "optimize_scipy",
-           "load_library", "BobeLibraryError"]
+
+def __getattr__(name):            # scikit-learn is only needed for the classifier GP
+    if name == "GPwithClassifier":
+        from .clf_gp import GPwithClassifier
+        return GPwithClassifier
+    raise AttributeError(name)
+
+
+__all__ = ["GP", "GPwithClassifier", "EI", "LogEI", "WIPV", "WIPStd", "get_mc_points", "get_mc_samples",
+           "optimize_scipy", "BOBE", "gp_fit", "nested_sampling", "compute_integrals", "load_library",
+           "BobeLibraryError"]
