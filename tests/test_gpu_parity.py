@@ -377,6 +377,11 @@ def test_headline_config_properties(lib):
     mll_gpu, _ = gp.mll_data(ls, kv, want_grad=False)          # data term only (the default priors are constants)
     assert abs(mll_gpu - mll_o) <= 1e-10 * abs(mll_o)
     assert -f == pytest.approx(mll_gpu + gp.prior_func(ls, kv, 1.0), rel=1e-14)
+    # full gradient against the oracle's LAPACK (dpotrf/dpotri) evaluation at the same theta (~5 s of CPU)
+    mll_cpu, g_cpu = O.cycle_value_and_grad(X, y, ls, kv, 1e-6)
+    _, g_gpu = gp.mll_data(ls, kv)
+    assert abs(mll_gpu - mll_cpu) <= 1e-10 * abs(mll_cpu)
+    assert np.max(np.abs(g_gpu - g_cpu)) <= 1e-8 * np.max(np.abs(g_cpu))
     e = 1e-4
     for j in (0, d):
         tp, tm = th[-1].copy(), th[-1].copy()
