@@ -46,6 +46,8 @@ SIGNATURES = [
                                     c_int64_p, c_double_p, c_int64_p, c_double_p]),
     ("bobe_gp_fantasy_var", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]),
     ("bobe_gp_acq_ei", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    ("bobe_gp_predict_grad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     ("bobe_gp_kernel", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
                                  C.c_double, C.c_int, C.c_void_p]),
     ("bobe_gp_get_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

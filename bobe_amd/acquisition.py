@@ -4,10 +4,10 @@ WIPV / WIPStd evaluate every candidate in ONE call of ``bobe_gp_wip_sweep`` (the
 ``fun`` over the candidates sequentially with ``lax.map``, acquisition.py:390-394).  EI / LogEI are
 pointwise scorers on the batched posterior (``bobe_gp_acq_ei``).
 
-Deviation from the reference, stated once: where the reference differentiates ``fun`` with JAX
-(local L-BFGS-B refinement for N <= 500, acquisition.py:403-412; EI restarts, acquisition.py:281-290)
-this module uses batched forward differences evaluated on the GPU (d+1 points per gradient in one
-call), because a C-ABI GP is opaque to autodiff.
+Where the reference differentiates ``fun`` with JAX: EI / LogEI restarts (acquisition.py:281-290) use the
+analytic posterior gradients of ``bobe_gp_predict_grad``; the WIPV / WIPStd local refinement for N <= 500
+(acquisition.py:403-412) uses batched forward differences evaluated on the GPU (d+1 points per gradient in
+one call) — the one stated deviation, because a C-ABI GP is opaque to autodiff.
 """
 from __future__ import annotations
 
@@ -79,11 +79,29 @@ class EI(AcquisitionFunction):
         return val[0] if np.ndim(x) == 1 else val
 
     def _value_and_grad(self, gp, best_y, zeta):
+        """(-EI, d(-EI)/dx) or (-logEI, ...) from the GPU's analytic posterior gradients (bobe_gp_predict_grad):
+        dEI = Phi(u) dmu + phi(u) dsigma, u = (mu - zeta - best)/sigma; logEI through log-space ratios."""
+        from scipy.special import log_ndtr
+        lo = 1e-18 if self._log else 1e-20                      # acquisition.py:247, 324
+
         def vg(x):
             x = np.asarray(x, dtype=np.float64)
-            pts = np.vstack([x] + [x + _FD_STEP * e for e in np.eye(len(x))])
-            v = self.fun(pts, gp, best_y, zeta)
-            return float(v[0]), (v[1:] - v[0]) / _FD_STEP
+            m, v, dm, dv = gp.predict_grad(x[None, :])
+            m, v, dm, dv = float(m[0]), float(v[0]), dm[0], dv[0]
+            clipped = v < lo
+            v = max(v, lo)
+            sigma = np.sqrt(v)
+            dsig = np.zeros_like(dv) if clipped else dv / (2.0 * sigma)
+            u = (m - zeta - best_y) / sigma
+            log_phi = -0.5 * u * u - 0.5 * np.log(2.0 * np.pi)
+            log_Phi = float(log_ndtr(u))
+            if not self._log:
+                val = -float(gp.acq_ei(x[None, :], best_y, zeta, log_ei=False)[0])
+                return val, -(np.exp(log_Phi) * dm + np.exp(log_phi) * dsig)
+            log_ei = float(gp.acq_ei(x[None, :], best_y, zeta, log_ei=True)[0])       # = log h(u) + log sigma
+            # d logEI = (Phi dmu + phi dsigma) / EI, with EI = exp(log_ei)
+            grad = np.exp(log_Phi - log_ei) * dm + np.exp(log_phi - log_ei) * dsig
+            return -log_ei, -grad
         return vg
 
     def get_next_point(self, gp, acq_kwargs=None, maxiter: int = 250, n_restarts: int = 20, verbose: bool = True,

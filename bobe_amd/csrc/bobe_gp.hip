@@ -899,6 +899,69 @@ int bobe_gp_acq_ei(bobe_gp_t* g, const double* Xq, int64_t C, double best_y, dou
   API_END
 }
 
+int bobe_gp_predict_grad(bobe_gp_t* g, const double* Xq, int64_t C, double* mean, double* var, double* dmean,
+                         double* dvar) {
+  API_BEGIN
+  if (!g || !Xq || !dmean || !dvar) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  if (C <= 0) throw Err(BOBE_ERR_ARG, "C must be positive");
+  g->use();
+  const int d = g->d, nb = g->nb;
+  const int64_t Np = g->Np, CH = std::min<int64_t>(g->chunk, 2048);
+  const double kself = g->hyp.kvar + g->hyp.noise;
+  const double* cin = g->fetch(Xq, (size_t)C * d, g->in_stage);
+  g->CsT.ensure((size_t)d * std::max<int64_t>(CH, g->chunk) * sizeof(double));
+  g->kXC.ensure((size_t)Np * std::max<int64_t>(CH, g->chunk) * sizeof(double));
+  g->VZ.ensure((size_t)Np * CH * sizeof(double));     // V = Linv k
+  g->WZ.ensure((size_t)Np * CH * sizeof(double));     // U = Linv^T V = K^-1 k
+  g->qpart.ensure((size_t)nb * std::max<int64_t>(CH, g->chunk) * sizeof(double));
+  g->part.ensure((size_t)nb * std::max<int64_t>(Np, std::max<int64_t>(CH, g->chunk)) * sizeof(double));
+  g->sc.ensure((size_t)std::max<int64_t>(CH, g->chunk) * sizeof(double));
+  double* d_mean = g->out_dev(mean, C, g->o_mean);
+  double* d_var = g->out_dev(var, C, g->o_var);
+  double* d_dm = g->out_dev(dmean, (size_t)C * d, g->o_wipv);
+  double* d_dv = g->out_dev(dvar, (size_t)C * d, g->o_wipstd);
+  const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+  for (int64_t c0 = 0; c0 < C; c0 += CH) {
+    const int64_t nc = std::min<int64_t>(CH, C - c0), ncp = round_up(nc, TILE);
+    g->scale(cin + c0 * d, nc, ncp, g->hyp, g->CsT.d(), CH);
+    g->kernel_matrix_cross(g->XsT.d(), Np, g->N, Np, g->CsT.d(), CH, nc, ncp, g->hyp, g->kXC.d(), CH);
+    if (d_mean) {
+      hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(ncp / 64), (unsigned)nb), dim3(256), 0, g->stream,
+                         (const double*)g->kXC.d(), CH, 0, (const double*)g->alpha.d(), g->part.d(), CH);
+      hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, g->stream,
+                         (const double*)g->part.d(), CH, nb, 0, nc, d_mean + c0);
+    }
+    hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, g->stream,
+                       (const double*)g->Linv.d(), Np, nb, (const double*)g->kXC.d(), CH, g->VZ.d(), CH, g->qpart.d(), CH,
+                       (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, g->stream,
+                       (const double*)g->qpart.d(), CH, nb, nc, kself, 1, g->sc.d(), d_var ? d_var + c0 : nullptr);
+    hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, g->stream,
+                       (const double*)g->Linv.d(), Np, nb, (const double*)g->VZ.d(), CH, g->WZ.d(), CH);
+    const dim3 grid((unsigned)((nc + 63) / 64));
+    const size_t sm = (size_t)(d + 1) * 128 * sizeof(double);
+#define PG(KE, DC)                                                                                                  \
+  hipLaunchKernelGGL((k_predict_grad<KE, DC>), grid, dim3(256), sm, g->stream, (const double*)g->XsT.d(), Np, g->N,    \
+                     (const double*)g->CsT.d(), CH, nc, (const double*)g->alpha.d(), (const double*)g->WZ.d(), CH,     \
+                     (const double*)g->sc.d(), g->hyp, d_dm + c0 * d, d_dv + c0 * d)
+    if (g->hyp.kern == 0) {
+      if (dcap == 8) PG(0, 8); else if (dcap == 16) PG(0, 16); else PG(0, 32);
+    } else {
+      if (dcap == 8) PG(1, 8); else if (dcap == 16) PG(1, 16); else PG(1, 32);
+    }
+#undef PG
+    LAUNCH_CHECK();
+  }
+  g->out_finish(mean, C, g->o_mean);
+  g->out_finish(var, C, g->o_var);
+  g->out_finish(dmean, (size_t)C * d, g->o_wipv);
+  g->out_finish(dvar, (size_t)C * d, g->o_wipstd);
+  g->sync();
+  return BOBE_OK;
+  API_END
+}
+
 int bobe_gp_kernel(bobe_gp_t* g, const double* A, int64_t nA, const double* B, int64_t nB, const double* ls,
                    double kvar, double noise, int include_noise, double* out) {
   API_BEGIN

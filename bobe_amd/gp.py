@@ -373,6 +373,17 @@ class GP:
                                             1 if log_ei else 0, _lib.ptr(out)), "bobe_gp_acq_ei")
         return out
 
+    def predict_grad(self, x):
+        """Standardised (mean, var, dmean/dx, dvar/dx) of ``predict_single`` (gp.py:476-489) for C points: what the
+        reference gets by JAX autodiff through the GP (acquisition.py:246-253, samplers.py:268-276)."""
+        x = _lib.as_f64(np.atleast_2d(x))
+        c = x.shape[0]
+        mean, var = np.empty(c), np.empty(c)
+        dmean, dvar = np.empty((c, self.ndim)), np.empty((c, self.ndim))
+        _lib.check(self._lib.bobe_gp_predict_grad(self._h, _lib.ptr(x), c, _lib.ptr(mean), _lib.ptr(var),
+                                                  _lib.ptr(dmean), _lib.ptr(dvar)), "bobe_gp_predict_grad")
+        return mean, var, dmean, dvar
+
     def get_random_point(self, rng=None, nstd=None):
         """BOBE/gp.py:578-585."""
         rng = rng if rng is not None else get_numpy_rng()

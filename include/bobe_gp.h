@@ -98,6 +98,13 @@ int bobe_gp_fantasy_var(bobe_gp_t* gp, const double* cand, int64_t C, const doub
  * +log EI (mode 1); best_y, zeta in standardised units. */
 int bobe_gp_acq_ei(bobe_gp_t* gp, const double* Xq, int64_t C, double best_y, double zeta, int mode, double* out);
 
+/* Input gradients of GP.predict_single (gp.py:476-489) — what the reference obtains by differentiating through
+ * the GP with JAX (EI restarts acquisition.py:246-253/281-290; NUTS on predict_mean_batched samplers.py:268-276).
+ * mean, var (may be NULL): as bobe_gp_predict with nan_policy 1.  dmean, dvar: C x d, derivatives with respect
+ * to the query coordinates, standardised units; dvar is 0 where var sits at its 1e-12 floor (gradient of where). */
+int bobe_gp_predict_grad(bobe_gp_t* gp, const double* Xq, int64_t C, double* mean, double* var, double* dmean,
+                         double* dvar);
+
 /* GP.kernel(xa, xb, ls, kvar, noise, include_noise) (gp.py:124-168; call site acquisition.py:388).
  * lengthscales == NULL uses the handle's current hyper-parameters (kernel_variance / noise arguments
  * are then ignored).  The factorised state is not touched.  out is nA x nB. */

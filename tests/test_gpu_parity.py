@@ -502,3 +502,41 @@ def test_config4_candidate_count_single_gpu():
     rp = gp.wip_sweep(cand[:65536], Z)
     assert np.array_equal(r["wipstd"][:65536], rp["wipstd"]) and np.array_equal(r["wipv"][:65536], rp["wipv"])
     assert r["argmin_s"] == int(np.argmin(r["wipstd"])) and np.all(np.isfinite(r["wipv"]))
+
+
+@pytest.mark.parametrize("kernel,d", [("rbf", 3), ("matern", 5), ("rbf", 12)])
+def test_predict_grad_against_central_differences(kernel, d):
+    """bobe_gp_predict_grad = the JAX autodiff of gp.predict_single in the reference (acquisition.py:246-253)."""
+    X, y = smooth_data(180, d, seed=40 + d)
+    ls = 0.35 + 0.05 * np.arange(d)
+    gp, og = both(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.3)
+    q = np.random.default_rng(3).uniform(0.1, 0.9, size=(9, d))
+    m, v, dm, dv = gp.predict_grad(q)
+    mo, vo = og.predict_batched(q)
+    assert np.allclose(m, mo, atol=3e-8) and np.all(np.abs(v - vo) <= 1e-9 * 1.3 + 1e-7 * vo)
+    e = 1e-6
+    for j in range(d):
+        qp, qm = q.copy(), q.copy()
+        qp[:, j] += e
+        qm[:, j] -= e
+        mp, vp = og.predict_batched(qp)
+        mm, vm = og.predict_batched(qm)
+        assert np.allclose(dm[:, j], (mp - mm) / (2 * e), rtol=2e-5, atol=1e-6)
+        assert np.allclose(dv[:, j], (vp - vm) / (2 * e), rtol=2e-4, atol=1e-6)
+    # at a training point the variance sits near the floor; on the floor the gradient is zero
+    _, v0, _, dv0 = gp.predict_grad(X[:1])
+    assert v0[0] >= 1e-12 and np.all(np.isfinite(dv0))
+
+
+def test_ei_analytic_gradient_matches_finite_differences():
+    from bobe_amd import EI, LogEI
+    X, y = ref_data(30, 2)
+    y = -np.sum((X - 0.7) ** 2, axis=1, keepdims=True)
+    gp = GP(X, y, noise=1e-6, lengthscales=[0.3, 0.3])
+    best = float(np.max(gp.train_y))
+    for cls in (EI, LogEI):
+        vg = cls()._value_and_grad(gp, best, 0.01)
+        for x0 in (np.array([0.55, 0.62]), np.array([0.2, 0.9])):
+            f, g = vg(x0)
+            fd = np.array([(vg(x0 + h)[0] - vg(x0 - h)[0]) / 2e-6 for h in (np.array([1e-6, 0]), np.array([0, 1e-6]))])
+            assert np.allclose(g, fd, rtol=1e-3, atol=1e-7 * max(1.0, abs(f)))
