@@ -100,6 +100,7 @@ void configure_kernels_once() {
   allow_big_lds(k_potf2<false, false>, POTF2_SMEM_BYTES);
   allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
   allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
+  allow_big_lds(k_panel_fused, FUSED_SMEM_BYTES);
   allow_big_lds(k_syrk_trail<128, SYRK128_BK>, SYRK128_SMEM);
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
@@ -136,10 +137,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk64_below, trtri64_below, lauum64_below, lookahead, reserve_cus; double syrk_t128_us, syrk_t64_us; int syrk32_max_tiles; };
+struct Tuning { int syrk64_below, trtri64_below, lauum64_below, lookahead, reserve_cus; double syrk_t128_us, syrk_t64_us; int syrk32_max_tiles, fused_panel; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{600, 600, 1200, 0, 32, 25.0, 6.5, 8192};   // lookahead off: cross-stream event cost exceeds the overlap gain
+    Tuning v{600, 600, 1200, 0, 32, 25.0, 6.5, 8192, 0};   // lookahead, fused panel off: hand-off costs exceed the overlap gain
     if (const char* e = std::getenv("BOBE_SYRK64")) v.syrk64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -147,6 +148,7 @@ const Tuning& tuning() {
     if (const char* e = std::getenv("BOBE_SYRK_T128")) v.syrk_t128_us = std::atof(e);
     if (const char* e = std::getenv("BOBE_SYRK_T64")) v.syrk_t64_us = std::atof(e);
     if (const char* e = std::getenv("BOBE_SYRK32_MAX")) v.syrk32_max_tiles = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_FUSED_PANEL")) v.fused_panel = std::atoi(e);
     if (const char* e = std::getenv("BOBE_RESERVE_CUS")) v.reserve_cus = std::atoi(e);
     return v;
   }();
@@ -167,7 +169,8 @@ struct bobe_gp {
   bool have_data = false, factored = false, not_pd = false;
   int64_t chunk = 8192;
 
-  DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs;
+  DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs, flags;
+  int num_cus = 0;
   // sweep / predict workspace
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
@@ -356,17 +359,32 @@ void bobe_gp::syrk(double* a, int k, int first, int colmode, hipStream_t st) {
 void bobe_gp::potrf(double* a, double* linv) {
   const Tuning& tu = tuning();
   const bool la = tu.lookahead && upd_stream && nb > 2;
+  // fused panel launch: potf2(k) publishes its sub-panels to the co-resident panel solvers of the same launch
+  const bool fused = tu.fused_panel && nb > 1 && (1 + 2 * (nb - 1)) <= num_cus;
+  if (fused) {
+    flags.ensure((size_t)nb * sizeof(int));
+    HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)nb * sizeof(int), stream));
+  }
   for (int k = 0; k < nb; ++k) {
-    prof_begin(BOBE_PROF_POTF2);
-    hipLaunchKernelGGL((k_potf2<true, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
-                       static_cast<int*>(info.p), (unsigned long long*)nullptr);
-    prof_end(BOBE_PROF_POTF2);
     const int rem = nb - k - 1;
+    if (fused && rem > 0) {
+      prof_begin(BOBE_PROF_POTF2);
+      hipLaunchKernelGGL(k_panel_fused, dim3(1 + 2 * rem), dim3(256), FUSED_SMEM_BYTES, stream, a, Np, linv, Np, k,
+                         static_cast<int*>(info.p), static_cast<int*>(flags.p));
+      prof_end(BOBE_PROF_POTF2);
+    } else {
+      prof_begin(BOBE_PROF_POTF2);
+      hipLaunchKernelGGL((k_potf2<true, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
+                         static_cast<int*>(info.p), (unsigned long long*)nullptr);
+      prof_end(BOBE_PROF_POTF2);
+    }
     if (rem > 0) {
-      prof_begin(BOBE_PROF_TRSM);
-      hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rem), dim3(256), TRSM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np, k,
-                         (unsigned long long*)nullptr);
-      prof_end(BOBE_PROF_TRSM);
+      if (!fused) {
+        prof_begin(BOBE_PROF_TRSM);
+        hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rem), dim3(256), TRSM_SMEM_BYTES, stream, a, Np,
+                           (const double*)linv, Np, k, (unsigned long long*)nullptr);
+        prof_end(BOBE_PROF_TRSM);
+      }
       if (!la) {
         prof_begin(BOBE_PROF_SYRK);
         syrk(a, k, k + 1, 0, stream);
@@ -663,6 +681,11 @@ int bobe_gp_create(bobe_gp_t** out, int device, int kernel, int d) {
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     g->own_stream = true;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->h_res), 128 * sizeof(double), hipHostMallocDefault));
+    {
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, device));
+      g->num_cus = prop.multiProcessorCount;
+    }
     if (tuning().lookahead) {
       // second stream for the bulk trailing updates; its CU mask leaves `reserve_cus` CUs to the panel chain
       hipDeviceProp_t prop;
@@ -698,7 +721,7 @@ void bobe_gp_destroy(bobe_gp_t* g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   DBuf* bufs[] = {&g->X, &g->y, &g->XsT, &g->XsT2, &g->A, &g->Linv, &g->A2, &g->Linv2, &g->Tmp, &g->alpha, &g->w,
-                  &g->alpha2, &g->w2, &g->part, &g->gpart, &g->res, &g->info, &g->probs, &g->in_stage, &g->z_stage,
+                  &g->alpha2, &g->w2, &g->part, &g->gpart, &g->res, &g->info, &g->probs, &g->flags, &g->in_stage, &g->z_stage,
                   &g->CsT, &g->ZsT, &g->kXC, &g->kXZ, &g->VZ, &g->WZ, &g->basez, &g->sc, &g->qpart, &g->pv, &g->ps,
                   &g->o_mean, &g->o_var, &g->o_wipv, &g->o_wipstd, &g->o_misc, &g->kin_a, &g->kin_b, &g->kout};
   for (DBuf* b : bufs) b->release();
@@ -798,6 +821,7 @@ int bobe_gp_factor(bobe_gp_t* g) {
   g->use();
   g->factor_into(g->hyp, g->XsT.d(), g->A.d(), g->Linv.d(), g->w.d(), g->alpha.d());
   const int inf = g->read_info();
+  if (inf < 0) throw Err(BOBE_ERR_HIP, "fused panel launch timed out waiting for the factorisation (set BOBE_FUSED_PANEL=0)");
   g->factored = true;
   g->not_pd = (inf != 0x7f7f7f7f);
   if (g->not_pd) {
@@ -836,6 +860,7 @@ int bobe_gp_mll(bobe_gp_t* g, const double* ls, double kvar, double* mll, double
   LAUNCH_CHECK();
   HIPCHK(hipMemcpyAsync(g->h_res, g->res.p, (size_t)(3 + d) * sizeof(double), hipMemcpyDeviceToHost, g->stream));
   const int inf = g->read_info();
+  if (inf < 0) throw Err(BOBE_ERR_HIP, "fused panel launch timed out waiting for the factorisation (set BOBE_FUSED_PANEL=0)");
   if (inf != 0x7f7f7f7f) {
     *mll = std::nan("");
     if (grad)

@@ -15,6 +15,7 @@
 namespace bobe {
 
 constexpr int PLD = 130;                          // LDS leading dimension of a 128x128 block (doubles)
+constexpr int POTF2_DLD = 17;                     // leading dimension of a staged 16x16 inverse
 
 // coalesced 128x128 block <-> LDS (16-byte accesses, one row per wave per step).  LOWER: only the lower
 // triangle is needed; lanes right of the diagonal re-read the diagonal's 16-byte granule (same cache line,
@@ -74,7 +75,6 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
 //   B  rows below: X^T = inv(Lpp) A^T, four MFMAs per 16-row tile.
 //   C  the one urgent update, the next diagonal tile (p+1,p+1), by wave 0 without a barrier; every other
 //      tile of the step's in-block update is deferred to the next step's phase A.
-constexpr int POTF2_DLD = 17;
 constexpr int POTF2_SMEM_BYTES = (TILE * PLD + 8 * 16 * POTF2_DLD) * 8;   // 150,528 B
 
 // integer-only lower-triangular decode for small indices (t = i(i+1)/2 + j, i < 8)
@@ -111,10 +111,40 @@ __device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0
   }
 }
 
-template <bool FACTOR, bool STAMP = false>
-__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                               int64_t ldl, int blk, int* __restrict__ info,
-                                               unsigned long long* __restrict__ stamps = nullptr) {
+// Hand-off of the fused panel launch (k_panel_fused), in the write-through form of cdna_hip_programming.md
+// Guideline 16 / MI355X_MICROARCH.md "Valid forms": EVERY published byte is stored with an agent-scope (sc1,
+// write-through) store and loaded with an agent-scope (sc1, L1-bypassing) load; the one storing wave drains its
+// stores (s_waitcnt vmcnt(0)) before its lane 0 stores the flag; consumers poll the flag with sc1 loads and load
+// the data only after the poll has matched (plus a workgroup barrier for the non-polling waves).  No fences.
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Publish sub-panel p of the block being factored: rows 16p..16p+15, columns < 16p of L and the 16x16 inverse
+// invD_p, then flag = p+1.  Called by ONE wave.
+__device__ __forceinline__ void potf2_publish(const double* S, const double* Dall, double* __restrict__ Ab, int64_t lda,
+                                              double* __restrict__ Ib, int64_t ldl, int p, int* flag, int lane) {
+  const int o = 16 * p;
+  for (int i = 0; i < 16; ++i)
+    for (int c = lane; c < o; c += 64) st_agent(Ab + (int64_t)(o + i) * lda + c, S[(o + i) * PLD + c]);
+  {
+    const int rr = lane >> 2, c0 = (lane & 3) * 4;
+    const double* src = Dall + (p * 16 + rr) * POTF2_DLD + c0;
+    double* dst = Ib + (int64_t)(o + rr) * ldl + o + c0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) st_agent(dst + c, src[c]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(flag, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool FACTOR, bool STAMP, bool PUB>
+__device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv, int64_t ldl,
+                                           int blk, int* __restrict__ info, unsigned long long* __restrict__ stamps,
+                                           int* flag) {
   extern __shared__ double S[];
   double* Dall = S + TILE * PLD;  // [8][16][POTF2_DLD]: inverses of the 16x16 diagonal sub-blocks
   const int t = threadIdx.x;
@@ -163,6 +193,8 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t l
       if (bad && lane == 0) atomicMin(info, blk * TILE + o + 1);
       }
     } else if (p > 0) {
+      // fused launch: wave 3 first hands sub-panel p-1 (final since the last barrier) to the panel solvers
+      if (PUB && wave == 3) potf2_publish(S, Dall, Ab, lda, Ib, ldl, p - 1, flag, lane);
       // ---- phase A, waves 1..3: deferred updates of step p-1: every tile (ti, tj), p <= tj <= ti <= 7,
       //      except the diagonal tile (p, p), which wave 0 updated right after the previous phase B ----
       const int op = o - 16;
@@ -199,6 +231,7 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t l
   }
   __syncthreads();
   BOBE_STAMP(26);
+  if (FACTOR && PUB && wave == 3) potf2_publish(S, Dall, Ab, lda, Ib, ldl, 7, flag, lane);   // last sub-panel first
   if (FACTOR) {
     block_store_lower(S, Ab, lda);
     // the eight 16x16 inverses: thread t -> sub-block t>>5, row (t>>1)&15, half row t&1
@@ -224,6 +257,13 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t l
     for (int r = 0; r < 16; ++r) Ib[(int64_t)(o + r) * ldl + o + col] = x[r];
   }
   BOBE_STAMP(28);
+}
+
+template <bool FACTOR, bool STAMP = false>
+__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
+                                               int64_t ldl, int blk, int* __restrict__ info,
+                                               unsigned long long* __restrict__ stamps = nullptr) {
+  potf2_body<FACTOR, STAMP, false>(A, lda, Linv, ldl, blk, info, stamps, nullptr);
 }
 
 // ---- inverse of every diagonal 128x128 block (grid = nb) --------------------------------------------
@@ -372,6 +412,110 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
   for (int i = 0; i < 16; ++i)
     *reinterpret_cast<v2d*>(Aw + (int64_t)i * lda + 2 * lane) = *reinterpret_cast<const v2d*>(Sw + i * PLD + 2 * lane);
   BOBE_STAMP(3);
+}
+
+// ---- fused panel launch: potf2(k) (workgroup 0) + streaming panel solve (workgroups 1..2*rem) -------------
+// The solvers are the same register-resident algorithm as k_trsm_panel, but instead of waiting for the whole
+// L_kk they consume its 16-column sub-panels as workgroup 0 publishes them (flag value p+1 = sub-panels 0..p
+// are in global memory; write-through hand-off, see st_agent / ld_agent above), so only the last sub-step is
+// left when the factorisation finishes.  All workgroups
+// of the launch are co-resident (grid <= 1 + 2*(nb-1) <= #CUs, one workgroup per CU by LDS size), the
+// producer never waits for a consumer, and every spin is bounded (timeout -> *info = -1, results invalid).
+constexpr int FUSED_LROW = 16 * PLD;                                  // one staged 16-row tile of L_kk
+constexpr int FUSED_CONS_DOUBLES = 64 * PLD + 2 * FUSED_LROW + 2 * 16 * POTF2_DLD;
+constexpr int FUSED_SMEM_BYTES = (POTF2_SMEM_BYTES > FUSED_CONS_DOUBLES * 8) ? POTF2_SMEM_BYTES : FUSED_CONS_DOUBLES * 8;
+
+__device__ __forceinline__ void trsm_stream_body(double* __restrict__ A, int64_t lda, const double* __restrict__ Dinv,
+                                                 int64_t ldl, int k, int wg, int* flag, int* __restrict__ info) {
+  extern __shared__ double S[];
+  double* Xs = S;                              // [64][PLD]   row transposes (start / end)
+  double* Lp = S + 64 * PLD;                   // [2][16][PLD] staged row tiles of L_kk (double-buffered)
+  double* Dp = Lp + 2 * FUSED_LROW;            // [2][16][POTF2_DLD] staged invD_p
+  __shared__ int ok;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)wg * 64 + wave * 16;
+  const int64_t col0 = (int64_t)k * TILE;
+  const double* Lkk = A + col0 * lda + col0;
+  const double* Dk = Dinv + col0 * ldl + col0;
+  const int g = lane >> 4, li = lane & 15;
+  double* Aw = A + row0 * lda + col0;
+  double* Sw = Xs + (wave * 16) * PLD;
+  // this wave's 16 rows -> LDS slab -> transposed accumulators (no dependence on the factorisation)
+  {
+    v2d xr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xr[i] = *reinterpret_cast<const v2d*>(Aw + (int64_t)i * lda + 2 * lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<v2d*>(Sw + i * PLD + 2 * lane) = xr[i];
+  }
+  v4d X[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[p][r] = Sw[li * PLD + 16 * p + g + 4 * r];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    // wait for sub-panel p: lane 0 polls the flag with sc1 loads; the other waves load after the barrier
+    if (t == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p + 1 && spins < (1 << 24)) {
+        __builtin_amdgcn_s_sleep(2);
+        ++spins;
+      }
+      ok = spins < (1 << 24);
+    }
+    __syncthreads();
+    if (!ok) {
+      if (t == 0) atomicMin(info, -1);
+      return;
+    }
+    double* Lb = Lp + (p & 1) * FUSED_LROW;
+    double* Db = Dp + (p & 1) * 16 * POTF2_DLD;
+    if (p > 0) {   // row tile p of L_kk, columns < 16p: thread t -> row t>>4, 8 columns from 8*(t&15)
+      const int rr = t >> 4, c0 = 8 * (t & 15);
+      if (c0 < 16 * p) {
+        const double* src = Lkk + (int64_t)(16 * p + rr) * lda + c0;
+        double v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = ld_agent(src + c);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) Lb[rr * PLD + c0 + c] = v[c];
+      }
+    }
+    Db[(t >> 4) * POTF2_DLD + (t & 15)] = ld_agent(Dk + (int64_t)(16 * p + (t >> 4)) * ldl + 16 * p + (t & 15));
+    __syncthreads();
+    v4d x = X[p];
+#pragma unroll
+    for (int q = 0; q < p; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double av = -Lb[li * PLD + 16 * q + g + 4 * r];
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[q][r], x, 0, 0, 0);
+      }
+    v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double av = Db[li * POTF2_DLD + g + 4 * r];
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, x[r], y, 0, 0, 0);
+    }
+    X[p] = y;
+  }
+  // results back through the slab (each wave touches only its own 16 rows of Xs)
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sw[li * PLD + 16 * p + g + 4 * r] = X[p][r];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    *reinterpret_cast<v2d*>(Aw + (int64_t)i * lda + 2 * lane) = *reinterpret_cast<const v2d*>(Sw + i * PLD + 2 * lane);
+}
+
+__global__ __launch_bounds__(256) void k_panel_fused(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
+                                                     int64_t ldl, int k, int* __restrict__ info, int* flags) {
+  if (blockIdx.x == 0)
+    potf2_body<true, false, true>(A, lda, Linv, ldl, k, info, nullptr, flags + k);
+  else
+    trsm_stream_body(A, lda, Linv, ldl, k, (int)blockIdx.x - 1, flags + k, info);
 }
 
 // ---- trailing update: A[i][j] -= L[i][k] L[j][k]^T over lower T x T tiles of the trailing matrix -------
