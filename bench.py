@@ -3,7 +3,10 @@
 
 One *cycle* (SURVEY.md 8d / BASELINE.md section 2) =
     20 x [K(X,X) assembly + Cholesky + alpha + log-marginal-likelihood + analytic gradient]
-       at the fixed theta schedule  (bobe_gp_mll)
+       at the fixed theta schedule: the fit's 4 restarts (GP.fit / optim.py:335-354, independent L-BFGS-B runs)
+       x 5 evaluations each; every restart runs in its own host thread on its own evaluation slot of the library
+       (bobe_gp_mll_submit / bobe_gp_mll_wait), as GP.fit does (--fit-concurrency 1 = one bobe_gp_mll after the
+       other; --fit-mode batch = lock-step rounds through bobe_gp_mll_batch)
   + 1 x refactor at the last theta    (bobe_gp_factor)
   + 1 x sweep: posterior mean & variance of all C candidates, WIPV and WIPStd scores against the
         M = 512 integration points, argmin of both  (bobe_gp_wip_sweep)
@@ -43,6 +46,10 @@ def parse():
     ap.add_argument("--config", default="headline", choices=["tiny", "small", "headline"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-class", default="trimul", help="kernel class timed with HIP events for the roofline")
+    ap.add_argument("--fit-concurrency", type=int, default=4,
+                    help="restarts of the fit evaluated together per bobe_gp_mll_batch call (1 = sequential)")
+    ap.add_argument("--fit-mode", default="slots", choices=["slots", "batch"],
+                    help="slots: one thread + evaluation slot per restart, no barrier; batch: lock-step rounds")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk of the sweep (0 = library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a single GPU")
@@ -126,13 +133,46 @@ def main():
     av, asd, mv, ms = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
     last = {}
 
-    def cycle():
+    R = max(1, args.fit_concurrency)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=max(1, R))
+    ls_all = np.ascontiguousarray(np.exp(thetas[:, :d]))
+    kv_all = np.ascontiguousarray(np.exp(thetas[:, d]))
+    mll_b = np.empty(len(thetas))
+    grad_b = np.empty((len(thetas), d + 1))
+
+    def fit_evals():
+        """the 20 value+gradient evaluations; returns (best mll, its theta, last mll)"""
         best = (-np.inf, None)
-        for th in thetas:
-            ls = np.ascontiguousarray(np.exp(th[:d]))
-            _lib.check(lib.bobe_gp_mll(h, _lib.ptr(ls), float(np.exp(th[d])), C.byref(mll), _lib.ptr(grad)), "mll")
-            if mll.value > best[0]:
-                best = (mll.value, th)
+        if R == 1:
+            for k, th in enumerate(thetas):
+                _lib.check(lib.bobe_gp_mll(h, _lib.ptr(ls_all[k]), float(kv_all[k]), C.byref(mll), _lib.ptr(grad)), "mll")
+                mll_b[k] = mll.value
+        elif args.fit_mode == "slots":
+            def chain(r):                            # restart r: its evaluations, one after the other, on slot r
+                m_, g_ = C.c_double(), np.empty(d + 1)
+                for k in range(r, len(thetas), R):
+                    _lib.check(lib.bobe_gp_mll_submit(h, r, _lib.ptr(ls_all[k]), float(kv_all[k]), 1), "mll_submit")
+                    _lib.check(lib.bobe_gp_mll_wait(h, r, C.byref(m_), _lib.ptr(g_)), "mll_wait")
+                    mll_b[k] = m_.value
+                    grad_b[k] = g_
+            futs = [pool.submit(chain, r) for r in range(R)]
+            for f in futs:
+                f.result()
+        else:
+            for k0 in range(0, len(thetas), R):      # round k0/R of the R restarts
+                nb_ = min(R, len(thetas) - k0)
+                _lib.check(lib.bobe_gp_mll_batch(h, nb_, _lib.ptr(ls_all[k0:k0 + nb_]), _lib.ptr(kv_all[k0:k0 + nb_]),
+                                                 _lib.ptr(mll_b[k0:k0 + nb_]), _lib.ptr(grad_b[k0:k0 + nb_]), None),
+                           "mll_batch")
+        for k, th in enumerate(thetas):
+            if mll_b[k] > best[0]:
+                best = (float(mll_b[k]), th)
+        return best
+
+    def cycle():
+        best = fit_evals()
+        mll.value = float(mll_b[-1])
         _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")
         _lib.check(lib.bobe_gp_factor(h), "factor")
         _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
@@ -168,6 +208,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    fit_ms = {}
+    if rank == 0:               # the fit alone, both ways (outside the timed region)
+        for r_ in sorted({1, R}):
+            R_keep, R = R, r_
+            fit_evals()
+            lib.bobe_gp_sync(h)
+            t1 = time.perf_counter()
+            fit_evals()
+            lib.bobe_gp_sync(h)
+            fit_ms["concurrency_%d" % r_] = (time.perf_counter() - t1) * 1e3
+            R = R_keep
     if rank == 0:
         # Cholesky GF/s: mean device time of the factorisation alone (HIP events on the handle's stream)
         potrf_ms = C.c_double()
@@ -200,9 +251,12 @@ def main():
             "config": {"workload": f"synthetic RBF GP N={N} d={d}, {Cn} candidates per GPU, M={M}, fp64 "
                                    f"(BASELINE.json configs[{2 if args.config == 'headline' else 1}])",
                        "N": N, "d": d, "candidates_per_gpu": Cn, "M": M, "evals_per_cycle": len(thetas),
+                       "fit": f"{R} restarts x {len(thetas) // R} value+gradient evaluations, restarts concurrent ({args.fit_mode})"
+                              if R > 1 else f"{len(thetas)} sequential value+gradient evaluations",
                        "parallelism": f"candidate-sharded x{world}"},
             "cholesky_gflops": (N ** 3 / 3.0) / (potrf_ms.value * 1e-3) / 1e9,
             "cholesky_ms": potrf_ms.value,
+            "fit_ms": fit_ms,
             "check": last,
             "roofline": roof,
         }

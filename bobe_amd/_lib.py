@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libbobe_gp.so")
 
 BOBE_OK = 0
 BOBE_NOT_PD = 1
+MAX_MLL_SLOTS = 8
 PROF = {"potf2": 1, "trsm": 2, "syrk": 3, "trtri": 4, "lauum": 5, "trimul": 6, "cross": 7, "kxx": 8}
 
 c_double_p = C.POINTER(C.c_double)
@@ -40,6 +41,9 @@ SIGNATURES = [
     ("bobe_gp_set_hyper", C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double]),
     ("bobe_gp_factor", C.c_int, [C.c_void_p]),
     ("bobe_gp_mll", C.c_int, [C.c_void_p, C.c_void_p, C.c_double, c_double_p, C.c_void_p]),
+    ("bobe_gp_mll_batch", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("bobe_gp_mll_submit", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int]),
+    ("bobe_gp_mll_wait", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_void_p]),
     ("bobe_gp_predict", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]),
     ("bobe_gp_wip_sweep", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -7,10 +7,12 @@
 
 #include <algorithm>
 #include <climits>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -86,10 +88,9 @@ __global__ __launch_bounds__(256, 2) void k_debug_gemm(const double* __restrict_
   store_tile(acc, C, ldc, (int64_t)blockIdx.y * TILE, (int64_t)blockIdx.x * TILE, 1.0, 0.0);
 }
 
-constexpr int SYRK32_BK = 128, SYRK64_BK = 64, SYRK128_BK = 32;   // BK = 128 = the whole panel: one stage, one LDS buffer
+constexpr int SYRK32_BK = 128, SYRK64_BK = 16;   // BK = 128 = the whole panel: one stage, one LDS buffer
 constexpr int SYRK32_SMEM = gemm_smem_doubles_exact<KC, KC, 32, 32, SYRK32_BK>() * 8 / 2;  //  66,560 B (single buffer)
-constexpr int SYRK64_SMEM = gemm_smem_doubles_exact<KC, KC, 64, 64, SYRK64_BK>() * 8;      // 135,168 B
-constexpr int SYRK128_SMEM = gemm_smem_doubles_exact<KC, KC, 128, 128, SYRK128_BK>() * 8;  // 139,264 B
+constexpr int SYRK64_SMEM = gemm_smem_doubles_exact<KC, KC, 64, 64, SYRK64_BK>() * 8;      //  36,864 B -> four workgroups per CU
 
 void configure_kernels_once() {
   static bool done[64] = {false};
@@ -101,7 +102,6 @@ void configure_kernels_once() {
   allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
   allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
   allow_big_lds(k_panel_fused, FUSED_SMEM_BYTES);
-  allow_big_lds(k_syrk_trail<128, SYRK128_BK>, SYRK128_SMEM);
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_syrk_trail<64, SYRK64_BK>, SYRK64_SMEM);
@@ -137,19 +137,18 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk64_below, trtri64_below, lauum64_below, lookahead, reserve_cus; double syrk_t128_us, syrk_t64_us; int syrk32_max_tiles, fused_panel; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, superpanel, superpanel_batch, fused_panel, mll_slots, slot_mask; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{600, 600, 1200, 0, 32, 25.0, 6.5, 8192, 0};   // lookahead, fused panel off: hand-off costs exceed the overlap gain
-    if (const char* e = std::getenv("BOBE_SYRK64")) v.syrk64_below = std::atoi(e);
+    Tuning v{512, 600, 1200, 1, 1, 0, 4, 3};   // fused panel off: the hand-off costs exceed the overlap gain
+    if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
-    if (const char* e = std::getenv("BOBE_LOOKAHEAD")) v.lookahead = std::atoi(e);
-    if (const char* e = std::getenv("BOBE_SYRK_T128")) v.syrk_t128_us = std::atof(e);
-    if (const char* e = std::getenv("BOBE_SYRK_T64")) v.syrk_t64_us = std::atof(e);
-    if (const char* e = std::getenv("BOBE_SYRK32_MAX")) v.syrk32_max_tiles = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_SUPERPANEL")) v.superpanel = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("BOBE_SUPERPANEL_BATCH")) v.superpanel_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BOBE_FUSED_PANEL")) v.fused_panel = std::atoi(e);
-    if (const char* e = std::getenv("BOBE_RESERVE_CUS")) v.reserve_cus = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_SLOT_MASK")) v.slot_mask = std::atoi(e);
     return v;
   }();
   return t;
@@ -171,13 +170,44 @@ struct bobe_gp {
 
   DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs, flags;
   int num_cus = 0;
+  int eff_cus = 0;   // CUs the current stream may use (num_cus, or its share inside a concurrent batch)
   // sweep / predict workspace
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
   std::vector<Depth> depths;
   double* h_res = nullptr;  // pinned, 128 doubles
-  hipStream_t upd_stream = nullptr;   // trailing updates of the lookahead Cholesky (CU-masked)
-  hipEvent_t ev_panel = nullptr, ev_update = nullptr;
+
+  // Extra evaluation slots of bobe_gp_mll_batch: a private stream + workspace per concurrently evaluated
+  // hyper-parameter vector.  Slot 0 is the handle's own (stream, XsT2, A2, ...) set; a slot is made current by
+  // swapping its members in, so every pipeline stage below runs unchanged on it.
+  struct Slot {
+    hipStream_t stream = nullptr;
+    DBuf XsT2, A2, Linv2, Tmp, alpha2, w2, part, gpart, res, info, flags;
+    double* h_res = nullptr;
+    hipEvent_t ev = nullptr;
+    bool busy = false, want_grad = false;
+  };
+  std::vector<Slot*> slots;
+  // streams of a batch of w concurrent evaluations: wstreams[w][i] is confined to the i-th of w equal CU sets
+  // (the single-workgroup / panel kernels of one evaluation would otherwise queue behind the full-chip
+  // trailing updates of the others)
+  std::vector<std::vector<hipStream_t>> wstreams;
+  const std::vector<hipStream_t>& streams_for(int w);
+  hipEvent_t ev_batch = nullptr;
+  bool in_slot = false;
+  void swap_slot(Slot& s) {
+    std::swap(stream, s.stream);
+    std::swap(XsT2, s.XsT2); std::swap(A2, s.A2); std::swap(Linv2, s.Linv2); std::swap(Tmp, s.Tmp);
+    std::swap(alpha2, s.alpha2); std::swap(w2, s.w2); std::swap(part, s.part); std::swap(gpart, s.gpart);
+    std::swap(res, s.res); std::swap(info, s.info); std::swap(flags, s.flags);
+    std::swap(h_res, s.h_res);
+    in_slot = !in_slot;
+  }
+  std::mutex submit_mutex;          // serialises bobe_gp_mll_submit (the slot swap is not re-entrant)
+  void ensure_slots(int n);
+  void mll_enqueue(const Hyper& h, bool want_grad);
+  int slot_collect(Slot& sl, double* mll, double* grad);
+  int mll_collect(double* mll, double* grad);
 
   // optional per-kernel-class timing with HIP events on the handle's stream (bobe_gp_profile_*)
   int prof_tag = 0;
@@ -230,7 +260,7 @@ struct bobe_gp {
   void kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT, int64_t ldb,
                            int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo);
   void assemble_kxx(const Hyper& h, const double* xst, double* a);
-  void syrk(double* a, int k, int first, int colmode, hipStream_t st);
+  void syrk(double* a, int k0, int k1, int first, int colmode);
   void potrf(double* a, double* linv);
   void trtri(const double* a, double* linv);
   int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap);
@@ -327,81 +357,73 @@ void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a) {
   LAUNCH_CHECK();
 }
 
-// The trailing update has K = 128 only, so its tiles are latency-bound unless several K-steps are in
-// flight: 64x64 tiles use BK = 64 (both halves of the panel loaded up front), 128x128 tiles BK = 32.
-// Both variants take one workgroup per CU; the cheaper one by a simple rounds x tile-time estimate wins.
-void bobe_gp::syrk(double* a, int k, int first, int colmode, hipStream_t st) {
+// Trailing update with the panels of 128-blocks [k0, k1): colmode 0 = every lower tile from 128-block `first`
+// on, colmode 1 = only 128-block column `first` (rows from `first` down).  A tile's time is set by its MFMAs
+// per wave (512 / 128 / 32 per 128 of K): small trailing matrices take the smallest tile that still fills the
+// chip, large ones the cheapest by a rounds x tile-time estimate.
+void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode) {
   const Tuning& tu = tuning();
   const int rem = nb - first;                 // 128-blocks in the trailing matrix
-  if (rem <= 0) return;
-  const int t128 = colmode ? rem : rem * (rem + 1) / 2;
+  if (rem <= 0 || k1 <= k0) return;
+  const int kb = k1 - k0;
   const int n64 = 2 * rem, n32 = 4 * rem;
   const int t64 = colmode ? 2 * n64 - 1 : n64 * (n64 + 1) / 2;
-  const int t32 = n32 * (n32 + 1) / 2;
-  // a tile's time is set by its MFMAs per wave (512 / 128 / 32 at K = 128): small trailing matrices take the
-  // smallest tile that still fills the chip, large ones the cheapest by a rounds x tile-time estimate
-  if (!colmode && t32 <= tu.syrk32_max_tiles) {
-    hipLaunchKernelGGL((k_syrk_trail<32, SYRK32_BK>), dim3(t32), dim3(256), SYRK32_SMEM, st, a, Np, k, first, 0, n32);
+  const int t32 = colmode ? 4 * n32 - 6 : n32 * (n32 + 1) / 2;
+  // 64x64 tiles with BK = 16 (36 KB of LDS, four workgroups per CU) have the best saturated throughput of all
+  // variants at every K (tools/ubench_syrk.hip); when they would leave most of the chip idle, a single-panel
+  // update takes 32x32 tiles, which stage the whole K = 128 panel in one LDS buffer
+  if (kb == 1 && t64 < tu.syrk32_below * eff_cus / num_cus) {
+    hipLaunchKernelGGL((k_syrk_trail<32, SYRK32_BK>), dim3(t32), dim3(256), SYRK32_SMEM, stream, a, Np, k0, k1, first,
+                       colmode, n32);
     return;
   }
-  const double est128 = std::ceil(t128 / 256.0) * tu.syrk_t128_us, est64 = std::ceil(t64 / 256.0) * tu.syrk_t64_us;
-  if (est64 <= est128) {
-    hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(t64), dim3(256), SYRK64_SMEM, st, a, Np, k, first, colmode, n64);
-  } else {
-    hipLaunchKernelGGL((k_syrk_trail<128, SYRK128_BK>), dim3(t128), dim3(256), SYRK128_SMEM, st, a, Np, k, first, colmode,
-                       rem);
-  }
+  hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(t64), dim3(256), SYRK64_SMEM, stream, a, Np, k0, k1, first,
+                     colmode, n64);
 }
 
-// Right-looking blocked Cholesky.  With lookahead the panel chain potf2(k) -> trsm(k) -> update of block
-// column k+1 stays on the handle's stream while the update of the columns >= k+2 runs on a second stream
-// whose CU mask leaves a few CUs free, so the single-workgroup potf2 never waits for an LDS slot.
+// Blocked Cholesky, NB = 128, in super-panels of W blocks: inside a super-panel [k0, k1) the factorisation is
+// left-looking (block column j is brought up to date with the panels k0..j-1 just before it is factored), and
+// the trailing matrix is updated once per super-panel with all W panels (K = 128 W), which cuts the passes over
+// the trailing matrix by W and gives the update tiles a K long enough to reach the GEMM core's steady state.
 void bobe_gp::potrf(double* a, double* linv) {
   const Tuning& tu = tuning();
-  const bool la = tu.lookahead && upd_stream && nb > 2;
+  const int W = std::max(1, in_slot ? tu.superpanel_batch : tu.superpanel);
   // fused panel launch: potf2(k) publishes its sub-panels to the co-resident panel solvers of the same launch
   const bool fused = tu.fused_panel && nb > 1 && (1 + 2 * (nb - 1)) <= num_cus;
   if (fused) {
     flags.ensure((size_t)nb * sizeof(int));
     HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)nb * sizeof(int), stream));
   }
-  for (int k = 0; k < nb; ++k) {
-    const int rem = nb - k - 1;
-    if (fused && rem > 0) {
+  for (int k0 = 0; k0 < nb; k0 += W) {
+    const int k1 = std::min(k0 + W, nb);
+    for (int k = k0; k < k1; ++k) {
+      const int rem = nb - k - 1;
+      if (k > k0) {
+        prof_begin(BOBE_PROF_SYRK);
+        syrk(a, k0, k, k, 1);
+        prof_end(BOBE_PROF_SYRK);
+      }
       prof_begin(BOBE_PROF_POTF2);
-      hipLaunchKernelGGL(k_panel_fused, dim3(1 + 2 * rem), dim3(256), FUSED_SMEM_BYTES, stream, a, Np, linv, Np, k,
-                         static_cast<int*>(info.p), static_cast<int*>(flags.p));
+      if (fused && rem > 0)
+        hipLaunchKernelGGL(k_panel_fused, dim3(1 + 2 * rem), dim3(256), FUSED_SMEM_BYTES, stream, a, Np, linv, Np, k,
+                           static_cast<int*>(info.p), static_cast<int*>(flags.p));
+      else
+        hipLaunchKernelGGL((k_potf2<true, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
+                           static_cast<int*>(info.p), (unsigned long long*)nullptr);
       prof_end(BOBE_PROF_POTF2);
-    } else {
-      prof_begin(BOBE_PROF_POTF2);
-      hipLaunchKernelGGL((k_potf2<true, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
-                         static_cast<int*>(info.p), (unsigned long long*)nullptr);
-      prof_end(BOBE_PROF_POTF2);
-    }
-    if (rem > 0) {
-      if (!fused) {
+      if (rem > 0 && !fused) {
         prof_begin(BOBE_PROF_TRSM);
         hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rem), dim3(256), TRSM_SMEM_BYTES, stream, a, Np,
                            (const double*)linv, Np, k, (unsigned long long*)nullptr);
         prof_end(BOBE_PROF_TRSM);
       }
-      if (!la) {
-        prof_begin(BOBE_PROF_SYRK);
-        syrk(a, k, k + 1, 0, stream);
-        prof_end(BOBE_PROF_SYRK);
-      } else {
-        HIPCHK(hipEventRecord(ev_panel, stream));                 // panel k is final
-        HIPCHK(hipStreamWaitEvent(upd_stream, ev_panel, 0));
-        if (k > 0) HIPCHK(hipStreamWaitEvent(stream, ev_update, 0));   // update k-1 touched block column k+1 too
-        syrk(a, k, k + 1, 1, stream);                             // next panel's column: critical path
-        if (rem > 1) {
-          syrk(a, k, k + 2, 0, upd_stream);                       // the rest, overlapped with panel k+1
-          HIPCHK(hipEventRecord(ev_update, upd_stream));
-        }
-      }
+    }
+    if (k1 < nb) {
+      prof_begin(BOBE_PROF_SYRK);
+      syrk(a, k0, k1, k1, 0);
+      prof_end(BOBE_PROF_SYRK);
     }
   }
-  if (la) HIPCHK(hipStreamWaitEvent(stream, ev_update, 0));
   LAUNCH_CHECK();
 }
 
@@ -415,7 +437,7 @@ void bobe_gp::trtri(const double* a, double* linv) {
     const Depth& D = depths[dd];
     const TriProb* pr = static_cast<const TriProb*>(probs.p) + D.first;
     prof_begin(BOBE_PROF_TRTRI);
-    if (D.nblocks < tu.trtri64_below) {
+    if (D.nblocks < tu.trtri64_below * eff_cus / num_cus) {
       hipLaunchKernelGGL(k_trtri_T<64>, dim3(2 * D.nblocks), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
                          (const double*)linv, Np, Tmp.d(), Np, pr, D.count);
       hipLaunchKernelGGL(k_trtri_R<64>, dim3(2 * D.nblocks), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
@@ -434,6 +456,8 @@ void bobe_gp::trtri(const double* a, double* linv) {
 // K^-1 tiles fused with the gradient partial sums (optionally stores K^-1's lower tiles); returns #partials
 int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap) {
   const Tuning& tu = tuning();
+  // (not scaled by the CU share of a concurrent batch: the tile size fixes the order of the gradient's partial
+  // sums, and a batched evaluation must return the bits of a single one)
   const bool small = nb * (nb + 1) / 2 < tu.lauum64_below;
   const int nt = small ? 2 * nb : nb;
   const int ntiles = nt * (nt + 1) / 2;
@@ -481,6 +505,107 @@ int bobe_gp::read_info() {
   HIPCHK(hipMemcpyAsync(&v, info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
   sync();
   return v;
+}
+
+void bobe_gp::ensure_slots(int n) {
+  if (!ev_batch) HIPCHK(hipEventCreateWithFlags(&ev_batch, hipEventDisableTiming));
+  while ((int)slots.size() < n) {
+    Slot* sl = new Slot();
+    slots.push_back(sl);
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sl->h_res), 128 * sizeof(double), hipHostMallocDefault));
+  }
+  const size_t mat = (size_t)Np * Np * sizeof(double), vec = (size_t)Np * sizeof(double);
+  for (int i = 0; i < n; ++i) {
+    Slot& sl = *slots[i];
+    sl.A2.ensure(mat); sl.Linv2.ensure(mat); sl.Tmp.ensure(mat);
+    sl.alpha2.ensure(vec); sl.w2.ensure(vec); sl.XsT2.ensure((size_t)d * vec);
+    sl.part.ensure((size_t)nb * Np * sizeof(double));
+    sl.gpart.ensure((size_t)(2 * nb) * (2 * nb + 1) / 2 * (MAX_D + 1) * sizeof(double));
+    sl.res.ensure(128 * sizeof(double));
+    sl.info.ensure(sizeof(int));
+  }
+}
+
+const std::vector<hipStream_t>& bobe_gp::streams_for(int w) {
+  if ((int)wstreams.size() <= w) wstreams.resize(w + 1);
+  std::vector<hipStream_t>& v = wstreams[w];
+  if (!v.empty()) return v;
+  const int mode = tuning().slot_mask;
+  const int words = (num_cus + 31) / 32;
+  for (int i = 0; i < w; ++i) {
+    hipStream_t st = nullptr;
+    if (mode != 0 && w > 1 && w <= 8 && num_cus >= 8) {
+      std::vector<uint32_t> mask(words, 0u);
+      for (int c = 0; c < num_cus; ++c) {
+        // CU-mask bits are striped over the 8 XCDs (bit c -> XCD c % 8); a set made of whole XCDs (mode 3) keeps
+        // each evaluation's tiles behind one or two L2s, sets cutting through every XCD measured far slower
+        const bool mine = mode == 1 ? (c * w / num_cus == i) : mode == 2 ? (c % w == i) : ((c % 8) * w / 8 == i);
+        if (mine) mask[c / 32] |= (1u << (c % 32));
+      }
+      if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        st = nullptr;
+      }
+    }
+    if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    v.push_back(st);
+  }
+  return v;
+}
+
+// value (+ gradient) pipeline of one hyper-parameter vector on the current stream / workspace; results land in
+// the pinned h_res: [0] y^T K^-1 y, [1] sum log L_ii, [2..2+d] gradient, [100] the factorisation's info word
+void bobe_gp::mll_enqueue(const Hyper& h, bool want_grad) {
+  factor_into(h, XsT2.d(), A2.d(), Linv2.d(), w2.d(), alpha2.d());
+  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w2.d(), (const double*)A2.d(), Np, Np,
+                     res.d());
+  if (want_grad) {
+    const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+    const int ntiles = lauum(h, Linv2.d(), alpha2.d(), XsT2.d(), nullptr, dcap);
+    hipLaunchKernelGGL(k_grad_reduce, dim3(d + 1), dim3(64), 0, stream, (const double*)gpart.d(), ntiles, dcap + 1, d,
+                       dcap, res.d() + 2);
+  }
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(h_res, res.p, (size_t)(3 + d) * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(h_res + 100, info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+}
+
+int bobe_gp::slot_collect(Slot& sl, double* mll, double* grad) {
+  // touches only the slot's own stream and pinned results: safe while another thread submits to another slot
+  HIPCHK(hipStreamSynchronize(sl.stream));
+  const double* hr = sl.h_res;
+  int inf;
+  std::memcpy(&inf, hr + 100, sizeof(int));
+  if (inf < 0) throw Err(BOBE_ERR_HIP, "fused panel launch timed out waiting for the factorisation (set BOBE_FUSED_PANEL=0)");
+  if (inf != 0x7f7f7f7f) {
+    *mll = std::nan("");
+    if (grad)
+      for (int j = 0; j <= d; ++j) grad[j] = std::nan("");
+    g_err = "kernel matrix not positive definite at column " + std::to_string(inf - 1);
+    return BOBE_NOT_PD;
+  }
+  *mll = -0.5 * hr[0] - hr[1] - 0.5 * (double)N * std::log(2.0 * M_PI);
+  if (grad)
+    for (int j = 0; j <= d; ++j) grad[j] = hr[2 + j];
+  return BOBE_OK;
+}
+
+int bobe_gp::mll_collect(double* mll, double* grad) {
+  sync();
+  int inf;
+  std::memcpy(&inf, h_res + 100, sizeof(int));
+  if (inf < 0) throw Err(BOBE_ERR_HIP, "fused panel launch timed out waiting for the factorisation (set BOBE_FUSED_PANEL=0)");
+  if (inf != 0x7f7f7f7f) {
+    *mll = std::nan("");
+    if (grad)
+      for (int j = 0; j <= d; ++j) grad[j] = std::nan("");
+    g_err = "kernel matrix not positive definite at column " + std::to_string(inf - 1);
+    return BOBE_NOT_PD;
+  }
+  *mll = -0.5 * h_res[0] - h_res[1] - 0.5 * (double)N * std::log(2.0 * M_PI);
+  if (grad)
+    for (int j = 0; j <= d; ++j) grad[j] = h_res[2 + j];
+  return BOBE_OK;
 }
 
 // Z-side quantities of the sweep: ZsT, kXZ, V_Z = Linv kXZ, base_z = kself - |V_Z[:,z]|^2, W_Z = Linv^T V_Z
@@ -685,27 +810,7 @@ int bobe_gp_create(bobe_gp_t** out, int device, int kernel, int d) {
       hipDeviceProp_t prop;
       HIPCHK(hipGetDeviceProperties(&prop, device));
       g->num_cus = prop.multiProcessorCount;
-    }
-    if (tuning().lookahead) {
-      // second stream for the bulk trailing updates; its CU mask leaves `reserve_cus` CUs to the panel chain
-      hipDeviceProp_t prop;
-      HIPCHK(hipGetDeviceProperties(&prop, device));
-      const int ncu = prop.multiProcessorCount;
-      const int keep = std::max(0, std::min(tuning().reserve_cus, ncu / 2));
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      // CUs are numbered round-robin over the shader engines, so taking every (ncu/keep)-th CU out keeps the
-      // reserved set spread over the chip
-      const int stride = keep > 0 ? ncu / keep : 0;
-      for (int c = 0; c < ncu; ++c) {
-        const bool reserved = keep > 0 && (c % stride == 0) && (c / stride < keep);
-        if (!reserved) mask[c / 32] |= (1u << (c % 32));
-      }
-      if (hipExtStreamCreateWithCUMask(&g->upd_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        HIPCHK(hipStreamCreateWithFlags(&g->upd_stream, hipStreamNonBlocking));
-      }
-      HIPCHK(hipEventCreateWithFlags(&g->ev_panel, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&g->ev_update, hipEventDisableTiming));
+      g->eff_cus = g->num_cus;
     }
   } catch (...) {
     delete g;
@@ -730,12 +835,20 @@ void bobe_gp_destroy(bobe_gp_t* g) {
     (void)hipEventDestroy(pr.second);
   }
   if (g->h_res) (void)hipHostFree(g->h_res);
-  if (g->upd_stream) {
-    (void)hipStreamSynchronize(g->upd_stream);
-    (void)hipStreamDestroy(g->upd_stream);
+  for (auto& v : g->wstreams)
+    for (hipStream_t st : v) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+  for (bobe_gp::Slot* sl : g->slots) {
+    DBuf* sb[] = {&sl->XsT2, &sl->A2, &sl->Linv2, &sl->Tmp, &sl->alpha2, &sl->w2, &sl->part, &sl->gpart, &sl->res,
+                  &sl->info, &sl->flags};
+    for (DBuf* b : sb) b->release();
+    if (sl->h_res) (void)hipHostFree(sl->h_res);
+    if (sl->ev) (void)hipEventDestroy(sl->ev);
+    delete sl;
   }
-  if (g->ev_panel) (void)hipEventDestroy(g->ev_panel);
-  if (g->ev_update) (void)hipEventDestroy(g->ev_update);
+  if (g->ev_batch) (void)hipEventDestroy(g->ev_batch);
   if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -847,31 +960,127 @@ int bobe_gp_mll(bobe_gp_t* g, const double* ls, double kvar, double* mll, double
   Hyper h = g->hyp;
   for (int j = 0; j < g->d; ++j) h.ls[j] = ls[j];
   h.kvar = kvar;
-  g->factor_into(h, g->XsT2.d(), g->A2.d(), g->Linv2.d(), g->w2.d(), g->alpha2.d());
-  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, g->stream, (const double*)g->w2.d(), (const double*)g->A2.d(),
-                     g->Np, g->Np, g->res.d());
+  g->mll_enqueue(h, grad != nullptr);
+  return g->mll_collect(mll, grad);
+  API_END
+}
+
+int bobe_gp_mll_batch(bobe_gp_t* g, int64_t B, const double* ls, const double* kvar, double* mll, double* grad,
+                      int* status) {
+  API_BEGIN
+  if (!g || !ls || !kvar || !mll) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (B < 0) throw Err(BOBE_ERR_ARG, "B must be >= 0");
+  if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
+  g->use();
   const int d = g->d;
-  if (grad) {
-    const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
-    const int ntiles = g->lauum(h, g->Linv2.d(), g->alpha2.d(), g->XsT2.d(), nullptr, dcap);
-    hipLaunchKernelGGL(k_grad_reduce, dim3(d + 1), dim3(64), 0, g->stream, (const double*)g->gpart.d(), ntiles, dcap + 1, d,
-                       dcap, g->res.d() + 2);
+  const int width = std::max(1, std::min<int>(tuning().mll_slots, BOBE_MAX_MLL_SLOTS));
+  int worst = BOBE_OK;
+  for (int64_t b0 = 0; b0 < B; b0 += width) {
+    const int nbat = (int)std::min<int64_t>(width, B - b0);
+    static const bool trace = std::getenv("BOBE_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    if (nbat == 1) {   // a lone evaluation owns the whole chip on the handle's stream
+      Hyper h = g->hyp;
+      for (int j = 0; j < d; ++j) h.ls[j] = ls[b0 * d + j];
+      h.kvar = kvar[b0];
+      g->mll_enqueue(h, grad != nullptr);
+    } else {
+      g->ensure_slots(nbat);
+      const std::vector<hipStream_t>& sts = g->streams_for(nbat);
+      // the batch streams start after everything already queued on the handle's stream (data uploads)
+      HIPCHK(hipEventRecord(g->ev_batch, g->stream));
+      for (int i = 0; i < nbat; ++i) {
+        Hyper h = g->hyp;
+        for (int j = 0; j < d; ++j) h.ls[j] = ls[(b0 + i) * d + j];
+        h.kvar = kvar[b0 + i];
+        bobe_gp::Slot& sl = *g->slots[i];
+        sl.stream = sts[i];
+        HIPCHK(hipStreamWaitEvent(sl.stream, g->ev_batch, 0));
+        g->swap_slot(sl);
+        g->eff_cus = (tuning().slot_mask && nbat <= 8) ? std::max(1, g->num_cus / nbat) : g->num_cus;
+        try {
+          g->mll_enqueue(h, grad != nullptr);
+        } catch (...) {
+          g->eff_cus = g->num_cus;
+          g->swap_slot(sl);
+          throw;
+        }
+        g->eff_cus = g->num_cus;
+        g->swap_slot(sl);
+      }
+    }
+    const auto t_enq = std::chrono::steady_clock::now();
+    for (int i = 0; i < nbat; ++i) {
+      double* gi = grad ? grad + (b0 + i) * (d + 1) : nullptr;
+      int st;
+      if (nbat == 1) {
+        st = g->mll_collect(mll + b0, gi);
+      } else {
+        bobe_gp::Slot& sl = *g->slots[i];
+        g->swap_slot(sl);
+        try {
+          st = g->mll_collect(mll + b0 + i, gi);
+        } catch (...) {
+          g->swap_slot(sl);
+          throw;
+        }
+        g->swap_slot(sl);
+      }
+      if (status) status[b0 + i] = st;
+      if (st != BOBE_OK) worst = st;
+    }
+    if (trace) {
+      const auto t_end = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[bobe] mll_batch B=%d: enqueue %.3f ms, total %.3f ms\n", nbat,
+                   std::chrono::duration<double, std::milli>(t_enq - t_start).count(),
+                   std::chrono::duration<double, std::milli>(t_end - t_start).count());
+    }
   }
-  LAUNCH_CHECK();
-  HIPCHK(hipMemcpyAsync(g->h_res, g->res.p, (size_t)(3 + d) * sizeof(double), hipMemcpyDeviceToHost, g->stream));
-  const int inf = g->read_info();
-  if (inf < 0) throw Err(BOBE_ERR_HIP, "fused panel launch timed out waiting for the factorisation (set BOBE_FUSED_PANEL=0)");
-  if (inf != 0x7f7f7f7f) {
-    *mll = std::nan("");
-    if (grad)
-      for (int j = 0; j <= d; ++j) grad[j] = std::nan("");
-    g_err = "kernel matrix not positive definite at column " + std::to_string(inf - 1);
-    return BOBE_NOT_PD;
+  return worst;
+  API_END
+}
+
+int bobe_gp_mll_submit(bobe_gp_t* g, int slot, const double* ls, double kvar, int want_grad) {
+  API_BEGIN
+  if (!g || !ls) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (slot < 0 || slot >= BOBE_MAX_MLL_SLOTS) throw Err(BOBE_ERR_ARG, "slot out of range");
+  if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
+  std::lock_guard<std::mutex> lock(g->submit_mutex);
+  g->use();
+  g->ensure_slots(slot + 1);
+  const std::vector<hipStream_t>& sts = g->streams_for(BOBE_MAX_MLL_SLOTS);
+  Hyper h = g->hyp;
+  for (int j = 0; j < g->d; ++j) h.ls[j] = ls[j];
+  h.kvar = kvar;
+  bobe_gp::Slot& sl = *g->slots[slot];
+  sl.stream = sts[slot];
+  // ordered after whatever is queued on the handle's stream (data uploads); the event is private to the slot
+  if (!sl.ev) HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(sl.ev, g->stream));
+  HIPCHK(hipStreamWaitEvent(sl.stream, sl.ev, 0));
+  g->swap_slot(sl);
+  try {
+    g->mll_enqueue(h, want_grad != 0);
+  } catch (...) {
+    g->swap_slot(sl);
+    throw;
   }
-  *mll = -0.5 * g->h_res[0] - g->h_res[1] - 0.5 * (double)g->N * std::log(2.0 * M_PI);
-  if (grad)
-    for (int j = 0; j <= d; ++j) grad[j] = g->h_res[2 + j];
+  g->swap_slot(sl);
+  sl.busy = true;
+  sl.want_grad = want_grad != 0;
   return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_mll_wait(bobe_gp_t* g, int slot, double* mll, double* grad) {
+  API_BEGIN
+  if (!g || !mll) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (slot < 0 || slot >= (int)g->slots.size() || !g->slots[slot]->busy)
+    throw Err(BOBE_ERR_STATE, "no evaluation was submitted to this slot");
+  HIPCHK(hipSetDevice(g->device));
+  bobe_gp::Slot& sl = *g->slots[slot];
+  sl.busy = false;
+  return g->slot_collect(sl, mll, sl.want_grad ? grad : nullptr);
   API_END
 }
 

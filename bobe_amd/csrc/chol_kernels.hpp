@@ -518,30 +518,34 @@ __global__ __launch_bounds__(256) void k_panel_fused(double* __restrict__ A, int
     trsm_stream_body(A, lda, Linv, ldl, k, (int)blockIdx.x - 1, flags + k, info);
 }
 
-// ---- trailing update: A[i][j] -= L[i][k] L[j][k]^T over lower T x T tiles of the trailing matrix -------
-// The tiles start at 128-block `first`.  colmode 0: every lower tile (grid = n(n+1)/2, n = (Np-first*128)/T).
-// colmode 1: only the tiles of 128-block column `first` (the next panel; T = 128 or 64 only).
-// The lookahead Cholesky issues colmode 1 for block k+1 on the panel stream and colmode 0 from block k+2
-// on the update stream.
+// ---- trailing update: A[i][j] -= sum_{k0 <= k < k1} L[i][k] L[j][k]^T over lower T x T tiles ---------------
+// The tiles start at 128-block `first`; n = trailing size in T-tiles.  colmode 0: every lower tile (grid =
+// n(n+1)/2).  colmode 1: only the tiles of 128-block column `first` (the next block column of a super-panel):
+// tile columns b < 128/T, rows b <= a < n, grid = S n - S(S-1)/2 with S = 128/T.
 template <int T, int BK>
-__global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k, int first,
+__global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k0, int k1, int first,
                                                     int colmode, int n) {
   extern __shared__ double smem[];
   int a, b;
   if (colmode == 0) {
     tri_decode(blockIdx.x, a, b);
-  } else if (T == 128 || (int)blockIdx.x < n) {
-    a = blockIdx.x;
-    b = 0;
   } else {
-    a = blockIdx.x - n + 1;
-    b = 1;
+    constexpr int S = TILE / T;
+    int idx = blockIdx.x;
+    b = 0;
+#pragma unroll
+    for (int c = 0; c < S - 1; ++c)
+      if (b == c && idx >= n - c) {
+        idx -= n - c;
+        b = c + 1;
+      }
+    a = b + idx;
   }
   const int64_t base = (int64_t)first * TILE;
   v4d acc[T / 32][T / 32];
   load_tile<T, T>(acc, A, lda, base + (int64_t)a * T, base + (int64_t)b * T);   // acc = C, then acc -= A B^T
   gemm_tile<KC, KC, T, T, BK, true>(acc, A, lda, base + (int64_t)a * T, A, lda, base + (int64_t)b * T,
-                                    (int64_t)k * TILE, (int64_t)(k + 1) * TILE, smem);
+                                    (int64_t)k0 * TILE, (int64_t)k1 * TILE, smem);
   store_tile<T, T>(acc, A, lda, base + (int64_t)a * T, base + (int64_t)b * T, 1.0, 0.0);
 }
 

@@ -57,6 +57,8 @@ class GP:
             log.warning("only the scipy optimiser is implemented (optax variants are out of scope); using scipy")
         self.mll_optimize = optimize_scipy
         self.optimizer_options = optimizer_options
+        self.concurrent_restarts = True        # fit(): the restarts run concurrently, one evaluation slot each
+        self.restart_slots = 4                 # evaluations in flight at once (more than 4 oversubscribes the queues)
 
         self.lengthscale_bounds = lengthscale_bounds
         self.kernel_variance_bounds = kernel_variance_bounds
@@ -176,24 +178,57 @@ class GP:
         return ls, float(kvar), float(tausq)
 
     # ------------------------------------------------------------------ objective
-    def mll_data(self, lengthscales, kernel_variance, want_grad=True):
-        """Data term of the MLL (gp_mll, gp.py:170-178) and its gradient wrt (log ls, log kvar) on the GPU."""
+    def mll_data(self, lengthscales, kernel_variance, want_grad=True, slot=None):
+        """Data term of the MLL (gp_mll, gp.py:170-178) and its gradient wrt (log ls, log kvar) on the GPU.
+        ``slot`` (0..7): evaluate on that private stream / workspace (bobe_gp_mll_submit + _wait) so that several
+        host threads — the restarts of ``fit`` — can have evaluations in flight together; same bits either way."""
         ls = _lib.as_f64(lengthscales).reshape(-1)
         mll = C.c_double(0.0)
         grad = np.empty(self.ndim + 1) if want_grad else None
-        st = self._lib.bobe_gp_mll(self._h, _lib.ptr(ls), float(kernel_variance), C.byref(mll), _lib.ptr(grad))
-        _lib.check(st, "bobe_gp_mll")
+        if slot is None:
+            st = self._lib.bobe_gp_mll(self._h, _lib.ptr(ls), float(kernel_variance), C.byref(mll), _lib.ptr(grad))
+            _lib.check(st, "bobe_gp_mll")
+        else:
+            _lib.check(self._lib.bobe_gp_mll_submit(self._h, int(slot), _lib.ptr(ls), float(kernel_variance),
+                                                    int(want_grad)), "bobe_gp_mll_submit")
+            _lib.check(self._lib.bobe_gp_mll_wait(self._h, int(slot), C.byref(mll), _lib.ptr(grad)), "bobe_gp_mll_wait")
         return mll.value, grad
+
+    def mll_data_batch(self, lengthscales, kernel_variances, want_grad=True):
+        """``mll_data`` for B hyper-parameter vectors evaluated concurrently on the GPU (bobe_gp_mll_batch).
+        Vectors whose kernel matrix is not positive definite come back as NaN, like ``mll_data``."""
+        ls = _lib.as_f64(lengthscales).reshape(-1, self.ndim)
+        B = ls.shape[0]
+        kv = _lib.as_f64(kernel_variances).reshape(B)
+        mll = np.empty(B)
+        grad = np.empty((B, self.ndim + 1)) if want_grad else None
+        status = np.zeros(B, dtype=np.int32)
+        st = self._lib.bobe_gp_mll_batch(self._h, B, _lib.ptr(ls), _lib.ptr(kv), _lib.ptr(mll), _lib.ptr(grad),
+                                         C.c_void_p(status.ctypes.data))
+        _lib.check(st, "bobe_gp_mll_batch")
+        return mll, grad
 
     def neg_mll(self, log_params):
         """BOBE/gp.py:385-398."""
         return self.neg_mll_value_and_grad(log_params, want_grad=False)[0]
 
-    def neg_mll_value_and_grad(self, log_params, want_grad=True):
+    def neg_mll_value_and_grad(self, log_params, want_grad=True, slot=None):
         """(f, df/dtheta) with f = -(MLL + log prior), theta = log hp — the closure optim.py:306-309 builds."""
         log_params = np.asarray(log_params, dtype=np.float64)
         ls, kvar, tausq = self._parse_hyperparams(log_params)
-        mll, g_data = self.mll_data(ls, kvar, want_grad)
+        mll, g_data = self.mll_data(ls, kvar, want_grad, slot=slot)
+        return self._assemble_objective(log_params, ls, kvar, tausq, mll, g_data, want_grad)
+
+    def neg_mll_value_and_grad_batch(self, log_params_list, want_grad=True):
+        """``neg_mll_value_and_grad`` for several theta at once (the concurrently running restarts of ``fit``);
+        returns a list of (f, grad) pairs with exactly the values of the one-at-a-time call."""
+        thetas = [np.asarray(t, dtype=np.float64) for t in log_params_list]
+        parsed = [self._parse_hyperparams(t) for t in thetas]
+        mll, g_data = self.mll_data_batch(np.array([p[0] for p in parsed]), np.array([p[1] for p in parsed]), want_grad)
+        return [self._assemble_objective(t, p[0], p[1], p[2], float(mll[i]), None if g_data is None else g_data[i],
+                                         want_grad) for i, (t, p) in enumerate(zip(thetas, parsed))]
+
+    def _assemble_objective(self, log_params, ls, kvar, tausq, mll, g_data, want_grad):
         lp, g_ls, g_kvar, g_tau = self._prior_and_grad(ls, kvar, tausq)
         val = -(mll + lp)
         if not want_grad:
@@ -214,9 +249,13 @@ class GP:
             x0 = np.log(self.get_hyperparams())[None, :]
         x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
         optimizer_options = dict(self.optimizer_options)
+        # restarts are independent L-BFGS-B runs: each gets a host thread and an evaluation slot of the library
+        extra = {"slot_value_and_grad": lambda x, slot: self.neg_mll_value_and_grad(x, slot=slot),
+                 "n_slots": self.restart_slots} \
+            if (self.concurrent_restarts and x0.shape[0] > 1 and self.mll_optimize is optimize_scipy) else {}
         best_params_log, best_loss = self.mll_optimize(
             self.neg_mll_value_and_grad, num_params=self.num_hyperparams, bounds=self.hyperparam_bounds, x0=x0,
-            maxiter=maxiter, n_restarts=x0.shape[0], optimizer_options=optimizer_options)
+            maxiter=maxiter, n_restarts=x0.shape[0], optimizer_options=optimizer_options, **extra)
         return {"mll": -best_loss, "params": best_params_log}
 
     def update_hyperparams(self, hyperparams):

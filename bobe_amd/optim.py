@@ -5,7 +5,8 @@ a ``value_and_grad(x) -> (f, g)`` callable whose heavy part runs on the GPU thro
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import threading
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 from scipy.optimize import minimize
@@ -27,12 +28,130 @@ def _setup_bounds(bounds, num_params):
     return bounds
 
 
+class _LockStep:
+    """Runs R independent SciPy minimisations in R threads and serves their objective calls in rounds: when
+    every still-running minimisation has asked for a value, the pending points go to ``batch_fun`` in ONE call
+    (restart order), so the GPU evaluates them concurrently.  Each minimisation sees exactly the values it would
+    have seen alone; the rounds are deterministic, and ``batch_fun`` is only ever called from one thread at a time.
+    """
+
+    def __init__(self, batch_fun: Callable, n_workers: int):
+        self.batch_fun = batch_fun
+        self.cv = threading.Condition()
+        self.active = n_workers
+        self.pending = {}          # worker -> x
+        self.results = {}          # worker -> (f, g) or exception
+
+    def _flush_locked(self):
+        ids = sorted(self.pending)
+        xs = [self.pending[i] for i in ids]
+        self.pending = {}
+        try:
+            out = self.batch_fun(xs)
+            for i, r in zip(ids, out):
+                self.results[i] = r
+        except Exception as e:          # delivered to every waiting minimisation
+            for i in ids:
+                self.results[i] = e
+        self.cv.notify_all()
+
+    def call(self, wid: int, x):
+        with self.cv:
+            self.pending[wid] = np.array(x, dtype=np.float64)
+            if len(self.pending) == self.active:
+                self._flush_locked()
+            while wid not in self.results:
+                self.cv.wait()
+            r = self.results.pop(wid)
+        if isinstance(r, Exception):
+            raise r
+        return r
+
+    def done(self, wid: int):
+        with self.cv:
+            self.active -= 1
+            if self.active > 0 and len(self.pending) == self.active:
+                self._flush_locked()
+
+
+def _minimize_concurrently(batch_fun: Callable, starts: np.ndarray, has_grad: bool, **kw) -> List:
+    """``scipy.optimize.minimize`` from every row of ``starts``; returns the results (or the exception) per row."""
+    ls = _LockStep(batch_fun, len(starts))
+    out: List = [None] * len(starts)
+
+    def work(i):
+        try:
+            f = (lambda x: ls.call(i, x)) if has_grad else (lambda x: ls.call(i, x)[0])
+            out[i] = minimize(f, starts[i], jac=has_grad, **kw)
+        except Exception as e:
+            out[i] = e
+        finally:
+            ls.done(i)
+
+    threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(starts))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return out
+
+
+def _minimize_in_slots(slot_fun: Callable, starts: np.ndarray, has_grad: bool, n_slots: int, **kw) -> List:
+    """``scipy.optimize.minimize`` from every row of ``starts``, each in its own thread; restart i evaluates through
+    ``slot_fun(x, i % n_slots)`` (a slot carries one evaluation at a time, so restarts sharing one take turns).
+    Nothing synchronises the restarts: each advances as fast as its own evaluations return."""
+    locks = [threading.Lock() for _ in range(n_slots)]
+    out: List = [None] * len(starts)
+
+    def work(i):
+        slot = i % n_slots
+
+        def f(x):
+            with locks[slot]:
+                r = slot_fun(x, slot)
+            return r if has_grad else r[0]
+        try:
+            out[i] = minimize(f, starts[i], jac=has_grad, **kw)
+        except Exception as e:
+            out[i] = e
+
+    threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(starts))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return out
+
+
+def _evaluate_in_slots(slot_fun: Callable, xs, n_slots: int) -> List:
+    """slot_fun(x, slot) for every x, up to n_slots at a time (one thread per slot)."""
+    xs = list(xs)
+    out: List = [None] * len(xs)
+
+    def work(slot):
+        for i in range(slot, len(xs), n_slots):
+            out[i] = slot_fun(xs[i], slot)
+
+    threads = [threading.Thread(target=work, args=(s_,), daemon=True) for s_ in range(min(n_slots, len(xs)))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return out
+
+
 def optimize_scipy(value_and_grad: Callable, num_params: int = 1, bounds=None, x0=None,
                    optimizer_options: Optional[dict] = None, maxiter: int = 200, n_restarts: int = 4,
-                   verbose: bool = False) -> Tuple[np.ndarray, float]:
+                   verbose: bool = False, batch_value_and_grad: Optional[Callable] = None,
+                   slot_value_and_grad: Optional[Callable] = None, n_slots: int = 4) -> Tuple[np.ndarray, float]:
     """Same restart / screening / acceptance logic as BOBE/optim.py:292-359.
 
     ``value_and_grad`` may return ``g=None``; SciPy then falls back to finite differences.
+    ``batch_value_and_grad(list of x) -> list of (f, g)`` (optional) lets the restarts — independent L-BFGS-B
+    runs that the reference walks one after the other — advance in lock-step with their objective evaluations
+    batched on the GPU; every restart follows the same trajectory and the acceptance order is unchanged.
+    ``slot_value_and_grad(x, slot) -> (f, g)`` (optional, takes precedence) runs every restart in its own thread on
+    one of ``n_slots`` evaluation slots without any barrier between them; same trajectories, same acceptance order.
     """
     options = dict(optimizer_options if optimizer_options is not None else
                    {"method": "L-BFGS-B", "ftol": 1e-6, "gtol": 1e-6})      # optim.py:256
@@ -52,17 +171,42 @@ def optimize_scipy(value_and_grad: Callable, num_params: int = 1, bounds=None, x
     has_grad = probe[1] is not None
     fun = value_and_grad if has_grad else (lambda x: value_and_grad(x)[0])
 
+    slotted = slot_value_and_grad is not None and len(x0) > 1
+    concurrent = batch_value_and_grad is not None and len(x0) > 1 and not slotted
     best_f, best_x = np.inf, None
+    screen = None
+    if slotted:
+        try:
+            screen = [probe] + _evaluate_in_slots(slot_value_and_grad, x0[1:], n_slots)
+        except Exception as e:  # pragma: no cover
+            log.warning(f"  concurrent screening failed with {e}; evaluating the starts one by one")
+    if concurrent:
+        try:
+            screen = [probe] + list(batch_value_and_grad([x for x in x0[1:]]))
+        except Exception as e:  # pragma: no cover
+            log.warning(f"  batched screening failed with {e}; evaluating the starts one by one")
     for i, x_init in enumerate(x0):                                        # optim.py:325-333
         try:
-            val = probe[0] if i == 0 else value_and_grad(x_init)[0]
+            val = screen[i][0] if screen is not None else (probe[0] if i == 0 else value_and_grad(x_init)[0])
             if np.isfinite(val) and val < best_f:
                 best_f, best_x = float(val), np.array(x_init)
         except Exception as e:  # pragma: no cover
             log.warning(f"  Initial point {i + 1}/{n_restarts}: failed with {e}")
+    results = None
+    if slotted:
+        results = _minimize_in_slots(slot_value_and_grad, x0, has_grad, n_slots, method=method, bounds=scipy_bounds,
+                                     options=options)
+    elif concurrent:
+        results = _minimize_concurrently(batch_value_and_grad, x0, has_grad, method=method, bounds=scipy_bounds,
+                                         options=options)
     for i, x_init in enumerate(x0):                                        # optim.py:335-354
         try:
-            res = minimize(fun, x_init, method=method, jac=has_grad, bounds=scipy_bounds, options=options)
+            if results is not None:
+                res = results[i]
+                if isinstance(res, Exception):
+                    raise res
+            else:
+                res = minimize(fun, x_init, method=method, jac=has_grad, bounds=scipy_bounds, options=options)
         except Exception as e:
             if verbose:
                 log.warning(f"  Restart {i + 1}/{n_restarts}: failed with {e}")

@@ -73,6 +73,26 @@ int bobe_gp_factor(bobe_gp_t* gp);
  * left by bobe_gp_factor.  BOBE_NOT_PD -> *mll and grad are NaN. */
 int bobe_gp_mll(bobe_gp_t* gp, const double* lengthscales, double kernel_variance, double* mll, double* grad);
 
+/* bobe_gp_mll for B hyper-parameter vectors at once: lengthscales is B x d, kernel_variance has B entries,
+ * mll B, grad (may be NULL) B x (d+1), status (may be NULL) B per-vector codes (BOBE_OK / BOBE_NOT_PD).
+ * The restarts of optimize_scipy (optim.py:335-354) are independent L-BFGS-B runs which the reference walks
+ * one after the other; here up to BOBE_MAX_MLL_SLOTS of their evaluations run concurrently, each on a private
+ * HIP stream and workspace, through exactly the kernels of bobe_gp_mll (bit-identical results).  Returns
+ * BOBE_NOT_PD when any vector was not positive definite (its outputs are NaN), < 0 on usage / HIP errors. */
+#define BOBE_MAX_MLL_SLOTS 8
+int bobe_gp_mll_batch(bobe_gp_t* gp, int64_t B, const double* lengthscales, const double* kernel_variance,
+                      double* mll, double* grad, int* status);
+
+/* The same evaluation, split into a non-blocking submit to one of BOBE_MAX_MLL_SLOTS slots and a blocking wait,
+ * so that every restart of the fit can run in its own host thread and advance at its own pace (no round
+ * barrier): the restarts end up in different phases of the pipeline, the single-workgroup factorisation steps of
+ * one overlapping the matrix-core phases of the others.  Results are those of bobe_gp_mll, bit for bit.
+ * Threading: submit calls are serialised inside the library; bobe_gp_mll_wait may run concurrently with submits
+ * and waits on OTHER slots; a slot holds one evaluation at a time; no other entry point of the same handle may
+ * run while evaluations are in flight.  wait returns BOBE_OK / BOBE_NOT_PD (NaN outputs) / < 0. */
+int bobe_gp_mll_submit(bobe_gp_t* gp, int slot, const double* lengthscales, double kernel_variance, int want_grad);
+int bobe_gp_mll_wait(bobe_gp_t* gp, int slot, double* mll, double* grad);
+
 /* GP.predict_mean_batched / predict_var_batched / predict_batched (gp.py:450-493) for C query points
  * Xq (C x d).  mean[c] = k_c^T alpha; var[c] = kvar + noise - |L^-1 k_c|^2 with
  *   nan_policy 0: clip(var, 1e-12) keeps NaN (predict_var_single, gp.py:465)

@@ -382,6 +382,13 @@ def test_headline_config_properties(lib):
     _, g_gpu = gp.mll_data(ls, kv)
     assert abs(mll_gpu - mll_cpu) <= 1e-10 * abs(mll_cpu)
     assert np.max(np.abs(g_gpu - g_cpu)) <= 1e-8 * np.max(np.abs(g_cpu))
+    # the concurrent evaluation of several theta (CU-partitioned streams, other tile sizes) returns the same bits
+    lsb, kvb = np.exp(th[-4:, :d]), np.exp(th[-4:, d])
+    mb, gb = gp.mll_data_batch(lsb, kvb)
+    for b in range(4):
+        m1, g1 = gp.mll_data(lsb[b], kvb[b])
+        assert mb[b] == m1 and np.array_equal(gb[b], g1)
+    assert mb[3] == mll_gpu
     e = 1e-4
     for j in (0, d):
         tp, tm = th[-1].copy(), th[-1].copy()
@@ -540,3 +547,86 @@ def test_ei_analytic_gradient_matches_finite_differences():
             f, g = vg(x0)
             fd = np.array([(vg(x0 + h)[0] - vg(x0 - h)[0]) / 2e-6 for h in (np.array([1e-6, 0]), np.array([0, 1e-6]))])
             assert np.allclose(g, fd, rtol=1e-3, atol=1e-7 * max(1.0, abs(f)))
+
+
+@pytest.mark.parametrize("n,d,B", [(300, 4, 1), (300, 4, 3), (700, 6, 4), (129, 2, 11)])
+def test_mll_batch_is_bitwise_the_single_evaluation(n, d, B):
+    """bobe_gp_mll_batch = the same kernels per vector on private streams / workspaces: identical bits, any B
+    (B above the slot count runs in rounds), and the factored state is left alone."""
+    X, y = smooth_data(n, d, seed=11)
+    gp = GP(X, y, noise=1e-6, lengthscales=np.full(d, 0.5))
+    chol0 = gp.cholesky.copy()
+    rng = np.random.default_rng(B)
+    ls = np.exp(rng.uniform(np.log(0.2), np.log(1.5), size=(B, d)))
+    kv = np.exp(rng.uniform(-0.5, 0.5, size=B))
+    one = [gp.mll_data(ls[b], kv[b]) for b in range(B)]
+    mll, grad = gp.mll_data_batch(ls, kv)
+    for b in range(B):
+        assert mll[b] == one[b][0]
+        assert np.array_equal(grad[b], one[b][1])
+    mll2, none = gp.mll_data_batch(ls, kv, want_grad=False)
+    assert none is None and np.array_equal(mll2, mll)
+    assert np.array_equal(gp.cholesky, chol0)
+    og = O.OracleGP(X, y, noise=1e-6, lengthscales=np.full(d, 0.5))
+    ref = O.gp_mll(O.rbf_kernel(og.train_x, og.train_x, ls[0], kv[0], noise=1e-6, include_noise=True), og.train_y, n)
+    assert abs(mll[0] - ref) <= 1e-10 * abs(ref)
+
+
+def test_mll_batch_not_pd_member_does_not_poison_the_others():
+    X = np.array([[0.1, 0.2], [0.1, 0.2], [0.7, 0.3], [0.4, 0.9]])      # duplicated point
+    y = np.array([1.0, 2.0, 3.0, 0.5])
+    gp = GP(X, y, noise=1e-9, lengthscales=[0.5, 0.5])
+    # huge length scales make K numerically singular for the middle member only
+    ls = np.array([[0.5, 0.5], [1e9, 1e9], [0.3, 0.8]])
+    kv = np.ones(3)
+    mll, grad = gp.mll_data_batch(ls, kv)
+    a, b = gp.mll_data(ls[0], 1.0), gp.mll_data(ls[2], 1.0)
+    mid = gp.mll_data(ls[1], 1.0)
+    assert mll[0] == a[0] and mll[2] == b[0] and np.array_equal(grad[0], a[1]) and np.array_equal(grad[2], b[1])
+    assert (np.isnan(mll[1]) and np.all(np.isnan(grad[1]))) if np.isnan(mid[0]) else mll[1] == mid[0]
+
+
+def test_slot_evaluations_from_threads_are_bitwise_the_single_evaluation():
+    """bobe_gp_mll_submit / _wait from concurrent host threads, one slot each (what GP.fit does per restart)."""
+    import threading
+    X, y = smooth_data(900, 5, seed=4)
+    gp = GP(X, y, noise=1e-6, lengthscales=np.full(5, 0.5))
+    rng = np.random.default_rng(1)
+    ls = np.exp(rng.uniform(np.log(0.2), np.log(1.5), size=(4, 6, 5)))      # 4 threads x 6 evaluations
+    ref = [[gp.mll_data(ls[t, k], 1.0 + 0.1 * k) for k in range(6)] for t in range(4)]
+    got = [[None] * 6 for _ in range(4)]
+
+    def work(t):
+        for k in range(6):
+            got[t][k] = gp.mll_data(ls[t, k], 1.0 + 0.1 * k, slot=t)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for t in range(4):
+        for k in range(6):
+            assert got[t][k][0] == ref[t][k][0] and np.array_equal(got[t][k][1], ref[t][k][1])
+    v, g = gp.mll_data(ls[0, 0], 1.0, want_grad=False, slot=2)
+    assert g is None and v == ref[0][0][0]
+    from bobe_amd import _lib
+    with pytest.raises(_lib.BobeLibraryError):                              # wait without a submit
+        _lib.check(gp._lib.bobe_gp_mll_wait(gp._h, 3, C.byref(C.c_double()), None), "wait")
+
+
+def test_fit_with_concurrent_restarts_equals_sequential_restarts():
+    """GP.fit runs its restarts concurrently (a thread and an evaluation slot each); every restart sees the values
+    it would see alone, so the result is exactly the sequential one (optim.py:335-354 order of acceptance)."""
+    X, y = ref_data(80, 3)
+    gp = GP(X, y, noise=1e-6, lengthscale_bounds=[0.01, 10], kernel_variance_bounds=[1e-4, 1e4])
+    rng = np.random.default_rng(5)
+    x0 = O.restart_points(np.log(gp.get_hyperparams()), gp.hyperparam_bounds, 5, rng)
+    gp.concurrent_restarts = False
+    seq = gp.fit(x0=x0, maxiter=40)
+    gp.concurrent_restarts = True
+    con = gp.fit(x0=x0, maxiter=40)
+    assert con["mll"] == seq["mll"] and np.array_equal(con["params"], seq["params"])
+    from bobe_amd.optim import optimize_scipy                               # the lock-step (batched) driver too
+    bat = optimize_scipy(gp.neg_mll_value_and_grad, num_params=gp.num_hyperparams, bounds=gp.hyperparam_bounds, x0=x0,
+                         maxiter=40, n_restarts=5, optimizer_options={},
+                         batch_value_and_grad=gp.neg_mll_value_and_grad_batch)
+    assert -bat[1] == seq["mll"] and np.array_equal(bat[0], seq["params"])
