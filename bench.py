@@ -14,7 +14,7 @@ All inputs are resident in HBM before the timed region; outputs stay in HBM (onl
 scalars and the two argmins cross PCIe, as they do in the BO loop).
 
 Multi-GPU (one process per GPU, torch.distributed / RCCL): weak scaling.  Every rank holds the full
-factor and runs the 20 evaluations of its own restart (the reference shards restarts over ranks,
+factor and runs the 20 evaluations of its own restarts (the reference shards restarts over ranks,
 BOBE/pool.py:298-326), sweeps its own shard of the N_gpus x C candidate set, and the ranks exchange
 (min score, global index) with one all-gather; value = cycles completed by all ranks / wall time.
 
@@ -223,6 +223,9 @@ def main():
         # Cholesky GF/s: mean device time of the factorisation alone (HIP events on the handle's stream)
         potrf_ms = C.c_double()
         lib.bobe_debug_time_potrf(h, 3, C.byref(potrf_ms))
+        potrf_b_ms = C.c_double()
+        if R > 1:
+            _lib.check(lib.bobe_debug_time_potrf_batch(h, min(R, 8), 3, C.byref(potrf_b_ms)), "time_potrf_batch")
         Np = (N + 127) // 128 * 128
         chunk = args.chunk or 8192
         # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 per candidate, triangular) fused with
@@ -256,6 +259,10 @@ def main():
                        "parallelism": f"candidate-sharded x{world}"},
             "cholesky_gflops": (N ** 3 / 3.0) / (potrf_ms.value * 1e-3) / 1e9,
             "cholesky_ms": potrf_ms.value,
+            "cholesky_concurrent": ({"in_flight": min(R, 8), "ms_all": potrf_b_ms.value,
+                                     "gflops": min(R, 8) * (N ** 3 / 3.0) / (potrf_b_ms.value * 1e-3) / 1e9,
+                                     "frac_of_fp64_mfma_peak": min(R, 8) * (N ** 3 / 3.0) / (potrf_b_ms.value * 1e-3) / 1e12
+                                     / FP64_MFMA_PEAK_TFLOPS} if R > 1 else None),
             "fit_ms": fit_ms,
             "check": last,
             "roofline": roof,

@@ -140,7 +140,7 @@ struct Depth { int first, count, nblocks; };
 struct Tuning { int syrk32_below, trtri64_below, lauum64_below, superpanel, superpanel_batch, fused_panel, mll_slots, slot_mask; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 1, 1, 0, 4, 3};   // fused panel off: the hand-off costs exceed the overlap gain
+    Tuning v{512, 600, 1200, 1, 1, 0, 4, 2};   // fused panel off: the hand-off costs exceed the overlap gain
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -530,16 +530,17 @@ const std::vector<hipStream_t>& bobe_gp::streams_for(int w) {
   if ((int)wstreams.size() <= w) wstreams.resize(w + 1);
   std::vector<hipStream_t>& v = wstreams[w];
   if (!v.empty()) return v;
+  // slot_mask 2 (default): streams made through the CU-mask entry point with every CU enabled - each gets a
+  // hardware queue of its own, which plain streams (multiplexed on a few queues) do not: 34 vs 42 ms for the
+  // 20-evaluation fit.  1: a real partition into w contiguous CU sets (slower, kept for experiments).  0: plain.
   const int mode = tuning().slot_mask;
   const int words = (num_cus + 31) / 32;
   for (int i = 0; i < w; ++i) {
     hipStream_t st = nullptr;
-    if (mode != 0 && w > 1 && w <= 8 && num_cus >= 8) {
+    if (mode != 0 && num_cus >= w) {
       std::vector<uint32_t> mask(words, 0u);
       for (int c = 0; c < num_cus; ++c) {
-        // CU-mask bits are striped over the 8 XCDs (bit c -> XCD c % 8); a set made of whole XCDs (mode 3) keeps
-        // each evaluation's tiles behind one or two L2s, sets cutting through every XCD measured far slower
-        const bool mine = mode == 1 ? (c * w / num_cus == i) : mode == 2 ? (c % w == i) : ((c % 8) * w / 8 == i);
+        const bool mine = mode == 1 ? (c * w / num_cus == i) : true;
         if (mine) mask[c / 32] |= (1u << (c % 32));
       }
       if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) {
@@ -803,6 +804,7 @@ int bobe_gp_create(bobe_gp_t** out, int device, int kernel, int d) {
   g->hyp.noise = 1e-8;
   try {
     g->use();
+    g->slots.reserve(BOBE_MAX_MLL_SLOTS);      // bobe_gp_mll_wait reads it without the submit mutex: never reallocate
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     g->own_stream = true;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->h_res), 128 * sizeof(double), hipHostMallocDefault));
@@ -997,7 +999,7 @@ int bobe_gp_mll_batch(bobe_gp_t* g, int64_t B, const double* ls, const double* k
         sl.stream = sts[i];
         HIPCHK(hipStreamWaitEvent(sl.stream, g->ev_batch, 0));
         g->swap_slot(sl);
-        g->eff_cus = (tuning().slot_mask && nbat <= 8) ? std::max(1, g->num_cus / nbat) : g->num_cus;
+        g->eff_cus = tuning().slot_mask == 1 ? std::max(1, g->num_cus / nbat) : g->num_cus;
         try {
           g->mll_enqueue(h, grad != nullptr);
         } catch (...) {
@@ -1441,6 +1443,58 @@ int bobe_debug_time_potrf(bobe_gp_t* g, int reps, double* ms) {
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  *ms = total / reps;
+  return BOBE_OK;
+  API_END
+}
+
+// B factorisations in flight at once, one evaluation slot each (the state of the fit's concurrent restarts):
+// device time from the first to the last factorisation kernel, averaged over reps; *ms is for all B together
+int bobe_debug_time_potrf_batch(bobe_gp_t* g, int B, int reps, double* ms) {
+  API_BEGIN
+  if (!g || !ms || reps < 1 || B < 1 || B > BOBE_MAX_MLL_SLOTS) throw Err(BOBE_ERR_ARG, "bad argument");
+  if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
+  g->use();
+  g->ensure_slots(B);
+  const std::vector<hipStream_t>& sts = g->streams_for(BOBE_MAX_MLL_SLOTS);
+  hipEvent_t e0, e1;
+  std::vector<hipEvent_t> done(B);
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (auto& e : done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  double total = 0.0;
+  for (int r = 0; r < reps; ++r) {
+    for (int i = 0; i < B; ++i) {      // K(X,X) of every slot, on the handle's stream
+      bobe_gp::Slot& sl = *g->slots[i];
+      g->scale(g->X.d(), g->N, g->Np, g->hyp, sl.XsT2.d(), g->Np);
+      g->assemble_kxx(g->hyp, sl.XsT2.d(), sl.A2.d());
+      HIPCHK(hipMemsetAsync(sl.info.p, 0x7f, sizeof(int), g->stream));
+    }
+    HIPCHK(hipEventRecord(e0, g->stream));
+    for (int i = 0; i < B; ++i) {
+      bobe_gp::Slot& sl = *g->slots[i];
+      sl.stream = sts[i];
+      HIPCHK(hipStreamWaitEvent(sl.stream, e0, 0));
+      g->swap_slot(sl);
+      try {
+        g->potrf(g->A2.d(), g->Linv2.d());
+      } catch (...) {
+        g->swap_slot(sl);
+        throw;
+      }
+      g->swap_slot(sl);
+      HIPCHK(hipEventRecord(done[i], sl.stream));
+      HIPCHK(hipStreamWaitEvent(g->stream, done[i], 0));
+    }
+    HIPCHK(hipEventRecord(e1, g->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    total += t;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (auto& e : done) (void)hipEventDestroy(e);
   *ms = total / reps;
   return BOBE_OK;
   API_END
