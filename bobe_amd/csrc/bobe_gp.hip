@@ -122,10 +122,6 @@ void configure_kernels_once() {
   allow_big_lds(k_lauum_grad<1, 8, 128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<1, 16, 128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<1, 32, 128>, GEMM_SMEM_BYTES);
-  allow_big_lds(k_kernel_matrix<0, true>, 2 * MAX_D * TILE * 8);
-  allow_big_lds(k_kernel_matrix<0, false>, 2 * MAX_D * TILE * 8);
-  allow_big_lds(k_kernel_matrix<1, true>, 2 * MAX_D * TILE * 8);
-  allow_big_lds(k_kernel_matrix<1, false>, 2 * MAX_D * TILE * 8);
   allow_big_lds(k_debug_gemm<0, 0>, GEMM_SMEM_BYTES);
   allow_big_lds(k_debug_gemm<0, 1>, GEMM_SMEM_BYTES);
   allow_big_lds(k_debug_gemm<1, 0>, GEMM_SMEM_BYTES);
@@ -334,28 +330,43 @@ void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, d
   LAUNCH_CHECK();
 }
 
+#define KM_LAUNCH(KE, SQ, DC, grid, ...)                                                                 \
+  do {                                                                                                   \
+    if (h.d == DC)                                                                                       \
+      hipLaunchKernelGGL((k_kernel_matrix<KE, SQ, DC, true>), grid, dim3(256), 0, stream, __VA_ARGS__);  \
+    else                                                                                                 \
+      hipLaunchKernelGGL((k_kernel_matrix<KE, SQ, DC, false>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+  } while (0)
+#define KM_DISPATCH(SQ, grid, ...)                                                                    \
+  do {                                                                                                \
+    const int dc_ = h.d <= 8 ? 8 : (h.d <= 16 ? 16 : 32);                                             \
+    if (h.kern == 0) {                                                                                \
+      if (dc_ == 8) KM_LAUNCH(0, SQ, 8, grid, __VA_ARGS__);                                           \
+      else if (dc_ == 16) KM_LAUNCH(0, SQ, 16, grid, __VA_ARGS__);                                    \
+      else KM_LAUNCH(0, SQ, 32, grid, __VA_ARGS__);                                                   \
+    } else {                                                                                          \
+      if (dc_ == 8) KM_LAUNCH(1, SQ, 8, grid, __VA_ARGS__);                                           \
+      else if (dc_ == 16) KM_LAUNCH(1, SQ, 16, grid, __VA_ARGS__);                                    \
+      else KM_LAUNCH(1, SQ, 32, grid, __VA_ARGS__);                                                   \
+    }                                                                                                 \
+  } while (0)
+
 void bobe_gp::kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT,
                                   int64_t ldb, int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo) {
   const dim3 grid((unsigned)(nbpad / TILE), (unsigned)(napad / TILE));
-  const size_t sm = (size_t)2 * h.d * TILE * sizeof(double);
-  if (h.kern == 0)
-    hipLaunchKernelGGL((k_kernel_matrix<0, false>), grid, dim3(256), sm, stream, AT, lda, na, BT, ldb, nbv, h, out, ldo);
-  else
-    hipLaunchKernelGGL((k_kernel_matrix<1, false>), grid, dim3(256), sm, stream, AT, lda, na, BT, ldb, nbv, h, out, ldo);
+  KM_DISPATCH(false, grid, AT, lda, na, BT, ldb, nbv, h, out, ldo);
   LAUNCH_CHECK();
 }
 
 void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a) {
   const dim3 grid((unsigned)(nb * (nb + 1) / 2));
-  const size_t sm = (size_t)2 * h.d * TILE * sizeof(double);
   prof_begin(BOBE_PROF_KXX);
-  if (h.kern == 0)
-    hipLaunchKernelGGL((k_kernel_matrix<0, true>), grid, dim3(256), sm, stream, xst, Np, N, xst, Np, N, h, a, Np);
-  else
-    hipLaunchKernelGGL((k_kernel_matrix<1, true>), grid, dim3(256), sm, stream, xst, Np, N, xst, Np, N, h, a, Np);
+  KM_DISPATCH(true, grid, xst, Np, N, xst, Np, N, h, a, Np);
   prof_end(BOBE_PROF_KXX);
   LAUNCH_CHECK();
 }
+#undef KM_DISPATCH
+#undef KM_LAUNCH
 
 // Trailing update with the panels of 128-blocks [k0, k1): colmode 0 = every lower tile from 128-block `first`
 // on, colmode 1 = only 128-block column `first` (rows from `first` down).  A tile's time is set by its MFMAs

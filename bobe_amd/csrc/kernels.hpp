@@ -74,13 +74,15 @@ __global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t
 // out[a*ldo + b] = k(A_a, B_b) for a < na, b < nb; padding is 0, or identity when SQUARE.
 // SQUARE: blockIdx.x enumerates lower tiles (ti >= tj) and noise is added on the diagonal.
 // else  : blockIdx.x = tile column, blockIdx.y = tile row.
-template <int KERN, bool SQUARE>
+// A thread owns one column b of the 128x128 tile (its d scaled coordinates stay in registers) and walks 64
+// rows; a wave's lanes share the row, so the row's coordinates are wave-uniform and come through the scalar
+// cache.  No LDS: the kernel is bound by the exp / pairwise-distance arithmetic and the coalesced 8-byte stores
+// (512 B per wave per row).
+// FULL: d == DCAP exactly (no per-dimension predication at all).
+template <int KERN, bool SQUARE, int DCAP, bool FULL>
 __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ AT, int64_t lda, int64_t na,
                                                        const double* __restrict__ BT, int64_t ldb, int64_t nb,
                                                        Hyper h, double* __restrict__ out, int64_t ldo) {
-  extern __shared__ double kmsm[];
-  double* xa = kmsm;                 // [d][128]
-  double* xb = kmsm + h.d * TILE;    // [d][128]
   int ti, tj;
   if (SQUARE) {
     tri_decode(blockIdx.x, ti, tj);
@@ -89,20 +91,24 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
     tj = blockIdx.x;
   }
   const int t = threadIdx.x;
-  for (int e = t; e < h.d * TILE; e += 256) {
-    const int j = e >> 7, c = e & 127;
-    xa[j * TILE + c] = AT[j * lda + (int64_t)ti * TILE + c];
-    xb[j * TILE + c] = BT[j * ldb + (int64_t)tj * TILE + c];
-  }
-  __syncthreads();
   const int b = t & 127;
   const int64_t gb = (int64_t)tj * TILE + b;
-  for (int a = t >> 7; a < TILE; a += 2) {
+  double xb[DCAP];
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) xb[j] = (FULL || j < h.d) ? BT[j * ldb + gb] : 0.0;
+  const int a0 = __builtin_amdgcn_readfirstlane(t >> 7);   // wave-uniform (a wave spans 64 consecutive columns)
+  const double* arow = AT + (int64_t)ti * TILE;
+#pragma unroll 4
+  for (int a = a0; a < TILE; a += 2) {
     const int64_t ga = (int64_t)ti * TILE + a;
     double r2 = 0.0;
-    for (int j = 0; j < h.d; ++j) {
-      const double df = xa[j * TILE + a] - xb[j * TILE + b];
-      r2 += df * df;
+    double xa[DCAP];   // unconditional (clamped) loads: all in flight at once, no branch per dimension
+#pragma unroll
+    for (int j = 0; j < DCAP; ++j) xa[j] = arow[(int64_t)((FULL || j < h.d) ? j : 0) * lda + a];
+#pragma unroll
+    for (int j = 0; j < DCAP; ++j) {
+      const double df = (FULL || j < h.d) ? xa[j] - xb[j] : 0.0;
+      r2 = __builtin_fma(df, df, r2);
     }
     double v;
     if (ga < na && gb < nb) {
