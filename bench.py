@@ -219,6 +219,38 @@ def main():
             lib.bobe_gp_sync(h)
             fit_ms["concurrency_%d" % r_] = (time.perf_counter() - t1) * 1e3
             R = R_keep
+    sub_ms, lbfgs = {}, None
+    if rank == 0:               # the other two sub-times of a cycle and a real L-BFGS-B fit, untimed region
+        lib.bobe_gp_sync(h)
+        t1 = time.perf_counter()
+        _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")
+        _lib.check(lib.bobe_gp_factor(h), "factor")
+        lib.bobe_gp_sync(h)
+        t2 = time.perf_counter()
+        _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
+                                         _lib.ptr(out_wipstd), _lib.ptr(out_mean), _lib.ptr(out_var),
+                                         C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
+        lib.bobe_gp_sync(h)
+        t3 = time.perf_counter()
+        sub_ms = {"fit": fit_ms.get("concurrency_%d" % R), "refactor": (t2 - t1) * 1e3, "sweep": (t3 - t2) * 1e3}
+        if args.config != "tiny":
+            # GP.fit as the BO loop calls it for N >= 750 (bo.py:651-653): 4 restarts (pool.py:277-286 recipe), maxiter 200
+            from bobe_amd.bo import gp_fit
+            calls = [0]
+            orig = gp.mll_data
+
+            def counted(*a, **k):
+                calls[0] += 1
+                return orig(*a, **k)
+            gp.mll_data = counted
+            t4 = time.perf_counter()
+            r_fit = gp_fit(gp, maxiters=200, n_restarts=4, rng=np.random.default_rng(7))
+            t5 = time.perf_counter()
+            gp.mll_data = orig
+            _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")   # back to the cycle's state
+            _lib.check(lib.bobe_gp_factor(h), "factor")
+            lbfgs = {"restarts": 4, "maxiter": 200, "seconds": t5 - t4, "evaluations": calls[0],
+                     "ms_per_evaluation": (t5 - t4) * 1e3 / max(calls[0], 1), "mll": float(r_fit["mll"])}
     if rank == 0:
         # Cholesky GF/s: mean device time of the factorisation alone (HIP events on the handle's stream)
         potrf_ms = C.c_double()
@@ -264,6 +296,8 @@ def main():
                                      "frac_of_fp64_mfma_peak": min(R, 8) * (N ** 3 / 3.0) / (potrf_b_ms.value * 1e-3) / 1e12
                                      / FP64_MFMA_PEAK_TFLOPS} if R > 1 else None),
             "fit_ms": fit_ms,
+            "sub_ms": sub_ms,
+            "lbfgs_fit": lbfgs,
             "check": last,
             "roofline": roof,
         }
