@@ -133,10 +133,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, superpanel, superpanel_batch, fused_panel, mll_slots, slot_mask; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, superpanel, superpanel_batch, fused_panel, mll_slots, own_queues; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 1, 1, 0, 4, 2};   // fused panel off: the hand-off costs exceed the overlap gain
+    Tuning v{512, 600, 1200, 1, 1, 0, 4, 1};   // fused panel off: the hand-off costs exceed the overlap gain
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -144,7 +144,7 @@ const Tuning& tuning() {
     if (const char* e = std::getenv("BOBE_SUPERPANEL_BATCH")) v.superpanel_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BOBE_FUSED_PANEL")) v.fused_panel = std::atoi(e);
     if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
-    if (const char* e = std::getenv("BOBE_SLOT_MASK")) v.slot_mask = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_OWN_QUEUES")) v.own_queues = std::atoi(e);
     return v;
   }();
   return t;
@@ -166,7 +166,6 @@ struct bobe_gp {
 
   DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs, flags;
   int num_cus = 0;
-  int eff_cus = 0;   // CUs the current stream may use (num_cus, or its share inside a concurrent batch)
   // sweep / predict workspace
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
@@ -184,11 +183,8 @@ struct bobe_gp {
     bool busy = false, want_grad = false;
   };
   std::vector<Slot*> slots;
-  // streams of a batch of w concurrent evaluations: wstreams[w][i] is confined to the i-th of w equal CU sets
-  // (the single-workgroup / panel kernels of one evaluation would otherwise queue behind the full-chip
-  // trailing updates of the others)
-  std::vector<std::vector<hipStream_t>> wstreams;
-  const std::vector<hipStream_t>& streams_for(int w);
+  std::vector<hipStream_t> slot_streams;     // one per evaluation slot, created on first use
+  const std::vector<hipStream_t>& slot_stream_set();
   hipEvent_t ev_batch = nullptr;
   bool in_slot = false;
   void swap_slot(Slot& s) {
@@ -383,7 +379,7 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode) {
   // 64x64 tiles with BK = 16 (36 KB of LDS, four workgroups per CU) have the best saturated throughput of all
   // variants at every K (tools/ubench_syrk.hip); when they would leave most of the chip idle, a single-panel
   // update takes 32x32 tiles, which stage the whole K = 128 panel in one LDS buffer
-  if (kb == 1 && t64 < tu.syrk32_below * eff_cus / num_cus) {
+  if (kb == 1 && t64 < tu.syrk32_below) {
     hipLaunchKernelGGL((k_syrk_trail<32, SYRK32_BK>), dim3(t32), dim3(256), SYRK32_SMEM, stream, a, Np, k0, k1, first,
                        colmode, n32);
     return;
@@ -448,7 +444,7 @@ void bobe_gp::trtri(const double* a, double* linv) {
     const Depth& D = depths[dd];
     const TriProb* pr = static_cast<const TriProb*>(probs.p) + D.first;
     prof_begin(BOBE_PROF_TRTRI);
-    if (D.nblocks < tu.trtri64_below * eff_cus / num_cus) {
+    if (D.nblocks < tu.trtri64_below) {
       hipLaunchKernelGGL(k_trtri_T<64>, dim3(2 * D.nblocks), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
                          (const double*)linv, Np, Tmp.d(), Np, pr, D.count);
       hipLaunchKernelGGL(k_trtri_R<64>, dim3(2 * D.nblocks), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
@@ -467,8 +463,8 @@ void bobe_gp::trtri(const double* a, double* linv) {
 // K^-1 tiles fused with the gradient partial sums (optionally stores K^-1's lower tiles); returns #partials
 int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap) {
   const Tuning& tu = tuning();
-  // (not scaled by the CU share of a concurrent batch: the tile size fixes the order of the gradient's partial
-  // sums, and a batched evaluation must return the bits of a single one)
+  // (the tile size fixes the order of the gradient's partial sums: it depends on N only, so that an evaluation
+  // returns the same bits on every slot)
   const bool small = nb * (nb + 1) / 2 < tu.lauum64_below;
   const int nt = small ? 2 * nb : nb;
   const int ntiles = nt * (nt + 1) / 2;
@@ -537,23 +533,18 @@ void bobe_gp::ensure_slots(int n) {
   }
 }
 
-const std::vector<hipStream_t>& bobe_gp::streams_for(int w) {
-  if ((int)wstreams.size() <= w) wstreams.resize(w + 1);
-  std::vector<hipStream_t>& v = wstreams[w];
+// The slots' streams are made through the CU-mask entry point with every CU enabled: such a stream gets a
+// hardware queue of its own, which plain streams (multiplexed on a few queues) do not - 34 vs 42 ms for the
+// 20-evaluation fit at N = 4096.  (Real CU partitions were measured and dropped, DESIGN.md.)
+const std::vector<hipStream_t>& bobe_gp::slot_stream_set() {
+  std::vector<hipStream_t>& v = slot_streams;
   if (!v.empty()) return v;
-  // slot_mask 2 (default): streams made through the CU-mask entry point with every CU enabled - each gets a
-  // hardware queue of its own, which plain streams (multiplexed on a few queues) do not: 34 vs 42 ms for the
-  // 20-evaluation fit.  1: a real partition into w contiguous CU sets (slower, kept for experiments).  0: plain.
-  const int mode = tuning().slot_mask;
   const int words = (num_cus + 31) / 32;
-  for (int i = 0; i < w; ++i) {
+  for (int i = 0; i < BOBE_MAX_MLL_SLOTS; ++i) {
     hipStream_t st = nullptr;
-    if (mode != 0 && num_cus >= w) {
+    if (tuning().own_queues) {
       std::vector<uint32_t> mask(words, 0u);
-      for (int c = 0; c < num_cus; ++c) {
-        const bool mine = mode == 1 ? (c * w / num_cus == i) : true;
-        if (mine) mask[c / 32] |= (1u << (c % 32));
-      }
+      for (int c = 0; c < num_cus; ++c) mask[c / 32] |= (1u << (c % 32));
       if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) {
         (void)hipGetLastError();
         st = nullptr;
@@ -823,7 +814,6 @@ int bobe_gp_create(bobe_gp_t** out, int device, int kernel, int d) {
       hipDeviceProp_t prop;
       HIPCHK(hipGetDeviceProperties(&prop, device));
       g->num_cus = prop.multiProcessorCount;
-      g->eff_cus = g->num_cus;
     }
   } catch (...) {
     delete g;
@@ -848,11 +838,10 @@ void bobe_gp_destroy(bobe_gp_t* g) {
     (void)hipEventDestroy(pr.second);
   }
   if (g->h_res) (void)hipHostFree(g->h_res);
-  for (auto& v : g->wstreams)
-    for (hipStream_t st : v) {
-      (void)hipStreamSynchronize(st);
-      (void)hipStreamDestroy(st);
-    }
+  for (hipStream_t st : g->slot_streams) {
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+  }
   for (bobe_gp::Slot* sl : g->slots) {
     DBuf* sb[] = {&sl->XsT2, &sl->A2, &sl->Linv2, &sl->Tmp, &sl->alpha2, &sl->w2, &sl->part, &sl->gpart, &sl->res,
                   &sl->info, &sl->flags};
@@ -999,7 +988,7 @@ int bobe_gp_mll_batch(bobe_gp_t* g, int64_t B, const double* ls, const double* k
       g->mll_enqueue(h, grad != nullptr);
     } else {
       g->ensure_slots(nbat);
-      const std::vector<hipStream_t>& sts = g->streams_for(nbat);
+      const std::vector<hipStream_t>& sts = g->slot_stream_set();
       // the batch streams start after everything already queued on the handle's stream (data uploads)
       HIPCHK(hipEventRecord(g->ev_batch, g->stream));
       for (int i = 0; i < nbat; ++i) {
@@ -1010,16 +999,13 @@ int bobe_gp_mll_batch(bobe_gp_t* g, int64_t B, const double* ls, const double* k
         sl.stream = sts[i];
         HIPCHK(hipStreamWaitEvent(sl.stream, g->ev_batch, 0));
         g->swap_slot(sl);
-        g->eff_cus = tuning().slot_mask == 1 ? std::max(1, g->num_cus / nbat) : g->num_cus;
         try {
           g->mll_enqueue(h, grad != nullptr);
         } catch (...) {
-          g->eff_cus = g->num_cus;
-          g->swap_slot(sl);
+              g->swap_slot(sl);
           throw;
         }
-        g->eff_cus = g->num_cus;
-        g->swap_slot(sl);
+          g->swap_slot(sl);
       }
     }
     const auto t_enq = std::chrono::steady_clock::now();
@@ -1061,7 +1047,7 @@ int bobe_gp_mll_submit(bobe_gp_t* g, int slot, const double* ls, double kvar, in
   std::lock_guard<std::mutex> lock(g->submit_mutex);
   g->use();
   g->ensure_slots(slot + 1);
-  const std::vector<hipStream_t>& sts = g->streams_for(BOBE_MAX_MLL_SLOTS);
+  const std::vector<hipStream_t>& sts = g->slot_stream_set();
   Hyper h = g->hyp;
   for (int j = 0; j < g->d; ++j) h.ls[j] = ls[j];
   h.kvar = kvar;
@@ -1467,7 +1453,7 @@ int bobe_debug_time_potrf_batch(bobe_gp_t* g, int B, int reps, double* ms) {
   if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
   g->use();
   g->ensure_slots(B);
-  const std::vector<hipStream_t>& sts = g->streams_for(BOBE_MAX_MLL_SLOTS);
+  const std::vector<hipStream_t>& sts = g->slot_stream_set();
   hipEvent_t e0, e1;
   std::vector<hipEvent_t> done(B);
   HIPCHK(hipEventCreate(&e0));
