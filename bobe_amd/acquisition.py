@@ -146,14 +146,28 @@ class WeightedIntegratedPosteriorBase(AcquisitionFunction):
         idx = r["argmin_v"] if self._key == "wipv" else r["argmin_s"]
         return r[self._key], idx
 
+    def sweep_best(self, gp, candidates, mc_points, group=None):
+        """(best score, index of the best candidate).  With an initialised ``torch.distributed`` group of G > 1
+        ranks every rank scores its contiguous shard of the candidates on its own GPU (same factor everywhere) and
+        one all-gather of (min score, global index) picks the winner, ties to the lowest index like
+        ``jnp.argmin`` (acquisition.py:397)."""
+        from .dist_sweep import dist_info, sharded_wip_sweep
+        world, _, coll_dev = dist_info(group, gp.device)
+        if world > 1 and candidates.shape[0] >= world:
+            _, gmin, gidx = sharded_wip_sweep(lambda c: self.sweep(gp, c, mc_points), candidates, group=group,
+                                              device=coll_dev)
+            return float(gmin), int(gidx)
+        vals, idx = self.sweep(gp, candidates, mc_points)
+        return float(vals[idx]), int(idx)
+
     def get_next_point(self, gp, acq_kwargs=None, maxiter: int = 100, n_restarts: int = 1, verbose: bool = True,
                        early_stop_patience: int = 25, rng=None):
         acq_kwargs = acq_kwargs if acq_kwargs is not None else {}
         mc_samples = acq_kwargs.get("mc_samples")
         mc_points_size = acq_kwargs.get("mc_points_size", 128)
         mc_points = get_mc_points(mc_samples, mc_points_size=mc_points_size, rng=rng)
-        vals, idx = self.sweep(gp, mc_points, mc_points)                      # candidates == integration points
-        best_x, best_val = np.array(mc_points[idx]), float(vals[idx])
+        best_val, idx = self.sweep_best(gp, mc_points, mc_points)            # candidates == integration points
+        best_x = np.array(mc_points[idx])
         if gp.train_x.shape[0] > 500:                                          # acquisition.py:400-401
             return best_x, best_val
 

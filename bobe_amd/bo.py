@@ -5,7 +5,8 @@ Mirrors the parts of ``BOBE/bo.py`` that *call* the hot path: Sobol initialisati
 WIPV / WIPStd / EI iteration (bo.py:1174-1224, 1226-1390: mc points -> get_next_batch -> evaluate ->
 update_gp) and the refit policy of ``update_gp`` (bo.py:620-668, strict ``<`` size classes included).
 
-Not reproduced: MPI pool, classifier GP, NUTS.  The logZ convergence test (bo.py:886-891)
+Not reproduced: the MPI pool itself (its restart sharding is, over torch.distributed: ``gp_fit``),
+NUTS.  The logZ convergence test (bo.py:886-891)
 runs on ``bobe_amd.samplers.nested_sampling`` (batched on the GPU GP) instead of dynesty; the loop also stops
 on ``max_evals``, ``max_gp_size`` or an acquisition-value threshold.  Integration points come from the
 reference's ``'uniform'`` (scrambled Sobol, acquisition.py:476-479) or ``'NS'`` (acquisition.py:473-475) method.
@@ -19,6 +20,7 @@ import numpy as np
 from scipy.stats import qmc
 
 from .acquisition import EI, LogEI, WIPStd, WIPV, get_mc_samples
+from .dist_sweep import dist_info, merge_best_fit, shard_bounds
 from .gp import GP
 from .utils import get_logger, scale_from_unit, scale_to_unit
 
@@ -27,9 +29,15 @@ log = get_logger("bo")
 _ACQ = {"wipv": WIPV, "wipstd": WIPStd, "ei": EI, "logei": LogEI}
 
 
-def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.random.Generator] = None) -> dict:
-    """Serial branch of ``MPI_Pool.gp_fit`` (pool.py:268-293): x0 row 0 = log(current hp), further rows uniform
-    in the log-bounds; fit; adopt the best hyper-parameters (refactors on the GPU)."""
+def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.random.Generator] = None,
+           group=None) -> dict:
+    """``MPI_Pool.gp_fit`` (pool.py:268-328): x0 row 0 = log(current hp), further rows uniform in the log-bounds;
+    fit; adopt the best hyper-parameters (refactors on the GPU).
+
+    With an initialised ``torch.distributed`` group of G > 1 ranks (one process per GPU, every rank running the
+    same loop with the same seed) the restarts are split over the ranks the way the reference's MPI pool splits
+    them (``np.array_split``, pool.py:298-326): each rank runs its chunk — concurrently, on the evaluation slots of
+    its own GPU — then one all-gather of (mll, theta) and max-by-mll; every rank adopts the same theta."""
     rng = np.random.default_rng() if rng is None else rng
     n_params = gp.hyperparam_bounds.shape[1]
     init = np.log(gp.get_hyperparams())
@@ -38,7 +46,14 @@ def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.r
                                           size=(n_restarts - 1, n_params))])
     else:
         x0 = np.atleast_2d(init)
-    res = gp.fit(x0=x0, maxiter=maxiters)
+    world, rank, coll_dev = dist_info(group, gp.device)
+    if world > 1 and x0.shape[0] > 1:
+        lo, hi = shard_bounds(x0.shape[0], world, rank)
+        res = gp.fit(x0=x0[lo:hi], maxiter=maxiters) if hi > lo else {"mll": -np.inf, "params": init}
+        mll, params = merge_best_fit(res["mll"], res["params"], group=group, device=coll_dev)
+        res = {"mll": mll, "params": params}
+    else:
+        res = gp.fit(x0=x0, maxiter=maxiters)
     gp.update_hyperparams(res["params"])
     return res
 

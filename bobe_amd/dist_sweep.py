@@ -15,6 +15,23 @@ from typing import Callable, Optional, Tuple
 import numpy as np
 
 
+def dist_info(group=None, gpu_index: Optional[int] = None):
+    """(world size, rank, device for collective payloads) of the initialised process group, (1, 0, None) without
+    one.  RCCL ("nccl") needs the payload on this rank's GPU; gloo takes host tensors."""
+    try:
+        import torch
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover
+        return 1, 0, None
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0, None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = None
+    if world > 1 and str(dist.get_backend(group)).lower() == "nccl":
+        dev = torch.device("cuda", gpu_index if gpu_index is not None else torch.cuda.current_device())
+    return world, rank, dev
+
+
 def shard_bounds(n_candidates: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous shard of rank ``rank`` — np.array_split boundaries (BOBE/pool.py:302)."""
     base, extra = divmod(n_candidates, world)

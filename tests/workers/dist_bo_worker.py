@@ -1,0 +1,34 @@
+"""One rank of the 2-rank BO run of tests/test_gpu_dist.py (launched with torch.distributed.run, gloo backend,
+both ranks on the box's one GPU).  Rank 0 writes the trajectory as JSON to argv[1]."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from bobe_amd.bo import BOBE  # noqa: E402
+
+
+def banana(x):
+    return -0.5 * (x[0] ** 2 / 4.0 + (x[1] - 0.25 * x[0] ** 2) ** 2 * 4.0)
+
+
+def run_case():
+    bounds = np.array([[-4.0, 4.0], [-2.0, 6.0]]).T
+    bobe = BOBE(banana, ["x", "y"], bounds, n_sobol_init=12, seed=11)
+    res = bobe.run(acq="wipv", max_evals=22, mc_points_size=96, num_mc_samples=512, fit_n_points=2)
+    gp = res["gp"]
+    return {"train_x": gp.train_x.tolist(), "lengthscales": np.asarray(gp.lengthscales).tolist(),
+            "kernel_variance": float(gp.kernel_variance), "best_val": res["best_val"], "n": int(gp.npoints)}
+
+
+if __name__ == "__main__":
+    dist.init_process_group("gloo")
+    out = run_case()
+    if dist.get_rank() == 0:
+        with open(sys.argv[1], "w") as f:
+            json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
