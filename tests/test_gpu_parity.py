@@ -630,3 +630,73 @@ def test_fit_with_concurrent_restarts_equals_sequential_restarts():
                          maxiter=40, n_restarts=5, optimizer_options={},
                          batch_value_and_grad=gp.neg_mll_value_and_grad_batch)
     assert -bat[1] == seq["mll"] and np.array_equal(bat[0], seq["params"])
+
+
+def test_midsize_ragged_factor_inverse_and_gradient(lib):
+    """N = 2500 (20 blocks, not a power of two, last block ragged): exercises the 64x64/BK16 trailing update at a
+    size where it runs several rounds, the odd splits of the recursive inverse and the padded last block."""
+    from bobe_amd import _lib
+    n, d = 2500, 5
+    X, y = smooth_data(n, d, seed=21)
+    ls, kv = np.array([0.5, 0.6, 0.7, 0.55, 0.65]), 1.3
+    gp = GP(X, y, noise=1e-5, lengthscales=ls, kernel_variance=kv)
+    assert not gp.not_pd
+    K = O.rbf_kernel(X, X, ls, kv, 1e-5, include_noise=True)
+    L = gp.cholesky
+    assert np.all(np.triu(L, 1) == 0)
+    assert np.max(np.abs(L @ L.T - K)) <= 1e-12
+    Lo = O.chol_nan(K)
+    assert np.max(np.abs(L - Lo)) <= 1e-9
+    Li = np.empty((n, n))
+    assert lib.bobe_debug_linv(gp._h, _lib.ptr(Li)) == 0
+    assert np.max(np.abs(Li @ Lo - np.eye(n))) <= 1e-7
+    ys = (y - y.mean()) / y.std()
+    mll_cpu, g_cpu = O.cycle_value_and_grad(X, ys, ls, kv, 1e-5)
+    mll_gpu, g_gpu = gp.mll_data(ls, kv)
+    assert abs(mll_gpu - mll_cpu) <= 1e-10 * abs(mll_cpu)
+    assert np.max(np.abs(g_gpu - g_cpu)) <= 1e-8 * np.max(np.abs(g_cpu))
+    mb, gb = gp.mll_data_batch(np.tile(ls, (3, 1)) * np.array([[1.0], [0.9], [1.1]]), np.array([kv, kv, 1.0]))
+    assert mb[0] == mll_gpu and np.array_equal(gb[0], g_gpu)
+
+
+@pytest.mark.parametrize("kernel,d", [("rbf", 1), ("matern", 1), ("rbf", 32), ("matern", 32)])
+def test_dimension_limits(kernel, d):
+    """d = 1 and d = 32 (the library's maximum): value, gradient, posterior and sweep against the oracle."""
+    n = 90
+    X, y = smooth_data(n, d, seed=d)
+    ls = np.full(d, 0.5 if d == 1 else 2.0) * (1.0 + 0.01 * np.arange(d))
+    gp, og = both(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=0.9)
+    th = np.log(gp.get_hyperparams())
+    f, g = gp.neg_mll_value_and_grad(th)
+    fo, go = og.neg_mll_value_and_grad(th)
+    assert abs(f - fo) <= 1e-10 * abs(fo) and np.max(np.abs(g - go)) <= 1e-8 * np.max(np.abs(go))
+    rng = np.random.default_rng(3)
+    cand, Z = rng.uniform(size=(130, d)), rng.uniform(size=(33, d))
+    r, ro = gp.wip_sweep(cand, Z, want_mean_var=True), O.wip_sweep(og, cand, Z)
+    assert np.allclose(r["mean"], ro["mean"], atol=1e-8 * 3)
+    assert_var_close(r["var"], ro["var"], 0.9 + 1e-6)
+    assert np.all(np.abs(r["wipstd"] - ro["wipstd"]) <= 1e-7 * ro["wipstd"] + 1e-9 * og.y_std)
+    assert_argmin(r["argmin_s"], ro["wipstd"])
+    with pytest.raises(Exception):
+        GP(np.zeros((4, 33)), np.zeros(4))                   # d > 32 is rejected, not truncated
+
+
+def test_random_small_shapes_against_oracle():
+    """Seeded random shapes (N, d, C, M, kernel): every padding / ragged-tile combination of the sweep."""
+    rng = np.random.default_rng(2024)
+    for case in range(12):
+        n, d = int(rng.integers(1, 260)), int(rng.integers(1, 7))
+        c, m = int(rng.integers(1, 400)), int(rng.integers(1, 150))
+        kernel = "rbf" if case % 2 == 0 else "matern"
+        X, y = smooth_data(n, d, seed=100 + case)
+        ls = rng.uniform(0.3, 1.2, size=d)
+        gp, og = both(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=float(rng.uniform(0.5, 2.0)))
+        cand, Z = rng.uniform(size=(c, d)), rng.uniform(size=(m, d))
+        r, ro = gp.wip_sweep(cand, Z, want_mean_var=True), O.wip_sweep(og, cand, Z)
+        kself = gp.kernel_variance + 1e-6
+        assert r["wipv"].shape == (c,) and r["mean"].shape == (c,), (n, d, c, m)
+        assert np.allclose(r["mean"], ro["mean"], atol=1e-8 * 3), (n, d, c, m)
+        assert_var_close(r["var"], ro["var"], kself)
+        assert np.all(np.abs(r["wipv"] - ro["wipv"]) <= og.y_std ** 2 * (1e-9 * kself + 1e-7 * ro["wipv"] / og.y_std ** 2)), (n, d, c, m)
+        assert_argmin(r["argmin_v"], ro["wipv"])
+        assert_argmin(r["argmin_s"], ro["wipstd"])
