@@ -1,4 +1,5 @@
-// Per-tile latency of the tile-GEMM core at K = 128 (the Cholesky trailing-update shape) for each tile/BK variant.
+// Tile-GEMM core per tile/BK variant: per-tile latency at K = 128 (the Cholesky trailing-update shape) and
+// steady-state throughput at K = 4096 (the sweep's shape).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/bin/ubench_gemm tools/ubench_gemm.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,7 +24,8 @@ __global__ __launch_bounds__(256) void k_t(const double* __restrict__ A, int64_t
 }
 
 template <int T, int BK>
-int run(const char* name, const double* A, double* C, int64_t n, unsigned long long* st, double* flush, size_t flush_n) {
+int run(const char* name, const double* A, double* C, int64_t n, unsigned long long* st, double* flush, size_t flush_n,
+        int64_t K = 128) {
   const int smem = gemm_smem_doubles<T, T, BK>() * 8;
   CK(hipFuncSetAttribute((const void*)k_t<T, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   hipEvent_t e0, e1;
@@ -37,14 +39,14 @@ int run(const char* name, const double* A, double* C, int64_t n, unsigned long l
       for (int rep = 0; rep < 4; ++rep) {
         if (cold) CK(hipMemsetAsync(flush, rep, flush_n, 0));   // evict L2 / MALL
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((k_t<T, BK>), dim3(nt), dim3(256), smem, 0, A, n, C, n, tiles_side, (int64_t)128, st);
+        hipLaunchKernelGGL((k_t<T, BK>), dim3(nt), dim3(256), smem, 0, A, n, C, n, tiles_side, K, st);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) { best = ms; CK(hipMemcpy(h, st, 16, hipMemcpyDeviceToHost)); }
       }
-      const double fl = 2.0 * nt * T * T * 128.0;
-      printf("%-10s tiles=%5d %s: %7.2f us  %6.2f TFLOP/s | block0 cycles: gemm %llu store %llu\n", name, nt, cold ? "cold" : "warm",
+      const double fl = 2.0 * nt * T * T * (double)K;
+      printf("%-10s K=%lld tiles=%5d %s: %7.2f us  %6.2f TFLOP/s | block0 cycles: gemm %llu store %llu\n", name, (long long)K, nt, cold ? "cold" : "warm",
              best * 1e3, fl / (best * 1e-3) / 1e12, h[0], h[1]);
     }
   }
@@ -65,5 +67,9 @@ int main() {
   if (run<64, 16>("T64/BK16", A, C, n, st, flush, flush_n)) return 1;
   if (run<64, 32>("T64/BK32", A, C, n, st, flush, flush_n)) return 1;
   if (run<64, 64>("T64/BK64", A, C, n, st, flush, flush_n)) return 1;
+  if (run<128, 16>("T128/BK16", A, C, n, st, flush, flush_n, 4096)) return 1;
+  if (run<64, 16>("T64/BK16", A, C, n, st, flush, flush_n, 4096)) return 1;
+  if (run<64, 32>("T64/BK32", A, C, n, st, flush, flush_n, 4096)) return 1;
+  if (run<128, 32>("T128/BK32", A, C, n, st, flush, flush_n, 4096)) return 1;
   return 0;
 }
