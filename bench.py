@@ -306,6 +306,7 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()              # rank 0's secondary measurements are done: leave together
         dist.destroy_process_group()
 
 

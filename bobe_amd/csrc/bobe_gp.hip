@@ -416,7 +416,8 @@ void bobe_gp::potrf(double* a, double* linv) {
                            static_cast<int*>(info.p), static_cast<int*>(flags.p));
       else
         hipLaunchKernelGGL((k_potf2<true, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
-                           static_cast<int*>(info.p), (unsigned long long*)nullptr);
+                           static_cast<int*>(info.p), (unsigned long long*)nullptr,
+                           (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE));
       prof_end(BOBE_PROF_POTF2);
       if (rem > 0 && !fused) {
         prof_begin(BOBE_PROF_TRSM);

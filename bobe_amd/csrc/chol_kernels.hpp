@@ -146,9 +146,12 @@ __device__ __forceinline__ void potf2_publish(const double* S, const double* Dal
 template <bool FACTOR, bool STAMP, bool PUB>
 __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv, int64_t ldl,
                                            int blk, int* __restrict__ info, unsigned long long* __restrict__ stamps,
-                                           int* flag) {
+                                           int* flag, int nvalid = TILE) {
   extern __shared__ double S[];
   double* Dall = S + TILE * PLD;  // [8][16][POTF2_DLD]: inverses of the 16x16 diagonal sub-blocks
+  // columns >= nvalid of a ragged last block are the identity padding: their sub-steps are skipped (L = I,
+  // inverse = I, and the rows of the panel below them are zero, so no update is lost)
+  const int nsteps = FACTOR ? ((nvalid + 15) >> 4) : 0;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
@@ -156,10 +159,15 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, 
   double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
   BOBE_STAMP(0);
   block_load<true>(S, Ab, lda);
+  if (FACTOR && nsteps < 8)
+    for (int e = t; e < (8 - nsteps) * 16 * 16; e += 256) {
+      const int pp = nsteps + (e >> 8), rr = (e >> 4) & 15, cc = e & 15;
+      Dall[(pp * 16 + rr) * POTF2_DLD + cc] = (rr == cc) ? 1.0 : 0.0;
+    }
   __syncthreads();
   BOBE_STAMP(1);
 
-  for (int p = 0; FACTOR && p < 8; ++p) {
+  for (int p = 0; p < nsteps; ++p) {
     const int o = 16 * p;
     double* Dv = Dall + p * 16 * POTF2_DLD;
     BOBE_STAMP(2 + 3 * p);
@@ -229,7 +237,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, 
     // ---- phase C: the only urgent update is the next diagonal tile (p+1, p+1); wave 0 does it and runs
     //      straight into the next phase A (same wave: no barrier needed), the other waves go on to the
     //      deferred tiles ----
-    if (p < 7 && wave == 0) potf2_update2(S, o, p + 1, p + 1, p + 1, p + 1, false, lane);
+    if (p + 1 < nsteps && wave == 0) potf2_update2(S, o, p + 1, p + 1, p + 1, p + 1, false, lane);
   }
   __syncthreads();
   BOBE_STAMP(26);
@@ -264,8 +272,8 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, 
 template <bool FACTOR, bool STAMP = false>
 __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                int64_t ldl, int blk, int* __restrict__ info,
-                                               unsigned long long* __restrict__ stamps = nullptr) {
-  potf2_body<FACTOR, STAMP, false>(A, lda, Linv, ldl, blk, info, stamps, nullptr);
+                                               unsigned long long* __restrict__ stamps = nullptr, int nvalid = TILE) {
+  potf2_body<FACTOR, STAMP, false>(A, lda, Linv, ldl, blk, info, stamps, nullptr, nvalid);
 }
 
 // ---- inverse of every diagonal 128x128 block (grid = nb) --------------------------------------------
