@@ -700,3 +700,34 @@ def test_random_small_shapes_against_oracle():
         assert np.all(np.abs(r["wipv"] - ro["wipv"]) <= og.y_std ** 2 * (1e-9 * kself + 1e-7 * ro["wipv"] / og.y_std ** 2)), (n, d, c, m)
         assert_argmin(r["argmin_v"], ro["wipv"])
         assert_argmin(r["argmin_s"], ro["wipstd"])
+
+
+def test_large_n_spot_check():
+    """N = 16 384 (2 GiB per matrix, 128 blocks): the factor and the inverse factor on random sub-blocks, and the
+    posterior at training points — index arithmetic and padding at a size far beyond the headline."""
+    n, d = 16384, 8
+    rng = np.random.default_rng(77)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3.0 * X.sum(1)) + 0.1 * rng.normal(size=n)
+    ls, kv, noise = np.full(d, 0.35), 1.0, 1e-2
+    gp = GP(X, y, noise=noise, lengthscales=ls, kernel_variance=kv)
+    assert not gp.not_pd
+    L = gp.cholesky
+    assert L.shape == (n, n) and np.all(np.isfinite(L))
+    idx_i = np.sort(rng.choice(n, 192, replace=False))
+    idx_j = np.sort(rng.choice(n, 192, replace=False))
+    K_ij = O.rbf_kernel(X[idx_i], X[idx_j], ls, kv, noise, include_noise=False)
+    K_ij[idx_i[:, None] == idx_j[None, :]] += noise
+    assert np.max(np.abs(L[idx_i] @ L[idx_j].T - K_ij)) <= 1e-11
+    assert np.all(np.triu(L[:512, :512], 1) == 0) and np.all(np.diag(L)[::97] > 0)
+    # alpha solves K alpha = y_standardised: check a random set of rows of K alpha
+    ys = (y - y.mean()) / y.std()
+    rows = rng.choice(n, 64, replace=False)
+    K_rows = O.rbf_kernel(X[rows], X, ls, kv, noise, include_noise=False)
+    K_rows[np.arange(64), rows] += noise
+    assert np.max(np.abs(K_rows @ gp.alphas.ravel() - ys[rows])) <= 1e-8
+    m, v = gp.predict_batched(X[rows])
+    assert np.max(np.abs(m - K_rows @ gp.alphas.ravel() + noise * gp.alphas.ravel()[rows])) <= 1e-8
+    assert np.all(v > 0) and np.all(v < kv + noise)
+    mll, g = gp.mll_data(ls, kv)
+    assert np.isfinite(mll) and np.all(np.isfinite(g))
