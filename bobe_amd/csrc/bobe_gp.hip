@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -133,10 +134,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, superpanel, superpanel_batch, fused_panel, mll_slots, own_queues; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, superpanel, superpanel_batch, fused_panel, mll_slots, own_queues, graph_max_n; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 1, 1, 0, 4, 1};   // fused panel off: the hand-off costs exceed the overlap gain
+    Tuning v{512, 600, 1200, 1, 1, 0, 4, 1, 2048};   // fused panel off: the hand-off costs exceed the overlap gain
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -145,6 +146,7 @@ const Tuning& tuning() {
     if (const char* e = std::getenv("BOBE_FUSED_PANEL")) v.fused_panel = std::atoi(e);
     if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
     if (const char* e = std::getenv("BOBE_OWN_QUEUES")) v.own_queues = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_GRAPH_MAX_N")) v.graph_max_n = std::atoi(e);
     return v;
   }();
   return t;
@@ -175,13 +177,30 @@ struct bobe_gp {
   // Extra evaluation slots of bobe_gp_mll_batch: a private stream + workspace per concurrently evaluated
   // hyper-parameter vector.  Slot 0 is the handle's own (stream, XsT2, A2, ...) set; a slot is made current by
   // swapping its members in, so every pipeline stage below runs unchanged on it.
+  // Replayable evaluation pipeline (launch-bound sizes): the kernels of one value(+gradient) evaluation captured
+  // into a hipGraph per (workspace, data generation, with/without gradient).  The hyper-parameters reach the
+  // kernels through a device-resident copy that the graph's first node refreshes from pinned host memory.
+  struct EvalGraph {
+    hipGraphExec_t exec[2] = {nullptr, nullptr};    // [want_grad]
+    std::array<const void*, 16> sig[2] = {};        // every address / size the captured kernels were given
+    Hyper* h_hyp = nullptr;                         // pinned
+    DBuf hyp_dev;
+  };
   struct Slot {
     hipStream_t stream = nullptr;
     DBuf XsT2, A2, Linv2, Tmp, alpha2, w2, part, gpart, res, info, flags;
+    EvalGraph eg;
     double* h_res = nullptr;
     hipEvent_t ev = nullptr;
     bool busy = false, want_grad = false;
   };
+  EvalGraph eg;                    // of the handle's own workspace (swapped with a slot's like the buffers)
+  std::array<const void*, 16> eval_signature() const {
+    return {XsT2.p, A2.p, Linv2.p, Tmp.p, w2.p, alpha2.p, part.p, gpart.p, res.p, info.p, X.p, y.p, probs.p,
+            static_cast<const void*>(h_res), reinterpret_cast<const void*>(static_cast<uintptr_t>(N)),
+            static_cast<const void*>(stream)};
+  }
+  void mll_enqueue_body(const Hyper& h, bool want_grad, const Hyper* hdev);
   std::vector<Slot*> slots;
   std::vector<hipStream_t> slot_streams;     // one per evaluation slot, created on first use
   const std::vector<hipStream_t>& slot_stream_set();
@@ -193,6 +212,7 @@ struct bobe_gp {
     std::swap(alpha2, s.alpha2); std::swap(w2, s.w2); std::swap(part, s.part); std::swap(gpart, s.gpart);
     std::swap(res, s.res); std::swap(info, s.info); std::swap(flags, s.flags);
     std::swap(h_res, s.h_res);
+    std::swap(eg, s.eg);
     in_slot = !in_slot;
   }
   std::mutex submit_mutex;          // serialises bobe_gp_mll_submit (the slot swap is not re-entrant)
@@ -248,16 +268,19 @@ struct bobe_gp {
 
   void build_probs();
   void alloc_for_n();
-  void scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo);
+  void scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo,
+             const Hyper* hdev = nullptr);
   void kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT, int64_t ldb,
                            int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo);
-  void assemble_kxx(const Hyper& h, const double* xst, double* a);
+  void assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev = nullptr);
   void syrk(double* a, int k0, int k1, int first, int colmode);
   void potrf(double* a, double* linv);
   void trtri(const double* a, double* linv);
-  int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap);
+  int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
+            const Hyper* hdev = nullptr);
   void solve_alpha(const double* linv, double* wv, double* al);
-  void factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al);
+  void factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al,
+                   const Hyper* hdev = nullptr);
   int read_info();
   void prepare_z(const double* Z, int64_t M, int64_t Mp);
   void sweep(const double* cand, int64_t C, const double* Z, int64_t M, double y_std, double* wipv, double* wipstd,
@@ -321,8 +344,10 @@ void bobe_gp::alloc_for_n() {
   build_probs();
 }
 
-void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo) {
-  hipLaunchKernelGGL(k_scale_coords, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, stream, in, n, npad, h, out, ldo);
+void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo,
+                    const Hyper* hdev) {
+  hipLaunchKernelGGL(k_scale_coords, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, stream, in, n, npad, h, out, ldo,
+                     hdev);
   LAUNCH_CHECK();
 }
 
@@ -350,14 +375,14 @@ void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, d
 void bobe_gp::kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT,
                                   int64_t ldb, int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo) {
   const dim3 grid((unsigned)(nbpad / TILE), (unsigned)(napad / TILE));
-  KM_DISPATCH(false, grid, AT, lda, na, BT, ldb, nbv, h, out, ldo);
+  KM_DISPATCH(false, grid, AT, lda, na, BT, ldb, nbv, h, out, ldo, (const Hyper*)nullptr);
   LAUNCH_CHECK();
 }
 
-void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a) {
+void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev) {
   const dim3 grid((unsigned)(nb * (nb + 1) / 2));
   prof_begin(BOBE_PROF_KXX);
-  KM_DISPATCH(true, grid, xst, Np, N, xst, Np, N, h, a, Np);
+  KM_DISPATCH(true, grid, xst, Np, N, xst, Np, N, h, a, Np, hdev);
   prof_end(BOBE_PROF_KXX);
   LAUNCH_CHECK();
 }
@@ -462,7 +487,8 @@ void bobe_gp::trtri(const double* a, double* linv) {
 }
 
 // K^-1 tiles fused with the gradient partial sums (optionally stores K^-1's lower tiles); returns #partials
-int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap) {
+int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
+                   const Hyper* hdev) {
   const Tuning& tu = tuning();
   // (the tile size fixes the order of the gradient's partial sums: it depends on N only, so that an evaluation
   // returns the same bits on every slot)
@@ -472,7 +498,7 @@ int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const d
 #define LG(KE, DC, TT)                                                                                          \
   hipLaunchKernelGGL((k_lauum_grad<KE, DC, TT>), dim3(ntiles), dim3(256),                                       \
                      (TT == 128 ? GEMM_SMEM_BYTES : GEMM64_SMEM_BYTES), stream, linv, Np, Np, N, al, xst, Np, h, \
-                     gpart.d(), kinv_out, Np)
+                     gpart.d(), kinv_out, Np, hdev)
 #define LGD(KE, TT)                                                                 \
   do {                                                                              \
     if (dcap == 8) LG(KE, 8, TT); else if (dcap == 16) LG(KE, 16, TT); else LG(KE, 32, TT); \
@@ -499,9 +525,10 @@ void bobe_gp::solve_alpha(const double* linv, double* wv, double* al) {
   LAUNCH_CHECK();
 }
 
-void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al) {
-  scale(X.d(), N, Np, h, xst, Np);
-  assemble_kxx(h, xst, a);
+void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al,
+                          const Hyper* hdev) {
+  scale(X.d(), N, Np, h, xst, Np, hdev);
+  assemble_kxx(h, xst, a, hdev);
   HIPCHK(hipMemsetAsync(info.p, 0x7f, sizeof(int), stream));
   potrf(a, linv);
   trtri(a, linv);
@@ -559,19 +586,62 @@ const std::vector<hipStream_t>& bobe_gp::slot_stream_set() {
 
 // value (+ gradient) pipeline of one hyper-parameter vector on the current stream / workspace; results land in
 // the pinned h_res: [0] y^T K^-1 y, [1] sum log L_ii, [2..2+d] gradient, [100] the factorisation's info word
-void bobe_gp::mll_enqueue(const Hyper& h, bool want_grad) {
-  factor_into(h, XsT2.d(), A2.d(), Linv2.d(), w2.d(), alpha2.d());
+void bobe_gp::mll_enqueue_body(const Hyper& h, bool want_grad, const Hyper* hdev) {
+  if (hdev) HIPCHK(hipMemcpyAsync(eg.hyp_dev.p, eg.h_hyp, sizeof(Hyper), hipMemcpyHostToDevice, stream));
+  factor_into(h, XsT2.d(), A2.d(), Linv2.d(), w2.d(), alpha2.d(), hdev);
   hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w2.d(), (const double*)A2.d(), Np, Np,
                      res.d());
   if (want_grad) {
     const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
-    const int ntiles = lauum(h, Linv2.d(), alpha2.d(), XsT2.d(), nullptr, dcap);
+    const int ntiles = lauum(h, Linv2.d(), alpha2.d(), XsT2.d(), nullptr, dcap, hdev);
     hipLaunchKernelGGL(k_grad_reduce, dim3(d + 1), dim3(64), 0, stream, (const double*)gpart.d(), ntiles, dcap + 1, d,
                        dcap, res.d() + 2);
   }
   LAUNCH_CHECK();
   HIPCHK(hipMemcpyAsync(h_res, res.p, (size_t)(3 + d) * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIPCHK(hipMemcpyAsync(h_res + 100, info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+}
+
+void bobe_gp::mll_enqueue(const Hyper& h, bool want_grad) {
+  const Tuning& tu = tuning();
+  // Up to graph_max_n points an evaluation is tens of kernels of a few microseconds each, and with several slots
+  // in flight the host cannot enqueue them as fast as the GPU retires them: a slot replays its pipeline as one
+  // graph (N = 64 / 512 / 2048 with four in flight: 42 / 107 / 419 us per evaluation instead of 66 / 141 / 553).
+  // A lone evaluation on the handle's stream is NOT faster as a graph (125 vs 107 us at N = 64) and stays a
+  // plain launch sequence; so does everything while a kernel class is being timed (events are not captured).
+  if (!in_slot || N > tu.graph_max_n || prof_tag != 0 || tu.fused_panel) {
+    mll_enqueue_body(h, want_grad, nullptr);
+    return;
+  }
+  if (!eg.h_hyp) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&eg.h_hyp), sizeof(Hyper), hipHostMallocDefault));
+  eg.hyp_dev.ensure(sizeof(Hyper));
+  const int w = want_grad ? 1 : 0;
+  const std::array<const void*, 16> sig = eval_signature();
+  if (!eg.exec[w] || eg.sig[w] != sig) {     // first use, or N / a buffer changed since the capture
+    if (eg.exec[w]) {
+      (void)hipGraphExecDestroy(eg.exec[w]);
+      eg.exec[w] = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try {
+      mll_enqueue_body(h, want_grad, static_cast<const Hyper*>(eg.hyp_dev.p));
+    } catch (...) {
+      (void)hipStreamEndCapture(stream, &graph);
+      if (graph) (void)hipGraphDestroy(graph);
+      throw;
+    }
+    HIPCHK(hipStreamEndCapture(stream, &graph));
+    const hipError_t ie = hipGraphInstantiate(&eg.exec[w], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) {
+      eg.exec[w] = nullptr;
+      HIPCHK(ie);
+    }
+    eg.sig[w] = sig;
+  }
+  *eg.h_hyp = h;            // read by the graph's first node when it executes; the caller collects before reusing it
+  HIPCHK(hipGraphLaunch(eg.exec[w], stream));
 }
 
 int bobe_gp::slot_collect(Slot& sl, double* mll, double* grad) {
@@ -843,7 +913,15 @@ void bobe_gp_destroy(bobe_gp_t* g) {
     (void)hipStreamSynchronize(st);
     (void)hipStreamDestroy(st);
   }
+  auto free_eg = [](bobe_gp::EvalGraph& e) {
+    for (int w = 0; w < 2; ++w)
+      if (e.exec[w]) (void)hipGraphExecDestroy(e.exec[w]);
+    if (e.h_hyp) (void)hipHostFree(e.h_hyp);
+    e.hyp_dev.release();
+  };
+  free_eg(g->eg);
   for (bobe_gp::Slot* sl : g->slots) {
+    free_eg(sl->eg);
     DBuf* sb[] = {&sl->XsT2, &sl->A2, &sl->Linv2, &sl->Tmp, &sl->alpha2, &sl->w2, &sl->part, &sl->gpart, &sl->res,
                   &sl->info, &sl->flags};
     for (DBuf* b : sb) b->release();

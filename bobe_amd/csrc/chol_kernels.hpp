@@ -638,8 +638,9 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(const double* __restrict_
                                                        int64_t n, const double* __restrict__ alpha,
                                                        const double* __restrict__ XsT, int64_t ldx, Hyper h,
                                                        double* __restrict__ partial, double* __restrict__ Kinv,
-                                                       int64_t ldk) {
+                                                       int64_t ldk, const Hyper* __restrict__ hp = nullptr) {
   extern __shared__ double smem[];
+  if (hp) h = *hp;
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
   v4d acc[T / 32][T / 32];

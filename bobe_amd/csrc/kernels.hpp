@@ -63,8 +63,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---- coordinate scaling: out[j*ldo + i] = in[i*d + j] / ls[j]  (0 for i >= n) ------------
+// (hp, when given, overrides h with the device-resident hyper-parameters: a captured graph replays with new values)
 __global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t npad, Hyper h,
-                               double* __restrict__ out, int64_t ldo) {
+                               double* __restrict__ out, int64_t ldo, const Hyper* __restrict__ hp = nullptr) {
+  if (hp) h = *hp;
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= npad) return;
   for (int j = 0; j < h.d; ++j) out[j * ldo + i] = (i < n) ? in[i * h.d + j] / h.ls[j] : 0.0;
@@ -82,7 +84,9 @@ __global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t
 template <int KERN, bool SQUARE, int DCAP, bool FULL>
 __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ AT, int64_t lda, int64_t na,
                                                        const double* __restrict__ BT, int64_t ldb, int64_t nb,
-                                                       Hyper h, double* __restrict__ out, int64_t ldo) {
+                                                       Hyper h, double* __restrict__ out, int64_t ldo,
+                                                       const Hyper* __restrict__ hp = nullptr) {
+  if (hp) h = *hp;
   int ti, tj;
   if (SQUARE) {
     tri_decode(blockIdx.x, ti, tj);

@@ -97,25 +97,24 @@ def _minimize_concurrently(batch_fun: Callable, starts: np.ndarray, has_grad: bo
 
 
 def _minimize_in_slots(slot_fun: Callable, starts: np.ndarray, has_grad: bool, n_slots: int, **kw) -> List:
-    """``scipy.optimize.minimize`` from every row of ``starts``, each in its own thread; restart i evaluates through
-    ``slot_fun(x, i % n_slots)`` (a slot carries one evaluation at a time, so restarts sharing one take turns).
-    Nothing synchronises the restarts: each advances as fast as its own evaluations return."""
-    locks = [threading.Lock() for _ in range(n_slots)]
+    """``scipy.optimize.minimize`` from every row of ``starts`` on ``n_slots`` evaluation slots: one worker thread
+    per slot, worker w running the restarts w, w + n_slots, ... one after the other through ``slot_fun(x, w)``.
+    Nothing synchronises the workers: each advances as fast as its own evaluations return.  (Never more threads
+    than slots: threads queueing for a shared slot were measured 20x slower than the sequential loop.)"""
     out: List = [None] * len(starts)
+    n_workers = max(1, min(n_slots, len(starts)))
 
-    def work(i):
-        slot = i % n_slots
-
+    def work(slot):
         def f(x):
-            with locks[slot]:
-                r = slot_fun(x, slot)
+            r = slot_fun(x, slot)
             return r if has_grad else r[0]
-        try:
-            out[i] = minimize(f, starts[i], jac=has_grad, **kw)
-        except Exception as e:
-            out[i] = e
+        for i in range(slot, len(starts), n_workers):
+            try:
+                out[i] = minimize(f, starts[i], jac=has_grad, **kw)
+            except Exception as e:
+                out[i] = e
 
-    threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(starts))]
+    threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(n_workers)]
     for t in threads:
         t.start()
     for t in threads:
