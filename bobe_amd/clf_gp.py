@@ -157,6 +157,34 @@ class GPwithClassifier(GP):
             return self.train_x_clf[rng.choice(idx, size=1)[0]]
         return super().get_random_point(rng=rng, nstd=nstd)
 
+    @classmethod
+    def from_state_dict(cls, state, device: int = 0):
+        """clf_gp.py:322-386: rebuilt from the CLASSIFIER data set (the GP subset is re-derived by the thresholds),
+        hyper-parameters from the state (the GP is factored again on the GPU, as the reference recomputes it),
+        classifier parameters and flags restored without retraining."""
+        def plain(v):
+            return v.item() if isinstance(v, np.ndarray) and v.shape == () else v
+        g = cls(train_x=state["train_x_clf"], train_y=state["train_y_clf"], clf_type=plain(state["clf_type"]),
+                clf_settings=plain(state["clf_settings"]), clf_use_size=plain(state["clf_use_size"]),
+                clf_update_step=plain(state["clf_update_step"]),
+                probability_threshold=plain(state["probability_threshold"]), minus_inf=plain(state["minus_inf"]),
+                clf_threshold=plain(state["clf_threshold"]), gp_threshold=plain(state["gp_threshold"]),
+                noise=plain(state["noise"]), kernel=plain(state["kernel_name"]),
+                optimizer=plain(state["optimizer_method"]), optimizer_options=plain(state["optimizer_options"]),
+                kernel_variance_bounds=list(np.asarray(state["kernel_variance_bounds"]).tolist()),
+                lengthscale_bounds=list(np.asarray(state["lengthscale_bounds"]).tolist()),
+                lengthscales=state["lengthscales"], kernel_variance=plain(state["kernel_variance"]),
+                kernel_variance_prior=plain(state.get("kernel_variance_prior_spec")),
+                lengthscale_prior=plain(state.get("lengthscale_prior_spec")), tausq=plain(state.get("tausq", 1.0)),
+                tausq_bounds=list(np.asarray(state.get("tausq_bounds", [1e-4, 1e4])).tolist()),
+                train_clf_on_init=False, device=device)
+        g.use_clf = bool(plain(state["use_clf"]))
+        g.clf_params = plain(state.get("clf_params"))
+        g.clf_metrics = plain(state.get("clf_metrics", {})) or {}
+        if g.clf_params is not None:
+            g._clf_predict_func = get_svm_predict_proba_fn(g.clf_params)
+        return g
+
     def state_dict(self):
         """clf_gp.py:279-320: base GP state + classifier data / configuration / parameters."""
         state = super().state_dict()

@@ -1,7 +1,7 @@
 """The reference's own test expectations for the hot path, restated against the MI355X engine.
 
-One test here per test of the reference's ``tests/test_gp.py`` and ``tests/test_acquisition.py`` (plus the two
-GP-related ones of ``tests/test_mpi.py``): same synthetic data recipe, same calls on the same method surface, same
+One test here per test of the reference's ``tests/test_gp.py``, ``tests/test_acquisition.py`` and the SVM tests of
+``tests/test_clf_gp.py`` (plus the two GP-related ones of ``tests/test_mpi.py``): same synthetic data recipe, same calls on the same method surface, same
 assertions — cited as ``file:line`` of the reference test.  Nothing numeric is pinned by those tests,
 they pin the surface and the invariants a drop-in must keep; the numeric parity lives in test_gpu_parity.py.
 """
@@ -220,3 +220,97 @@ def test_gp_state_serialization_for_pool():
     assert np.allclose(re.lengthscales, gp.lengthscales)
     p = np.array([0.5, 0.5])
     assert np.isclose(gp.predict_mean_single(p), re.predict_mean_single(p), rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------- tests/test_clf_gp.py
+def clf_data(n_good=30, n_bad=20, d=2, seed=42):
+    """tests/test_clf_gp.py:18-37: a good region around 0.5 and a bad one in the corners, 10 log-units lower."""
+    rng = np.random.RandomState(seed)
+    Xg = rng.uniform(0.3, 0.7, size=(n_good, d))
+    yg = -np.sum((Xg - 0.5) ** 2, axis=1, keepdims=True)
+    Xb = rng.uniform(0, 1, size=(n_bad, d))
+    Xb = np.where(Xb < 0.5, Xb * 0.4, 0.6 + Xb * 0.4)
+    yb = -10 - np.sum((Xb - 0.5) ** 2, axis=1, keepdims=True)
+    X, y = np.vstack([Xg, Xb]), np.vstack([yg, yb])
+    perm = rng.permutation(len(y))
+    return X[perm], y[perm]
+
+
+def _CLF(*a, **k):
+    from bobe_amd.clf_gp import GPwithClassifier
+    return GPwithClassifier(*a, **k)
+
+
+def test_clf_gp_initialization_svm():
+    """tests/test_clf_gp.py:41-70 (the NN and ellipsoid classifiers of :73-130 are out of scope)."""
+    X, y = clf_data(40, 30, 3)
+    g = _CLF(train_x=X, train_y=y, clf_type="svm", clf_settings={"gamma": "scale", "C": 1e5}, clf_use_size=50,
+             clf_threshold=5.0, gp_threshold=10.0, noise=1e-6)
+    assert g.clf_type == "svm"
+    assert g.clf_data_size == len(X)
+    assert g.npoints <= len(X)
+    assert g.use_clf
+    with pytest.raises(ValueError):
+        _CLF(train_x=X, train_y=y, clf_type="nn")
+
+
+def test_clf_gp_predictions():
+    """tests/test_clf_gp.py:133-188."""
+    X, y = clf_data(40, 30, 2)
+    g = _CLF(train_x=X, train_y=y, clf_type="svm", clf_use_size=50, clf_threshold=5.0, gp_threshold=10.0,
+             probability_threshold=0.5, minus_inf=-1e5, noise=1e-6)
+    good, bad = np.array([0.5, 0.5]), np.array([0.05, 0.05])
+    mean_good, mean_bad = g.predict_mean_single(good), g.predict_mean_single(bad)
+    assert g.predict_var_single(good) > 0 and g.predict_var_single(bad) > 0
+    if g.use_clf:
+        assert mean_bad < mean_good                             # test_clf_gp.py:170
+    pts = np.array([[0.5, 0.5], [0.05, 0.05], [0.6, 0.4]])
+    assert g.predict_mean_batched(pts).shape == (3,) and g.predict_var_batched(pts).shape == (3,)
+
+
+def test_clf_gp_update():
+    """tests/test_clf_gp.py:191-226."""
+    X, y = clf_data(25, 15, 2)
+    g = _CLF(train_x=X, train_y=y, clf_type="svm", clf_use_size=30, clf_threshold=5.0, gp_threshold=10.0, noise=1e-6)
+    n_clf, n_gp = g.clf_data_size, g.npoints
+    new_X = np.array([[0.55, 0.45], [0.48, 0.52]])
+    g.update(new_X, -np.sum((new_X - 0.5) ** 2, axis=1, keepdims=True))
+    assert g.clf_data_size == n_clf + 2
+    assert g.npoints >= n_gp
+
+
+def test_clf_gp_classifier_training():
+    """tests/test_clf_gp.py:229-263: no classifier below clf_use_size, one after enough data arrived."""
+    Xs, ys = clf_data(15, 10, 2)
+    g = _CLF(train_x=Xs, train_y=ys, clf_type="svm", clf_use_size=50, clf_threshold=5.0, noise=1e-6)
+    assert not g.use_clf
+    Xa, ya = clf_data(25, 15, 2, seed=43)
+    g.update(Xa, ya)
+    g.train_classifier()
+    if g.clf_data_size >= g.clf_use_size:
+        assert g.use_clf
+
+
+def test_clf_gp_random_point():
+    """tests/test_clf_gp.py:266-296."""
+    X, y = clf_data(40, 30, 2)
+    g = _CLF(train_x=X, train_y=y, clf_type="svm", clf_use_size=50, clf_threshold=5.0, noise=1e-6)
+    rng = np.random.default_rng(42)
+    pts = np.array([g.get_random_point(rng=rng) for _ in range(5)])
+    assert pts.shape == (5, 2) and np.all(pts >= 0) and np.all(pts <= 1)
+
+
+def test_clf_gp_state_dict_and_copy():
+    """tests/test_clf_gp.py:299-345 and :348-376."""
+    from bobe_amd.clf_gp import GPwithClassifier
+    X, y = clf_data(35, 25, 2)
+    g1 = _CLF(train_x=X, train_y=y, clf_type="svm", clf_settings={"gamma": "scale", "C": 1e5}, clf_use_size=50,
+              clf_threshold=5.0, gp_threshold=10.0, noise=1e-6)
+    g2 = GPwithClassifier.from_state_dict(g1.state_dict())
+    assert g2.clf_type == g1.clf_type and g2.clf_data_size == g1.clf_data_size and g2.use_clf == g1.use_clf
+    assert np.allclose(g2.train_x_clf, g1.train_x_clf)
+    p = np.array([0.5, 0.5])
+    assert np.isclose(g1.predict_mean_single(p), g2.predict_mean_single(p), rtol=1e-5)
+    g3 = g1.copy()
+    g3.update(np.array([[0.6, 0.4]]), np.array([[-0.02]]))
+    assert g1.clf_data_size != g3.clf_data_size and g3.clf_data_size == g1.clf_data_size + 1
