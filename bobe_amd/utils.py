@@ -30,3 +30,11 @@ def scale_to_unit(x, param_bounds):
 def scale_from_unit(x, param_bounds):
     """BOBE/utils/core.py:188-193."""
     return x * (param_bounds[1] - param_bounds[0]) + param_bounds[0]
+
+
+def get_threshold_for_nsigma(nsigma: float, d: int) -> float:
+    """Log-probability drop from the peak of a d-dimensional Gaussian to its n-sigma contour (utils/core.py:150-167)."""
+    from scipy.special import erfc
+    from scipy.stats import chi2
+    nstd = np.sqrt(chi2.isf(erfc(nsigma / np.sqrt(2.0)), d))
+    return float(0.5 * nstd ** 2)

@@ -314,3 +314,65 @@ def test_clf_gp_state_dict_and_copy():
     g3 = g1.copy()
     g3.update(np.array([[0.6, 0.4]]), np.array([[-0.02]]))
     assert g1.clf_data_size != g3.clf_data_size and g3.clf_data_size == g1.clf_data_size + 1
+
+
+# ------------------------------------------------------------------------------------------ tests/test_bo_2d.py
+def _rosenbrock(x):
+    return -((1 - x[0]) ** 2 + 100 * (x[1] - x[0] ** 2) ** 2)          # test_bo_2d.py:16-21
+
+
+def _himmelblau(x):
+    return -((x[0] ** 2 + x[1] - 11) ** 2 + (x[0] + x[1] ** 2 - 7) ** 2)  # test_bo_2d.py:24-29
+
+
+_RESULT_KEYS = ("gp", "likelihood", "results_manager", "best_val", "best_pt", "termination_reason", "samples", "logz")
+
+
+def test_bobe_ei_2d():
+    """tests/test_bo_2d.py:32-100: the reference's constructor and run keywords, its result keys, EI on Rosenbrock."""
+    from bobe_amd.bo import BOBE
+    bobe = BOBE(loglikelihood=_rosenbrock, param_list=["x", "y"], param_bounds=np.array([[-2, 2], [-2, 2]]).T,
+                likelihood_name="rosenbrock_ei_test", n_sobol_init=4, save=False, use_clf=False, seed=42,
+                verbosity="WARNING")
+    results = bobe.run(acq="ei", min_evals=15, max_evals=40, max_gp_size=40, ei_goal=1e-6, fit_n_points=5,
+                       batch_size=1)
+    for key in _RESULT_KEYS:
+        assert key in results, key
+    assert results["samples"] == {} and results["logz"] == {}           # test_bo_2d.py:82-83
+    assert results["gp"].train_x.shape[0] >= 10 and results["gp"].train_x.shape[1] == 2
+    assert results["best_val"] > -1000
+    assert results["best_pt"].shape == (2,)
+    assert isinstance(results["termination_reason"], str)
+
+
+def test_bobe_wipstd_2d():
+    """tests/test_bo_2d.py:103-192: WIPStd on Himmelblau with the logZ convergence test on the surrogate."""
+    from bobe_amd.bo import BOBE
+    bobe = BOBE(loglikelihood=_himmelblau, param_list=["x", "y"], param_bounds=np.array([[-5, 5], [-5, 5]]).T,
+                likelihood_name="himmelblau_test", n_sobol_init=4, save=False, use_clf=False, seed=123,
+                verbosity="WARNING")
+    results = bobe.run(acq="wipstd", min_evals=25, max_evals=60, max_gp_size=60, logz_threshold=0.5,
+                       convergence_n_iters=2, fit_n_points=8, ns_n_points=15, batch_size=1,
+                       mc_points_method="uniform")
+    for key in _RESULT_KEYS:
+        assert key in results, key
+    assert results["gp"].train_x.shape[0] >= 30 and results["gp"].train_x.shape[1] == 2
+    assert results["best_val"] > -500
+    if results["samples"]:
+        assert len(results["samples"]["x"]) > 0
+    assert {"mean", "upper", "lower"} <= set(results["logz"])
+
+
+def test_bobe_with_classifier(tmp_path):
+    """tests/test_bo_2d.py:195-243, plus the save keyword: the GP checkpoint is written and reloads."""
+    from bobe_amd.bo import BOBE
+    from bobe_amd.clf_gp import GPwithClassifier
+    bobe = BOBE(loglikelihood=_rosenbrock, param_list=["x", "y"], param_bounds=np.array([[-2, 2], [-2, 2]]).T,
+                likelihood_name="rosenbrock_clf_test", n_sobol_init=4, save=True, save_dir=str(tmp_path),
+                use_clf=True, clf_type="svm", clf_use_size=10, seed=456, verbosity="WARNING")
+    results = bobe.run(acq="wipstd", min_evals=20, max_evals=50, max_gp_size=50, logz_threshold=0.5, fit_n_points=6,
+                       ns_n_points=12, batch_size=1)
+    assert "gp" in results and hasattr(results["gp"], "use_clf")
+    assert results["best_pt"].shape == (2,) and np.isfinite(results["best_val"])
+    re = GPwithClassifier.load(str(tmp_path / "rosenbrock_clf_test_gp"))
+    assert re.clf_data_size == results["gp"].clf_data_size
