@@ -12,6 +12,9 @@ vectors.  The restatement is therefore pinned only by
     scipy.special, torch fp64 autograd, central finite differences),
   * the literal (N+1)-factor ``fantasy_var`` against the rank-1 closed form,
   * the reference tests' invariants re-run on the same data recipes,
+  * a second, independently written restatement in plain C (oracle/bobe_oracle_c.c: scalar
+    loops, explicit inverse, literal (N+1)-factor fantasy variance) that must agree with
+    this one,
 see tests/test_oracle.py and tests/golden/make_golden.py.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of

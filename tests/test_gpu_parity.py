@@ -731,3 +731,32 @@ def test_large_n_spot_check():
     assert np.all(v > 0) and np.all(v < kv + noise)
     mll, g = gp.mll_data(ls, kv)
     assert np.isfinite(mll) and np.all(np.isfinite(g))
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern"])
+def test_hip_path_against_the_plain_c_restatement(kernel):
+    """The second, independently written CPU restatement (oracle/bobe_oracle_c.c: scalar loops, explicit inverse,
+    literal (N+1)-factor fantasy variance) as the checker."""
+    from oracle import c_binding as OC
+    kid = 0 if kernel == "rbf" else 1
+    n, d = 150, 4
+    X, y = smooth_data(n, d, seed=31)
+    ls, kv, noise = np.array([0.4, 0.55, 0.7, 0.5]), 1.25, 1e-6
+    gp = GP(X, y, noise=noise, kernel=kernel, lengthscales=ls, kernel_variance=kv)
+    ys = gp.train_y.ravel()
+    info, mll_c, grad_c, L_c, alpha_c = OC.mll(kid, X, ys, ls, kv, noise)
+    assert info == 0
+    mll, grad = gp.mll_data(ls, kv)
+    assert abs(mll - mll_c) <= 1e-10 * abs(mll_c)
+    assert np.max(np.abs(grad - grad_c)) <= 1e-8 * np.max(np.abs(grad_c))
+    assert np.max(np.abs(gp.cholesky - L_c)) <= 1e-10
+    rng = np.random.default_rng(2)
+    Xq, Z = rng.uniform(size=(40, d)), rng.uniform(size=(25, d))
+    m, v = gp.predict_batched(Xq)
+    m_c, v_c = OC.predict(kid, X, L_c, alpha_c, ls, kv, noise, Xq)
+    assert np.max(np.abs(m - m_c)) <= 1e-8 * 3
+    assert_var_close(v, v_c, kv + noise)
+    fv = gp.fantasy_var(Xq[:6], Z)
+    for i in range(6):
+        f_c = OC.fantasy_var(kid, X, L_c, ls, kv, noise, Xq[i], Z, gp.y_std)
+        assert np.all(np.abs(fv[i] - f_c) <= gp.y_std ** 2 * (1e-9 * (kv + noise) + 1e-6 * f_c / gp.y_std ** 2))

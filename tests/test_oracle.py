@@ -196,3 +196,45 @@ def test_ei_logei():
     assert np.all(O.ei_score(np.array([0.1, -2.0]), np.array([0.5, 1e-30]), 0.3) >= 0)     # tests/test_acquisition.py:92-95
     x = np.array([1e-3, 0.5, 0.7, 5.0])
     assert np.allclose(O.log1mexp(x), np.log(1 - np.exp(-x)), rtol=1e-12)
+
+
+# ---- the plain-C second restatement against the NumPy one (two independent CPU implementations) ----
+@pytest.mark.parametrize("kernel", ["rbf", "matern"])
+def test_c_restatement_agrees_with_numpy_restatement(kernel):
+    from oracle import c_binding as OC
+    kid = 0 if kernel == "rbf" else 1
+    rng = np.random.default_rng(12)
+    n, d = 45, 3
+    X = rng.uniform(size=(n, d))
+    y = np.sin(4 * X[:, 0]) + X[:, 1] * X[:, 2]
+    ls, kv, noise = np.array([0.35, 0.6, 0.8]), 1.7, 1e-6
+    og = O.OracleGP(X, y, noise=noise, kernel=kernel, lengthscales=ls, kernel_variance=kv)
+    ys = og.train_y.ravel()
+    # kernel matrix, factor, alpha, MLL value
+    kfun = O.get_kernel(kernel)
+    assert np.allclose(OC.kernel(kid, X, X[:7], ls, kv, noise, False), kfun(X, X[:7], ls, kv, noise, include_noise=False),
+                       rtol=1e-14, atol=0)
+    info, mll, grad, L, alpha = OC.mll(kid, X, ys, ls, kv, noise)
+    assert info == 0
+    assert np.allclose(L, og.cholesky, atol=1e-11) and np.allclose(alpha, og.alphas.ravel(), rtol=1e-6)
+    K = kfun(X, X, ls, kv, noise, include_noise=True)
+    assert mll == pytest.approx(O.gp_mll(K, ys, n), rel=1e-12)
+    # analytic gradient (C: explicit inverse, scalar loops) vs the NumPy analytic gradient
+    _, g_np = O.mll_value_and_grad(kernel, X, ys, ls, kv, noise)
+    assert np.allclose(grad, g_np, rtol=1e-8, atol=1e-10)
+    # posterior and the literal (N+1)-factor fantasy variance
+    Xq, Z = rng.uniform(size=(9, d)), rng.uniform(size=(11, d))
+    m_c, v_c = OC.predict(kid, X, L, alpha, ls, kv, noise, Xq)
+    m_np, v_np = og.predict_batched(Xq)
+    assert np.allclose(m_c, m_np, atol=1e-10) and np.allclose(v_c, v_np, rtol=1e-7, atol=1e-12)
+    for x in (Xq[0], X[3]):                       # a generic point and one on top of a training point
+        f_c = OC.fantasy_var(kid, X, L, ls, kv, noise, x, Z, og.y_std)
+        f_np = og.fantasy_var(x, Z, og._k12(Z))
+        assert np.allclose(f_c, f_np, rtol=1e-6, atol=1e-12 * og.y_std ** 2)
+
+
+def test_c_restatement_not_positive_definite_is_nan():
+    from oracle import c_binding as OC
+    X = np.array([[0.1, 0.2], [0.1, 0.2], [0.7, 0.3]])
+    info, mll, grad, L, alpha = OC.mll(0, X, np.array([1.0, -1.0, 0.0]), np.array([0.5, 0.5]), 1.0, 0.0)
+    assert info > 0 and np.isnan(mll) and np.all(np.isnan(grad)) and np.all(np.isnan(L)) and np.all(np.isnan(alpha))
