@@ -31,6 +31,47 @@ def _tofloat(x) -> float:
     return float(np.asarray(x).reshape(-1)[0]) if np.ndim(x) else float(x)
 
 
+# ---- module-level helpers of the reference's gp.py, same names and arguments --------------------------------
+_KERNEL_HANDLES: dict = {}
+
+
+def _kernel_on_gpu(kernel_id: int, xa, xb, lengthscales, kernel_variance, noise, include_noise, device: int = 0):
+    """K(xa, xb) through bobe_gp_kernel on a cached data-less handle per (kernel, d, device)."""
+    xa = _lib.as_f64(np.atleast_2d(xa))
+    xb = _lib.as_f64(np.atleast_2d(xb))
+    d = xa.shape[1]
+    lib = _lib.load()
+    key = (kernel_id, d, device)
+    if key not in _KERNEL_HANDLES:
+        h = C.c_void_p(0)
+        _lib.check(lib.bobe_gp_create(C.byref(h), device, kernel_id, d), "bobe_gp_create")
+        _KERNEL_HANDLES[key] = h
+    ls = _lib.as_f64(lengthscales).reshape(-1)
+    if ls.size == 1 and d > 1:
+        ls = np.full(d, float(ls[0]))
+    out = np.empty((xa.shape[0], xb.shape[0]))
+    _lib.check(lib.bobe_gp_kernel(_KERNEL_HANDLES[key], _lib.ptr(xa), xa.shape[0], _lib.ptr(xb), xb.shape[0],
+                                  _lib.ptr(ls), float(kernel_variance), float(noise), 1 if include_noise else 0,
+                                  _lib.ptr(out)), "bobe_gp_kernel")
+    return out
+
+
+def rbf_kernel(xa, xb, lengthscales, kernel_variance, noise, include_noise=True):
+    """BOBE/gp.py:124-154, evaluated on the GPU."""
+    return _kernel_on_gpu(KERNEL_IDS["rbf"], xa, xb, lengthscales, kernel_variance, noise, include_noise)
+
+
+def matern_kernel(xa, xb, lengthscales, kernel_variance, noise, include_noise=True):
+    """BOBE/gp.py:156-168 (Matérn-5/2), evaluated on the GPU."""
+    return _kernel_on_gpu(KERNEL_IDS["matern"], xa, xb, lengthscales, kernel_variance, noise, include_noise)
+
+
+def kernel_diag(x, kernel_variance, noise, include_noise=True):
+    """BOBE/gp.py:98-122: the constant diagonal of a stationary kernel (O(n) host vector)."""
+    diag = float(kernel_variance) * np.ones(np.atleast_2d(x).shape[0])
+    return diag + float(noise) if include_noise else diag
+
+
 class GP:
     def __init__(self, train_x, train_y, noise=1e-8, kernel="rbf", optimizer="scipy", optimizer_options={},
                  kernel_variance_bounds=[1e-4, 1e8], lengthscale_bounds=[0.01, 5], lengthscales=None,

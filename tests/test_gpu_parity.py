@@ -760,3 +760,17 @@ def test_hip_path_against_the_plain_c_restatement(kernel):
     for i in range(6):
         f_c = OC.fantasy_var(kid, X, L_c, ls, kv, noise, Xq[i], Z, gp.y_std)
         assert np.all(np.abs(fv[i] - f_c) <= gp.y_std ** 2 * (1e-9 * (kv + noise) + 1e-6 * f_c / gp.y_std ** 2))
+
+
+def test_module_level_kernel_helpers():
+    """``from BOBE.gp import rbf_kernel, matern_kernel, kernel_diag`` keeps working (gp.py:98-168)."""
+    from bobe_amd.gp import kernel_diag, matern_kernel, rbf_kernel
+    rng = np.random.default_rng(6)
+    A, B = rng.uniform(size=(37, 5)), rng.uniform(size=(140, 5))
+    ls = rng.uniform(0.3, 1.0, size=5)
+    assert np.allclose(rbf_kernel(A, B, ls, 1.3, 1e-6, include_noise=False),
+                       O.rbf_kernel(A, B, ls, 1.3, 1e-6, include_noise=False), rtol=1e-13, atol=1e-15)
+    assert np.allclose(matern_kernel(A, A, ls, 0.7, 1e-3, include_noise=True),
+                       O.matern_kernel(A, A, ls, 0.7, 1e-3, include_noise=True), rtol=1e-13, atol=1e-15)
+    assert np.array_equal(kernel_diag(A, 1.3, 1e-6), O.kernel_diag(A, 1.3, 1e-6))
+    assert np.array_equal(kernel_diag(A, 1.3, 1e-6, include_noise=False), np.full(37, 1.3))
