@@ -195,8 +195,8 @@ class WIPStd(WeightedIntegratedPosteriorBase):
 
 def get_mc_samples(gp: GP, warmup_steps=512, num_samples=1024, thinning=4, method="uniform", num_chains=4,
                    np_rng=None, rng_key=None):
-    """BOBE/acquisition.py:468-482.  Only the 'uniform' (scrambled Sobol) method lives on the hot path;
-    NUTS / nested sampling are sampler consumers ('next')."""
+    """BOBE/acquisition.py:468-482: 'NUTS' (Hamiltonian Monte Carlo on the surrogate, batched on the GPU), 'NS'
+    (nested sampling on the surrogate) or 'uniform' (scrambled Sobol)."""
     if method == "uniform":
         return {"x": qmc.Sobol(gp.ndim, scramble=True, seed=np_rng).random(num_samples)}
     if method == "NS":                                   # acquisition.py:473-475, batched on the GPU GP
@@ -204,7 +204,12 @@ def get_mc_samples(gp: GP, warmup_steps=512, num_samples=1024, thinning=4, metho
         rng = np_rng if isinstance(np_rng, np.random.Generator) else np.random.default_rng(np_rng)
         samples, _, _ = nested_sampling(gp, ndim=gp.ndim, mode="acq", rng=rng)
         return samples
-    raise NotImplementedError(f"mc-sample method {method!r} is not available (NUTS needs NumPyro; see DESIGN.md)")
+    if method == "NUTS":                                 # acquisition.py:470-472, batched HMC on the GPU GP
+        from .samplers import sample_GP_NUTS
+        rng = np_rng if isinstance(np_rng, np.random.Generator) else np.random.default_rng(np_rng)
+        return sample_GP_NUTS(gp, np_rng=rng, rng_key=rng_key, num_chains=num_chains, warmup_steps=warmup_steps,
+                              num_samples=num_samples, thinning=thinning)
+    raise NotImplementedError(f"mc-sample method {method!r} is not available")
 
 
 def get_mc_points(mc_samples, mc_points_size=128, rng=None):

@@ -155,7 +155,7 @@ class BOBE:
 
     def run(self, acq=None, min_evals: int = 0, max_evals: int = 250, max_gp_size: int = 1200,
             fit_n_points: int = 10, batch_size: int = 1, mc_points_size: int = 64, num_mc_samples: int = 1024,
-            mc_points_method: str = "uniform", logz_threshold: Optional[float] = None, ns_n_points: int = 10,
+            mc_points_method: str = "NUTS", logz_threshold: Optional[float] = None, ns_n_points: int = 10,
             convergence_n_iters: int = 1, do_final_ns: bool = False, acq_threshold: Optional[float] = None,
             zeta_ei: float = 0.01, verbose: bool = False, ei_goal: Optional[float] = None, num_hmc_warmup: int = 512,
             num_hmc_samples: int = 512, thinning: int = 4, num_chains: int = 4) -> dict:
@@ -178,7 +178,12 @@ class BOBE:
             it += 1
             t0 = time.time()
             if is_wip:
-                mc = get_mc_samples(self.gp, num_samples=num_mc_samples, method=mc_points_method, np_rng=self.np_rng)
+                if mc_points_method == "NUTS":               # bo.py:1243-1250: HMC settings of run()
+                    mc = get_mc_samples(self.gp, warmup_steps=num_hmc_warmup, num_samples=num_hmc_samples,
+                                        thinning=thinning, method="NUTS", num_chains=num_chains, np_rng=self.np_rng)
+                else:
+                    mc = get_mc_samples(self.gp, num_samples=num_mc_samples, method=mc_points_method,
+                                        np_rng=self.np_rng)
                 samples = mc
                 kwargs = {"mc_samples": mc, "mc_points_size": mc_points_size}
                 new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=batch_size, acq_kwargs=kwargs, n_restarts=1,

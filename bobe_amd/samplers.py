@@ -18,6 +18,7 @@ import math
 from typing import Dict, Optional, Tuple
 
 import numpy as np
+from scipy.special import expit
 
 from .utils import get_logger, get_numpy_rng
 
@@ -187,3 +188,121 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
         weights = np.ones(samples_x.shape[0])
     samples_dict = {"x": samples_x, "weights": weights, "logl": logl, "best": best_pt, "method": "nested"}
     return samples_dict, logz_dict, success
+
+
+# --------------------------------------------------------------------------------------------------------------
+# MCMC on the surrogate (samplers.py:196-360)
+# --------------------------------------------------------------------------------------------------------------
+def prior_transform(x):
+    """samplers.py:52-53: the unit cube is the prior."""
+    return x
+
+
+def nested_sampling_Dy(gp, mode: str = "acq", ndim: int = 1, dlogz: float = 0.1, dynamic: bool = False,
+                       maxcall: Optional[int] = int(5e6), print_progress: Optional[bool] = True,
+                       equal_weights: bool = False, sample_method: str = "rwalk", rng=None):
+    """The reference's entry point name and keywords (samplers.py:55-65) on ``nested_sampling`` above; ``dynamic``,
+    ``print_progress`` and ``sample_method`` are dynesty options without a counterpart here."""
+    return nested_sampling(gp, ndim=ndim if ndim and ndim > 1 else gp.ndim, mode=mode, dlogz=dlogz,
+                           maxcall=maxcall if maxcall is not None else int(5e6), equal_weights=equal_weights, rng=rng)
+
+
+def get_hmc_settings(ndim, warmup_steps=None, num_samples=None, thinning=None):
+    """samplers.py:196-214."""
+    warmup_steps = warmup_steps if warmup_steps is not None else (256 if ndim <= 9 else 512)
+    num_samples = num_samples if num_samples is not None else (1024 if ndim <= 9 else 2048)
+    thinning = thinning if thinning is not None else 4
+    return warmup_steps, num_samples, thinning
+
+
+def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: float = 1.0, **kwargs):
+    """Samples of the posterior whose log-density is the GP mean / ``temp`` over the unit cube — the target, keywords
+    and return dict of samplers.py:216-360 (``'x'`` of shape (num_chains * num_samples / thinning, d), ``'logp'``,
+    ``'best'``, ``'method'``).
+
+    Deviation: NumPyro's NUTS (one JAX call per leapfrog step and chain) is replaced by Hamiltonian Monte Carlo run
+    as ONE batch of ``16 * num_chains`` chains: every leapfrog step is a single ``bobe_gp_predict_grad`` call for all
+    chains.  Same stationary distribution; the per-chain length shrinks by the same factor so the number of returned
+    samples is the reference's.  The cube constraint is handled like NumPyro does it, by sampling u = logit(x) with
+    the Jacobian term; step size by dual averaging to 0.8 acceptance and a diagonal mass matrix from the warm-up
+    spread of the chains.  Chains start at the best training point and at ``gp.get_random_point`` draws
+    (samplers.py:296-300).  Works for ``GPwithClassifier`` too: infeasible points carry ``minus_inf`` and are never
+    accepted."""
+    rng = np_rng if isinstance(np_rng, np.random.Generator) else np.random.default_rng(np_rng)
+    d = gp.ndim
+    warmup_steps, num_samples, thinning = get_hmc_settings(d, kwargs.get("warmup_steps"), kwargs.get("num_samples"),
+                                                           kwargs.get("thinning"))
+    mult = 16
+    P = mult * max(1, int(num_chains))
+    n_keep_total = max(1, (int(num_chains) * num_samples) // thinning)
+    keep_per_chain = -(-n_keep_total // P)
+    base_gp_grad = getattr(gp, "predict_grad")
+    gated = hasattr(gp, "use_clf")
+
+    def logp_and_grad(U):
+        X = np.clip(expit(U), 1e-12, 1.0 - 1e-12)
+        m, _, dm, _ = base_gp_grad(X)
+        mean = m * gp.y_std + gp.y_mean
+        gx = dm * gp.y_std
+        if gated:                                              # classifier gate (clf_gp.py:173-205)
+            gm = np.asarray(gp.predict_mean_batched(X), dtype=np.float64)
+            bad = gm <= gp.minus_inf
+            mean = np.where(bad, gp.minus_inf, mean)
+            gx = np.where(bad[:, None], 0.0, gx)
+        jac = np.sum(np.log(X) + np.log1p(-X), axis=1)
+        lp = mean / temp + jac
+        g = gx / temp * (X * (1.0 - X)) + (1.0 - 2.0 * X)
+        return lp, g, mean, X
+
+    best = gp.train_x[int(np.argmax(gp.train_y))]
+    inits = np.vstack([np.clip(best + 1e-3 * rng.normal(size=d), 1e-6, 1 - 1e-6)] +
+                      [gp.get_random_point(rng=rng) for _ in range(P - 1)])
+    inits = np.clip(inits, 1e-6, 1.0 - 1e-6)
+    U = np.log(inits) - np.log1p(-inits)
+    lp, g, mean, X = logp_and_grad(U)
+    inv_mass = np.ones(d)
+    # dual averaging (Hoffman & Gelman 2014, as NumPyro's warm-up does) on one step size shared by the batch
+    eps, mu, hbar, log_eps_bar, t0, gamma, kappa, target = 0.1, math.log(1.0), 0.0, 0.0, 10.0, 0.05, 0.75, 0.8
+    windows = {int(warmup_steps * f) for f in (0.25, 0.5, 0.75)}
+    recent = []
+    xs, lps = [], []
+    total = warmup_steps + keep_per_chain * thinning
+    for it in range(total):
+        L = int(rng.integers(4, 13))
+        p0 = rng.normal(size=U.shape) / np.sqrt(inv_mass)
+        Un, pn, gn = U.copy(), p0 + 0.5 * eps * g, g
+        for s in range(L):
+            Un = Un + eps * inv_mass * pn
+            lpn, gn, meann, Xn = logp_and_grad(Un)
+            pn = pn + (eps if s < L - 1 else 0.5 * eps) * gn
+        h0 = lp - 0.5 * np.sum(p0 * p0 * inv_mass, axis=1)
+        h1 = lpn - 0.5 * np.sum(pn * pn * inv_mass, axis=1)
+        with np.errstate(over="ignore", invalid="ignore"):
+            acc_prob = np.where(np.isfinite(h1), np.minimum(1.0, np.exp(h1 - h0)), 0.0)
+        accept = rng.uniform(size=P) < acc_prob
+        U = np.where(accept[:, None], Un, U)
+        g = np.where(accept[:, None], gn, g)
+        lp = np.where(accept, lpn, lp)
+        mean = np.where(accept, meann, mean)
+        X = np.where(accept[:, None], Xn, X)
+        if it < warmup_steps:
+            m_ = it + 1
+            hbar = (1.0 - 1.0 / (m_ + t0)) * hbar + (target - float(np.mean(acc_prob))) / (m_ + t0)
+            log_eps = mu - math.sqrt(m_) / gamma * hbar
+            eta = m_ ** (-kappa)
+            log_eps_bar = eta * log_eps + (1.0 - eta) * log_eps_bar
+            eps = float(np.clip(math.exp(log_eps), 1e-4, 2.0))
+            recent.append(U.copy())
+            if m_ in windows:                                  # mass matrix from the spread of the batch
+                pool = np.concatenate(recent[len(recent) // 2:], axis=0)
+                inv_mass = np.var(pool, axis=0) + 1e-3
+                recent = []
+                mu, hbar, log_eps_bar = math.log(10.0 * eps), 0.0, 0.0
+            if m_ == warmup_steps:
+                eps = float(np.clip(math.exp(log_eps_bar), 1e-4, 2.0)) if log_eps_bar != 0.0 else eps
+        elif (it - warmup_steps + 1) % thinning == 0:
+            xs.append(X.copy())
+            lps.append(mean.copy())
+    samples_x = np.concatenate(xs, axis=0)[:n_keep_total]
+    logps = np.concatenate(lps, axis=0)[:n_keep_total]
+    return {"x": samples_x, "logp": logps, "best": samples_x[int(np.argmax(logps))], "method": "MCMC"}

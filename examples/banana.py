@@ -1,5 +1,5 @@
 """BASELINE.json config 1 — 2-D curved ("banana") likelihood, reference examples/Banana.py:14-18, 27-31, 54-68,
-end to end on the GPU GP with WIPStd and uniform (Sobol) integration points."""
+end to end on the GPU GP: WIPStd with HMC integration points and the logZ convergence test on the surrogate."""
 import os
 import sys
 import time
@@ -18,7 +18,13 @@ if __name__ == "__main__":
     bounds = np.array([[-1, 1], [-1, 2]]).T
     t0 = time.time()
     bobe = BOBE(loglike, ["x1", "x2"], bounds, n_sobol_init=8, seed=42)
-    res = bobe.run(acq="wipstd", max_evals=int(os.environ.get("MAX_EVALS", 60)), fit_n_points=1, batch_size=1,
-                   mc_points_size=512)
+    # the run settings of the reference's examples/Banana.py:53-68 (HMC integration points, logZ convergence on
+    # the surrogate, final nested sampling); MAX_EVALS shortens the run
+    max_evals = int(os.environ.get("MAX_EVALS", 250))
+    res = bobe.run(acq="wipstd", min_evals=25, max_evals=max_evals, max_gp_size=max_evals, logz_threshold=5e-2,
+                   do_final_ns=True, fit_n_points=1, batch_size=1, ns_n_points=1, num_hmc_warmup=512,
+                   num_hmc_samples=2048, mc_points_size=512, num_chains=4, convergence_n_iters=2)
+    print("termination:", res["termination_reason"], "| logZ:", {k: round(float(v), 3) for k, v in res["logz"].items()
+                                                                   if k in ("mean", "upper", "lower")})
     print("banana: %d evals in %.1fs, best logL %.4f at %s" % (res["n_evals"], time.time() - t0, res["best_val"], res["best_x"]))
     print("timing:", {k: round(v, 2) for k, v in res["timing"].items()})

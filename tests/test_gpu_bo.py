@@ -17,7 +17,8 @@ def test_wipstd_uniform_loop_himmelblau():
     from bobe_amd.bo import BOBE
     bounds = np.array([[-4.0, 4.0], [-4.0, 4.0]]).T
     bobe = BOBE(himmelblau, ["x", "y"], bounds, n_sobol_init=8, seed=1)
-    res = bobe.run(acq="wipstd", max_evals=36, fit_n_points=2, batch_size=2, mc_points_size=64, num_mc_samples=256)
+    res = bobe.run(acq="wipstd", max_evals=36, fit_n_points=2, batch_size=2, mc_points_size=64, num_mc_samples=256,
+                   mc_points_method="uniform")
     assert set(res) >= {"gp", "best_val", "best_x", "n_evals", "acq_history", "timing"}
     assert res["best_val"] > -500                       # tests/test_bo_2d.py:143-170 style bounds
     assert 8 < res["gp"].npoints <= 36 and res["n_evals"] == res["gp"].npoints

@@ -43,3 +43,38 @@ def test_bo_loop_with_logz_convergence():
                    logz_threshold=0.05, min_evals=24, ns_n_points=8)
     assert "logz" in res and res["logz"]["mean"] == pytest.approx(2 * 0.5 * math.log(2 * math.pi * sig ** 2), abs=0.25)
     assert res["n_evals"] <= 80 and (res["converged"] or res["n_evals"] == 80)
+
+
+def test_hmc_on_the_surrogate_recovers_a_gaussian_posterior():
+    """sample_GP_NUTS (samplers.py:216-360): target, keywords and return dict of the reference; the sampler is a
+    batched HMC (one bobe_gp_predict_grad call per leapfrog step for all chains)."""
+    from bobe_amd import GP
+    from bobe_amd.acquisition import get_mc_points, get_mc_samples
+    from bobe_amd.bo import gp_fit
+    from bobe_amd.samplers import get_hmc_settings, sample_GP_NUTS
+    d = 3
+    mu, sig = np.array([0.45, 0.55, 0.5]), np.array([0.08, 0.12, 0.1])
+    X = qmc.Sobol(d, scramble=True, seed=5).random(512)
+    y = -0.5 * np.sum(((X - mu) / sig) ** 2, axis=1)
+    gp = GP(X, y, noise=1e-8, lengthscales=[0.5] * d, kernel_variance=10.0)
+    gp_fit(gp, maxiters=100, n_restarts=2, rng=np.random.default_rng(0))
+    assert get_hmc_settings(d) == (256, 1024, 4) and get_hmc_settings(12) == (512, 2048, 4)      # samplers.py:196-214
+    s = sample_GP_NUTS(gp, np_rng=np.random.default_rng(1), num_chains=4)
+    assert set(s) == {"x", "logp", "best", "method"} and s["method"] == "MCMC"
+    assert s["x"].shape == (4 * 1024 // 4, d) and s["logp"].shape == (1024,)
+    assert np.all(s["x"] > 0) and np.all(s["x"] < 1)
+    assert np.all(np.abs(s["x"].mean(0) - mu) < 0.02)
+    assert np.all(np.abs(s["x"].std(0) / sig - 1.0) < 0.2)
+    assert np.all(np.abs(s["best"] - mu) < 0.06)
+    # logp is the (physical) GP mean at the samples
+    assert np.allclose(s["logp"][:50], gp.predict_mean_batched(s["x"][:50]), atol=1e-6)
+    # tempering widens the posterior: sigma scales like sqrt(temp)
+    s4 = sample_GP_NUTS(gp, np_rng=np.random.default_rng(2), num_chains=2, temp=4.0, num_samples=512)
+    assert s4["x"].shape[0] == 2 * 512 // 4
+    assert np.all(s4["x"].std(0) > 1.5 * sig)
+    # the reference's default mc_points_method (acquisition.py:466-471)
+    mc = get_mc_samples(gp, warmup_steps=128, num_samples=256, thinning=4, method="NUTS", num_chains=4,
+                        np_rng=np.random.default_rng(3))
+    assert mc["x"].shape == (256, d)
+    pts = get_mc_points(mc, mc_points_size=64, rng=np.random.default_rng(4))
+    assert pts.shape == (64, d)

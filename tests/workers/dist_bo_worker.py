@@ -18,7 +18,8 @@ def banana(x):
 def run_case():
     bounds = np.array([[-4.0, 4.0], [-2.0, 6.0]]).T
     bobe = BOBE(banana, ["x", "y"], bounds, n_sobol_init=12, seed=11)
-    res = bobe.run(acq="wipv", max_evals=22, mc_points_size=96, num_mc_samples=512, fit_n_points=2)
+    res = bobe.run(acq="wipv", max_evals=22, mc_points_size=96, num_mc_samples=512, fit_n_points=2,
+                   mc_points_method="uniform")
     gp = res["gp"]
     return {"train_x": gp.train_x.tolist(), "lengthscales": np.asarray(gp.lengthscales).tolist(),
             "kernel_variance": float(gp.kernel_variance), "best_val": res["best_val"], "n": int(gp.npoints)}
