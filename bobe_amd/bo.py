@@ -174,7 +174,10 @@ class BOBE:
         converged, n_ok, since_ns = False, 0, 0
         reason, it = None, 0
         self.timing.setdefault("Nested Sampling", 0.0)
-        while self.gp.npoints < min(max_evals, max_gp_size):
+        # the reference counts objective evaluations (bo.py:1198, 765-775): a proposal the GP rejects as a duplicate
+        # still counts, so the loop ends by max_evals even when nothing new is accepted
+        current_evals = self.gp.npoints
+        while current_evals < max_evals and self.gp.npoints < max_gp_size:
             it += 1
             t0 = time.time()
             if is_wip:
@@ -195,7 +198,6 @@ class BOBE:
             new_u = np.atleast_2d(new_u)
             self.timing["Acquisition Optimization"] += time.time() - t0
             acq_hist.append(float(np.mean(vals)))
-            n_before = self.gp.npoints
             new_vals = self._evaluate(scale_from_unit(new_u, self.param_bounds))
             self.update_gp(new_u, new_vals, fit_n_points)
             if verbose:
@@ -203,19 +205,17 @@ class BOBE:
             if self.save and it % self.save_step == 0:
                 import os
                 self.gp.save(os.path.join(self.save_dir, f"{self.likelihood_name}_gp"))
-            if self.gp.npoints == n_before:          # every proposal was a duplicate: nothing left to learn here
-                reason = "No new points accepted"
-                break
+            current_evals += new_u.shape[0]
             if acq_threshold is not None and is_wip and acq_hist[-1] <= acq_threshold:
                 reason = "Acquisition threshold reached"
                 break
-            if ei_goal is not None and not is_wip and self.gp.npoints >= min_evals:          # bo.py:1208-1215
+            if ei_goal is not None and not is_wip and current_evals >= min_evals:          # bo.py:1208-1215
                 goal_val = np.exp(acq_hist[-1]) if acq.lower() == "logei" else acq_hist[-1]
                 if goal_val < ei_goal:
                     converged, reason = True, f"{acq_fn.name.upper()} goal reached"
                     break
-            since_ns += self.gp.npoints - n_before
-            if logz_threshold is not None and self.gp.npoints >= min_evals and since_ns >= ns_n_points:
+            since_ns += new_u.shape[0]
+            if logz_threshold is not None and current_evals >= min_evals and since_ns >= ns_n_points:
                 t0 = time.time()
                 _, logz, ok = nested_sampling(self.gp, mode="convergence", rng=self.np_rng)
                 self.timing["Nested Sampling"] += time.time() - t0
