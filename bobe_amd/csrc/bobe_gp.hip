@@ -1214,7 +1214,8 @@ int bobe_gp_acq_ei(bobe_gp_t* g, const double* Xq, int64_t C, double best_y, dou
 int bobe_gp_predict_grad(bobe_gp_t* g, const double* Xq, int64_t C, double* mean, double* var, double* dmean,
                          double* dvar) {
   API_BEGIN
-  if (!g || !Xq || !dmean || !dvar) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g || !Xq || !dmean) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!dvar && var) throw Err(BOBE_ERR_ARG, "var without dvar: use bobe_gp_predict");
   if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
   if (C <= 0) throw Err(BOBE_ERR_ARG, "C must be positive");
   g->use();
@@ -1222,6 +1223,36 @@ int bobe_gp_predict_grad(bobe_gp_t* g, const double* Xq, int64_t C, double* mean
   const int64_t Np = g->Np, CH = std::min<int64_t>(g->chunk, 2048);
   const double kself = g->hyp.kvar + g->hyp.noise;
   const double* cin = g->fetch(Xq, (size_t)C * d, g->in_stage);
+  if (!dvar) {
+    // mean-only mode (HMC on the surrogate): scale the queries, then one kernel that walks the training points
+    // and accumulates the mean and its gradient - no K(X, C), no triangular products
+    g->CsT.ensure((size_t)d * std::max<int64_t>(CH, g->chunk) * sizeof(double));
+    double* d_mean = g->out_dev(mean, C, g->o_mean);
+    double* d_dm = g->out_dev(dmean, (size_t)C * d, g->o_wipv);
+    const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+    for (int64_t c0 = 0; c0 < C; c0 += CH) {
+      const int64_t nc = std::min<int64_t>(CH, C - c0), ncp = round_up(nc, TILE);
+      g->scale(cin + c0 * d, nc, ncp, g->hyp, g->CsT.d(), CH);
+      const dim3 grid((unsigned)((nc + 63) / 64));
+      const size_t sm = (size_t)(d + 1) * 128 * sizeof(double);
+#define PGM(KE, DC)                                                                                                  \
+  hipLaunchKernelGGL((k_predict_grad<KE, DC>), grid, dim3(256), sm, g->stream, (const double*)g->XsT.d(), Np, g->N,    \
+                     (const double*)g->CsT.d(), CH, nc, (const double*)g->alpha.d(), (const double*)nullptr,           \
+                     (int64_t)0, (const double*)nullptr, g->hyp, d_dm + c0 * d, (double*)nullptr,                     \
+                     d_mean ? d_mean + c0 : nullptr)
+      if (g->hyp.kern == 0) {
+        if (dcap == 8) PGM(0, 8); else if (dcap == 16) PGM(0, 16); else PGM(0, 32);
+      } else {
+        if (dcap == 8) PGM(1, 8); else if (dcap == 16) PGM(1, 16); else PGM(1, 32);
+      }
+#undef PGM
+      LAUNCH_CHECK();
+    }
+    g->out_finish(mean, C, g->o_mean);
+    g->out_finish(dmean, (size_t)C * d, g->o_wipv);
+    g->sync();
+    return BOBE_OK;
+  }
   g->CsT.ensure((size_t)d * std::max<int64_t>(CH, g->chunk) * sizeof(double));
   g->kXC.ensure((size_t)Np * std::max<int64_t>(CH, g->chunk) * sizeof(double));
   g->VZ.ensure((size_t)Np * CH * sizeof(double));     // V = Linv k

@@ -446,12 +446,15 @@ __device__ __forceinline__ double log_ei_helper(double u) {
 // with dk/dx_cj = G(r2) (s_nj - s_cj) / ls_j  (s = x / ls; G = k for RBF, the Matern-5/2 factor otherwise).
 // One workgroup = 64 candidates x 4 interleaved slices over the training points; fixed summation order.
 // dvar is zeroed where the (standardised) variance sits at its 1e-12 floor, like the gradient of jnp.where.
+// U == nullptr: mean-only mode (the HMC sampler's call): dvar is not touched, and mean_out (optional) receives
+// the posterior mean sum_n alpha_n k(x_n, x_c) itself, so that no K(X, C) matrix is needed at all.
 template <int KERN, int DCAP>
 __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__ XsT, int64_t ldx, int64_t n,
                                                       const double* __restrict__ CsT, int64_t ldc, int64_t ncols,
                                                       const double* __restrict__ alpha, const double* __restrict__ U,
                                                       int64_t ldu, const double* __restrict__ svar, Hyper h,
-                                                      double* __restrict__ dmean, double* __restrict__ dvar) {
+                                                      double* __restrict__ dmean, double* __restrict__ dvar,
+                                                      double* __restrict__ mean_out = nullptr) {
   extern __shared__ double psm[];            // [d][128] training coordinates + alpha[128]
   constexpr int NT = 128;
   __shared__ double red[2][4][64];
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__
   const int64_t c = (int64_t)blockIdx.x * 64 + cx;
   const bool live = c < ncols;
   double xc[DCAP], gm[DCAP], gv[DCAP];
+  double ms = 0.0;
 #pragma unroll
   for (int j = 0; j < DCAP; ++j) {
     xc[j] = (live && j < h.d) ? CsT[j * ldc + c] : 0.0;
@@ -486,7 +490,8 @@ __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__
         const double kv = kern_eval<KERN>(r2, h.kvar);
         const double gfac = kern_grad_factor<KERN>(r2, h.kvar, kv);
         const double a = psm[h.d * NT + nn] * gfac;
-        const double u = -2.0 * U[(n0 + nn) * ldu + c] * gfac;
+        const double u = U ? -2.0 * U[(n0 + nn) * ldu + c] * gfac : 0.0;
+        ms += psm[h.d * NT + nn] * kv;
 #pragma unroll
         for (int j = 0; j < DCAP; ++j) {
           gm[j] += a * df[j];
@@ -495,7 +500,13 @@ __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__
       }
     }
   }
-  const bool floored = live ? !(svar[c] >= NOISE_FLOOR) : true;
+  const bool floored = (live && svar) ? !(svar[c] >= NOISE_FLOOR) : true;
+  if (mean_out) {
+    __syncthreads();
+    red[0][sl][cx] = ms;
+    __syncthreads();
+    if (sl == 0 && live) mean_out[c] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+  }
 #pragma unroll
   for (int j = 0; j < DCAP; ++j) {
     if (j < h.d) {                       // uniform condition: barriers inside are safe
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__
         const double m = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
         const double v = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
         dmean[c * h.d + j] = m / h.ls[j];
-        dvar[c * h.d + j] = floored ? 0.0 : v / h.ls[j];
+        if (dvar) dvar[c * h.d + j] = floored ? 0.0 : v / h.ls[j];
       }
     }
   }

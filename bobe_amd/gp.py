@@ -453,11 +453,17 @@ class GP:
                                             1 if log_ei else 0, _lib.ptr(out)), "bobe_gp_acq_ei")
         return out
 
-    def predict_grad(self, x):
+    def predict_grad(self, x, mean_only=False):
         """Standardised (mean, var, dmean/dx, dvar/dx) of ``predict_single`` (gp.py:476-489) for C points: what the
-        reference gets by JAX autodiff through the GP (acquisition.py:246-253, samplers.py:268-276)."""
+        reference gets by JAX autodiff through the GP (acquisition.py:246-253, samplers.py:268-276).
+        ``mean_only``: (mean, None, dmean/dx, None) from one small kernel — the HMC sampler's call."""
         x = _lib.as_f64(np.atleast_2d(x))
         c = x.shape[0]
+        if mean_only:
+            mean, dmean = np.empty(c), np.empty((c, self.ndim))
+            _lib.check(self._lib.bobe_gp_predict_grad(self._h, _lib.ptr(x), c, _lib.ptr(mean), None, _lib.ptr(dmean),
+                                                      None), "bobe_gp_predict_grad")
+            return mean, None, dmean, None
         mean, var = np.empty(c), np.empty(c)
         dmean, dvar = np.empty((c, self.ndim)), np.empty((c, self.ndim))
         _lib.check(self._lib.bobe_gp_predict_grad(self._h, _lib.ptr(x), c, _lib.ptr(mean), _lib.ptr(var),

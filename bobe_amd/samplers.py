@@ -241,7 +241,7 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
 
     def logp_and_grad(U):
         X = np.clip(expit(U), 1e-12, 1.0 - 1e-12)
-        m, _, dm, _ = base_gp_grad(X)
+        m, _, dm, _ = base_gp_grad(X, mean_only=True)
         mean = m * gp.y_std + gp.y_mean
         gx = dm * gp.y_std
         if gated:                                              # classifier gate (clf_gp.py:173-205)

@@ -121,7 +121,8 @@ int bobe_gp_acq_ei(bobe_gp_t* gp, const double* Xq, int64_t C, double best_y, do
 /* Input gradients of GP.predict_single (gp.py:476-489) — what the reference obtains by differentiating through
  * the GP with JAX (EI restarts acquisition.py:246-253/281-290; NUTS on predict_mean_batched samplers.py:268-276).
  * mean, var (may be NULL): as bobe_gp_predict with nan_policy 1.  dmean, dvar: C x d, derivatives with respect
- * to the query coordinates, standardised units; dvar is 0 where var sits at its 1e-12 floor (gradient of where). */
+ * to the query coordinates, standardised units; dvar is 0 where var sits at its 1e-12 floor (gradient of where).
+ * var == dvar == NULL selects the mean-only mode (one small kernel, no K(X,C)): what HMC on the surrogate calls. */
 int bobe_gp_predict_grad(bobe_gp_t* gp, const double* Xq, int64_t C, double* mean, double* var, double* dmean,
                          double* dvar);
 

@@ -535,6 +535,18 @@ def test_predict_grad_against_central_differences(kernel, d):
     assert v0[0] >= 1e-12 and np.all(np.isfinite(dv0))
 
 
+def test_predict_grad_mean_only_mode():
+    """var = dvar = NULL: the one-kernel mode used by HMC returns the same mean and mean gradient."""
+    X, y = smooth_data(333, 5, seed=9)
+    gp = GP(X, y, noise=1e-6, kernel="matern", lengthscales=np.full(5, 0.6), kernel_variance=1.2)
+    q = np.random.default_rng(1).uniform(size=(77, 5))
+    m, v, dm, dv = gp.predict_grad(q)
+    m1, v1, dm1, dv1 = gp.predict_grad(q, mean_only=True)
+    assert v1 is None and dv1 is None
+    assert np.allclose(m1, m, rtol=1e-12, atol=1e-12) and np.allclose(dm1, dm, rtol=1e-12, atol=1e-12)
+    assert np.allclose(m1, gp.predict_batched(q)[0], rtol=1e-11, atol=1e-11)
+
+
 def test_ei_analytic_gradient_matches_finite_differences():
     from bobe_amd import EI, LogEI
     X, y = ref_data(30, 2)
