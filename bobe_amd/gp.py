@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 from . import priors as P
-from .optim import optimize_scipy
+from .optim import optimize_optax, optimize_scipy
 from .utils import get_logger, get_numpy_rng
 
 log = get_logger("gp")
@@ -94,9 +94,7 @@ class GP:
                    "bobe_gp_create")
 
         self.optimizer_method = optimizer
-        if optimizer != "scipy":
-            log.warning("only the scipy optimiser is implemented (optax variants are out of scope); using scipy")
-        self.mll_optimize = optimize_scipy
+        self.mll_optimize = optimize_scipy if optimizer == "scipy" else optimize_optax          # gp.py:264-267
         self.optimizer_options = optimizer_options
         self.concurrent_restarts = True        # fit(): the restarts run concurrently, one evaluation slot each
         self.restart_slots = 4                 # evaluations in flight at once (more than 4 oversubscribes the queues)

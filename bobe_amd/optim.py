@@ -216,3 +216,140 @@ def optimize_scipy(value_and_grad: Callable, num_params: int = 1, bounds=None, x
     if best_x is None:
         best_x = np.array(x0[0])
     return np.asarray(best_x), float(best_f)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# first-order optimisers (BOBE/optim.py:18-247: optimize_optax / optimize_optax_vmap)
+# --------------------------------------------------------------------------------------------------------------
+class _FirstOrder:
+    """The two optax transformations the reference names explicitly (optim.py:30-33), restated: ``adam`` (b1 = 0.9,
+    b2 = 0.999, eps = 1e-8, bias-corrected, update -lr * m_hat / (sqrt(v_hat) + eps)) and ``sgd`` (optional
+    ``momentum``).  State arrays carry a leading restart axis so that the vectorised driver updates all restarts at
+    once."""
+
+    def __init__(self, name: str, learning_rate: float, **kw):
+        self.name = name.lower()
+        if self.name not in ("adam", "sgd"):
+            raise ValueError(f"Optimizer '{name}' is not available (adam and sgd are built)")
+        self.lr = float(kw.pop("learning_rate", learning_rate))
+        self.b1, self.b2, self.eps = float(kw.pop("b1", 0.9)), float(kw.pop("b2", 0.999)), float(kw.pop("eps", 1e-8))
+        self.momentum = kw.pop("momentum", None)
+        if kw:
+            raise ValueError(f"unsupported optimizer options: {sorted(kw)}")
+
+    def init(self, params):
+        z = np.zeros_like(params)
+        return {"t": 0, "m": z.copy(), "v": z.copy()}
+
+    def update(self, grad, state):
+        state["t"] += 1
+        if self.name == "sgd":
+            if self.momentum:
+                state["m"] = self.momentum * state["m"] + grad
+                return -self.lr * state["m"]
+            return -self.lr * grad
+        state["m"] = self.b1 * state["m"] + (1.0 - self.b1) * grad
+        state["v"] = self.b2 * state["v"] + (1.0 - self.b2) * grad * grad
+        m_hat = state["m"] / (1.0 - self.b1 ** state["t"])
+        v_hat = state["v"] / (1.0 - self.b2 ** state["t"])
+        return -self.lr * m_hat / (np.sqrt(v_hat) + self.eps)
+
+
+def _first_order_setup(optimizer_options, num_params, bounds, x0, n_restarts, exact_restarts):
+    options = dict(optimizer_options if optimizer_options is not None else {})
+    patience = options.pop("early_stop_patience", 25)                      # optim.py:104-106
+    lr = options.pop("lr", 1e-3)
+    opt = _FirstOrder(options.pop("name", "adam"), lr, **options)
+    if x0 is None:
+        raise ValueError("x0 must be provided (shape: (n_restarts, num_params))")
+    x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
+    if (x0.shape[0] != n_restarts) if exact_restarts else (x0.shape[0] < n_restarts):
+        raise ValueError(f"x0 provided with {x0.shape[0]} restarts but n_restarts={n_restarts}")
+    bounds_arr = _setup_bounds(bounds, num_params)
+    if bounds_arr is not None:
+        span = bounds_arr[1] - bounds_arr[0]
+
+        def to_x(u):
+            return u * span + bounds_arr[0]                                # scale_from_unit
+    else:
+        span = None
+
+        def to_x(u):
+            return u
+    return opt, patience, x0[:n_restarts], bounds_arr, span, to_x
+
+
+def optimize_optax(value_and_grad: Callable, num_params: int = 1, bounds=None, x0=None,
+                   optimizer_options: Optional[dict] = None, maxiter: int = 200, n_restarts: int = 1,
+                   verbose: bool = False) -> Tuple[np.ndarray, float]:
+    """Restart-after-restart first-order minimisation, the loop of BOBE/optim.py:71-163 with ``value_and_grad(x) ->
+    (f, g)`` in place of ``jax.value_and_grad(fun)``: the iterate lives in unit coordinates of ``bounds`` and is
+    clipped to [0, 1] after every step; a restart stops after ``early_stop_patience`` steps without a new best value;
+    the value reported for a restart is the best value seen, the point its LAST iterate (optim.py:156-158).
+    As in the reference, the rows of ``x0`` are taken as they are as the first iterates (optim.py:138)."""
+    opt, patience0, x0, bounds_arr, span, to_x = _first_order_setup(optimizer_options, num_params, bounds, x0, n_restarts, False)
+
+    def vg_unit(u):
+        f, g = value_and_grad(to_x(u))
+        return float(f), (np.asarray(g, dtype=np.float64) * span if span is not None else np.asarray(g, dtype=np.float64))
+
+    best_f, best_u = np.inf, None
+    for x_init in x0:                                                      # optim.py:124-132
+        try:
+            val = vg_unit(x_init)[0]
+            if np.isfinite(val) and val < best_f:
+                best_f, best_u = val, np.array(x_init)
+        except Exception as e:  # pragma: no cover
+            log.warning(f"  Initial point: failed with {e}")
+    for x_init in x0:                                                      # optim.py:134-160
+        u = np.array(x_init)
+        state = opt.init(u)
+        best_restart, patience = np.inf, patience0
+        for _ in range(maxiter):
+            f, g = vg_unit(u)
+            u = u + opt.update(g, state)
+            if bounds_arr is not None:
+                u = np.clip(u, 0.0, 1.0)
+            if f < best_restart:
+                best_restart, patience = f, patience0
+            else:
+                patience -= 1
+                if patience == 0:
+                    break
+        if best_restart < best_f:
+            best_f, best_u = best_restart, u
+    if best_u is None:
+        best_u = np.array(x0[0])
+    return np.asarray(to_x(best_u)), float(best_f)
+
+
+def optimize_optax_vmap(batch_value_and_grad: Callable, num_params: int = 1, bounds=None, x0=None,
+                        optimizer_options: Optional[dict] = None, maxiter: int = 200, n_restarts: int = 1,
+                        verbose: bool = False) -> Tuple[np.ndarray, float]:
+    """All restarts step together (BOBE/optim.py:166-247, ``jax.vmap`` over restarts): one call of
+    ``batch_value_and_grad(list of x) -> list of (f, g)`` per iteration — on this engine one ``bobe_gp_mll_batch``
+    with every restart's evaluation in flight.  Per-restart best value / best iterate bookkeeping and the joint
+    early stop of optim.py:228-236."""
+    opt, patience0, x0, bounds_arr, span, to_x = _first_order_setup(optimizer_options, num_params, bounds, x0, n_restarts, True)
+    U = np.array(x0)
+    state = opt.init(U)
+    best_vals = np.full(n_restarts, np.inf)
+    best_params = np.zeros_like(U)
+    patience = np.full(n_restarts, patience0, dtype=np.int64)
+    for _ in range(maxiter):
+        out = batch_value_and_grad([to_x(u) for u in U])
+        vals = np.array([float(o[0]) for o in out])
+        G = np.array([np.asarray(o[1], dtype=np.float64) for o in out])
+        if span is not None:
+            G = G * span
+        U = U + opt.update(G, state)
+        if bounds_arr is not None:
+            U = np.clip(U, 0.0, 1.0)
+        improved = vals < best_vals
+        best_vals = np.where(improved, vals, best_vals)
+        best_params = np.where(improved[:, None], U, best_params)
+        patience = np.where(improved, patience0, patience - 1)
+        if np.all(patience <= 0):
+            break
+    i = int(np.argmin(best_vals))
+    return np.asarray(to_x(best_params[i])), float(best_vals[i])

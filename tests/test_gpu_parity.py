@@ -786,3 +786,22 @@ def test_module_level_kernel_helpers():
                        O.matern_kernel(A, A, ls, 0.7, 1e-3, include_noise=True), rtol=1e-13, atol=1e-15)
     assert np.array_equal(kernel_diag(A, 1.3, 1e-6), O.kernel_diag(A, 1.3, 1e-6))
     assert np.array_equal(kernel_diag(A, 1.3, 1e-6, include_noise=False), np.full(37, 1.3))
+
+
+def test_first_order_fit_paths():
+    """optimizer != 'scipy' selects the optax-style loop (gp.py:264-267); the vectorised variant drives every
+    restart's evaluation through one bobe_gp_mll_batch per step and finds what the sequential loop finds."""
+    from bobe_amd.optim import optimize_optax, optimize_optax_vmap
+    X, y = ref_data(60, 2)
+    gp = GP(X, y, noise=1e-6, optimizer="adam", optimizer_options={"name": "adam", "lr": 0.02, "early_stop_patience": 30})
+    assert gp.mll_optimize is optimize_optax
+    u0 = np.array([[0.5, 0.5, 0.5], [0.3, 0.6, 0.4], [0.7, 0.4, 0.6]])      # unit coordinates of the log-bounds
+    f0 = min(gp.neg_mll(gp.hyperparam_bounds[0] + u * (gp.hyperparam_bounds[1] - gp.hyperparam_bounds[0])) for u in u0)
+    r = gp.fit(x0=u0, maxiter=60)
+    assert np.isfinite(r["mll"]) and -r["mll"] < f0                          # improved on the best start
+    opts = {"name": "adam", "lr": 0.02, "early_stop_patience": 30}
+    xs, fs = optimize_optax(gp.neg_mll_value_and_grad, gp.num_hyperparams, gp.hyperparam_bounds, u0, dict(opts), 60, 3)
+    xv, fv = optimize_optax_vmap(gp.neg_mll_value_and_grad_batch, gp.num_hyperparams, gp.hyperparam_bounds, u0,
+                                 dict(opts), 60, 3)
+    assert fv == pytest.approx(fs, rel=1e-12)                                # same arithmetic, batched evaluations
+    assert -r["mll"] == pytest.approx(fs, rel=1e-12)

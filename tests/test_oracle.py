@@ -238,3 +238,45 @@ def test_c_restatement_not_positive_definite_is_nan():
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.7, 0.3]])
     info, mll, grad, L, alpha = OC.mll(0, X, np.array([1.0, -1.0, 0.0]), np.array([0.5, 0.5]), 1.0, 0.0)
     assert info > 0 and np.isnan(mll) and np.all(np.isnan(grad)) and np.all(np.isnan(L)) and np.all(np.isnan(alpha))
+
+
+# ---- host logic: the first-order optimisers restated from optax (bobe_amd/optim.py), against torch.optim -------
+@pytest.mark.parametrize("name,kw", [("adam", {}), ("sgd", {}), ("sgd", {"momentum": 0.9})])
+def test_first_order_optimisers_follow_torch(name, kw):
+    import torch
+    from bobe_amd.optim import optimize_optax, optimize_optax_vmap
+
+    A = np.array([[3.0, 0.5, 0.0], [0.5, 2.0, 0.3], [0.0, 0.3, 1.0]])
+    c = np.array([0.7, 0.2, 0.4])
+
+    def vg(x):
+        r = np.asarray(x) - c
+        return float(0.5 * r @ A @ r + 0.1 * np.sum(np.sin(3 * x))), A @ r + 0.3 * np.cos(3 * np.asarray(x))
+
+    x0 = np.array([[0.1, 0.9, 0.5], [0.8, 0.1, 0.2]])
+    lr, steps = 0.05, 40
+    # independent trajectory with torch (unit bounds [0, 1]: the scaling is the identity, clipping after each step)
+    finals, bests = [], []
+    for row in x0:
+        p = torch.tensor(row, dtype=torch.float64, requires_grad=True)
+        opt = torch.optim.Adam([p], lr=lr, eps=1e-8) if name == "adam" else torch.optim.SGD([p], lr=lr, **kw)
+        best = np.inf
+        for _ in range(steps):
+            f, g = vg(p.detach().numpy())
+            best = min(best, f)
+            p.grad = torch.tensor(g)
+            opt.step()
+            with torch.no_grad():
+                p.clamp_(0.0, 1.0)
+        finals.append(p.detach().numpy().copy())
+        bests.append(best)
+    i = int(np.argmin(bests))
+    options = {"name": name, "lr": lr, "early_stop_patience": 1000, **kw}
+    x, f = optimize_optax(vg, num_params=3, bounds=[0.0, 1.0], x0=x0, optimizer_options=dict(options), maxiter=steps,
+                          n_restarts=2)
+    assert f == pytest.approx(bests[i], rel=1e-12) and np.allclose(x, finals[i], atol=1e-12)
+    xv, fv = optimize_optax_vmap(lambda xs: [vg(q) for q in xs], num_params=3, bounds=[0.0, 1.0], x0=x0,
+                                 optimizer_options=dict(options), maxiter=steps, n_restarts=2)
+    assert fv == pytest.approx(bests[i], rel=1e-12)
+    with pytest.raises(ValueError):
+        optimize_optax(vg, 3, [0.0, 1.0], x0, {"name": "lbfgs"}, 5, 2)
