@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="headline", choices=["tiny", "small", "headline"])
+    ap.add_argument("--config", default="headline", choices=["tiny", "small", "headline", "large"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-class", default="trimul", help="kernel class timed with HIP events for the roofline")
     ap.add_argument("--fit-concurrency", type=int, default=4,
@@ -284,7 +284,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic RBF GP N={N} d={d}, {Cn} candidates per GPU, M={M}, fp64 "
-                                   f"(BASELINE.json configs[{2 if args.config == 'headline' else 1}])",
+                                   + {"headline": "(BASELINE.json configs[2])", "small": "(BASELINE.json configs[1])"}.get(
+                                       args.config, "(not a BASELINE.json config)"),
                        "N": N, "d": d, "candidates_per_gpu": Cn, "M": M, "evals_per_cycle": len(thetas),
                        "fit": f"{R} restarts x {len(thetas) // R} value+gradient evaluations, restarts concurrent ({args.fit_mode})"
                               if R > 1 else f"{len(thetas)} sequential value+gradient evaluations",

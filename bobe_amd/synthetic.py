@@ -13,6 +13,9 @@ CONFIGS = {
     "tiny": (256, 4, 1024, 128),
     "small": (1024, 6, 8192, 512),
     "headline": (4096, 8, 65536, 512),
+    # not in BASELINE.json: a 4x larger training set with twice the candidates, to show where the engine goes with
+    # size (the synthetic prior draw needs an O(N^3) CPU Cholesky: ~20 s at this N)
+    "large": (8192, 8, 131072, 512),
 }
 
 
