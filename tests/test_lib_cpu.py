@@ -131,3 +131,49 @@ def test_compute_integrals_closed_form_and_resampling():
     assert np.allclose(w, [0.1, 0.3, 0.6])
     xs, ls = resample_equal(np.arange(3)[:, None], np.arange(3.0), w, rng=np.random.default_rng(0))
     assert xs.shape == (3, 1) and set(xs.ravel()) <= {0, 1, 2}
+
+
+def test_concurrent_restart_drivers_equal_the_sequential_loop():
+    """Host logic of the restart concurrency (no GPU): the slot driver (one thread per slot, restarts dealt round
+    robin) and the lock-step batch driver must return exactly what the one-after-the-other loop returns."""
+    from bobe_amd.optim import optimize_scipy
+
+    def vg(x):
+        x = np.asarray(x)
+        f = float(np.sum(100 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+        g = np.zeros_like(x)
+        g[:-1] += -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        return f, g
+
+    x0 = np.random.default_rng(0).uniform(-2, 2, size=(7, 4))
+    seq = optimize_scipy(vg, 4, [-3, 3], x0, n_restarts=7)
+    slot_calls, batch_sizes = [], []
+
+    def slot_vg(x, slot):
+        slot_calls.append(slot)
+        return vg(x)
+
+    def batch_vg(xs):
+        batch_sizes.append(len(xs))
+        return [vg(x) for x in xs]
+
+    slots = optimize_scipy(vg, 4, [-3, 3], x0, n_restarts=7, slot_value_and_grad=slot_vg, n_slots=3)
+    batch = optimize_scipy(vg, 4, [-3, 3], x0, n_restarts=7, batch_value_and_grad=batch_vg)
+    assert np.array_equal(seq[0], slots[0]) and seq[1] == slots[1]
+    assert np.array_equal(seq[0], batch[0]) and seq[1] == batch[1]
+    assert set(slot_calls) == {0, 1, 2}                      # never more workers than slots
+    assert max(batch_sizes) == 7 and min(batch_sizes) >= 1   # rounds shrink as restarts finish
+
+
+def test_small_host_helpers():
+    from bobe_amd.dist_sweep import dist_info, shard_bounds
+    from bobe_amd.samplers import get_hmc_settings, prior_transform
+    from bobe_amd.utils import get_threshold_for_nsigma
+    assert dist_info() == (1, 0, None)                       # no process group: single rank
+    assert [shard_bounds(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]     # np.array_split boundaries
+    assert get_hmc_settings(4) == (256, 1024, 4) and get_hmc_settings(10, thinning=2) == (512, 2048, 2)
+    assert prior_transform(0.3) == 0.3
+    # utils/core.py:150-167: 1 sigma in 1-D is half a chi-square unit; grows with the dimension
+    assert get_threshold_for_nsigma(1.0, 1) == pytest.approx(0.5, rel=1e-9)
+    assert get_threshold_for_nsigma(2.0, 2) > get_threshold_for_nsigma(2.0, 1) > get_threshold_for_nsigma(1.0, 1)
