@@ -49,6 +49,8 @@ SIGNATURES = [
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     c_int64_p, c_double_p, c_int64_p, c_double_p]),
     ("bobe_gp_fantasy_var", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]),
+    ("bobe_gp_wip_grad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_acq_ei", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     ("bobe_gp_predict_grad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),

@@ -4,10 +4,10 @@ WIPV / WIPStd evaluate every candidate in ONE call of ``bobe_gp_wip_sweep`` (the
 ``fun`` over the candidates sequentially with ``lax.map``, acquisition.py:390-394).  EI / LogEI are
 pointwise scorers on the batched posterior (``bobe_gp_acq_ei``).
 
-Where the reference differentiates ``fun`` with JAX: EI / LogEI restarts (acquisition.py:281-290) use the
-analytic posterior gradients of ``bobe_gp_predict_grad``; the WIPV / WIPStd local refinement for N <= 500
-(acquisition.py:403-412) uses batched forward differences evaluated on the GPU (d+1 points per gradient in
-one call) — the one stated deviation, because a C-ABI GP is opaque to autodiff.
+Where the reference differentiates ``fun`` with JAX the build has explicit gradient entry points: EI / LogEI
+restarts (acquisition.py:281-290) use the analytic posterior gradients of ``bobe_gp_predict_grad``, the WIPV /
+WIPStd local refinement for N <= 500 (acquisition.py:403-412) the analytic score gradients of
+``bobe_gp_wip_grad``.
 """
 from __future__ import annotations
 
@@ -22,7 +22,6 @@ from .utils import get_logger, get_numpy_rng
 
 log = get_logger("acq")
 
-_FD_STEP = 1e-6
 
 
 class AcquisitionFunction:
@@ -171,11 +170,9 @@ class WeightedIntegratedPosteriorBase(AcquisitionFunction):
         if gp.train_x.shape[0] > 500:                                          # acquisition.py:400-401
             return best_x, best_val
 
-        def vg(x):
-            x = np.asarray(x, dtype=np.float64)
-            pts = np.vstack([x] + [x + _FD_STEP * e for e in np.eye(len(x))])
-            v = self.fun(pts, gp, mc_points=mc_points)
-            return float(v[0]), (v[1:] - v[0]) / _FD_STEP
+        def vg(x):                                    # value and exact gradient in one call (bobe_gp_wip_grad)
+            wv, ws, dv, ds = gp.wip_grad(np.asarray(x, dtype=np.float64)[None, :], mc_points)
+            return (float(wv[0]), dv[0]) if self._key == "wipv" else (float(ws[0]), ds[0])
         return self.acq_optimize(vg, num_params=gp.ndim, x0=best_x, bounds=[0, 1],
                                  optimizer_options=dict(self.optimizer_options), maxiter=maxiter,
                                  n_restarts=n_restarts, verbose=verbose)

@@ -1193,6 +1193,63 @@ int bobe_gp_fantasy_var(bobe_gp_t* g, const double* cand, int64_t C, const doubl
   API_END
 }
 
+int bobe_gp_wip_grad(bobe_gp_t* g, const double* cand, int64_t C, const double* Z, int64_t M, double y_std,
+                     double* wipv, double* wipstd, double* dwipv, double* dwipstd) {
+  API_BEGIN
+  if (!g || !cand || !Z) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  if (C <= 0 || M <= 0) throw Err(BOBE_ERR_ARG, "C and M must be positive");
+  g->use();
+  const int d = g->d, nb = g->nb;
+  const int64_t Np = g->Np, Mp = round_up(M, TILE), CH = std::min<int64_t>(g->chunk, 1024);
+  const double kself = g->hyp.kvar + g->hyp.noise;
+  const double* cin = g->fetch(cand, (size_t)C * d, g->in_stage);
+  g->prepare_z(Z, M, Mp);                                   // ZsT, W_Z = K^-1 K(X,Z), base_z
+  g->CsT.ensure((size_t)d * std::max<int64_t>(CH, g->chunk) * sizeof(double));
+  g->kXC.ensure((size_t)Np * std::max<int64_t>(CH, g->chunk) * sizeof(double));
+  g->pv.ensure((size_t)Np * CH * sizeof(double));           // V = Linv k_c
+  g->ps.ensure((size_t)Np * CH * sizeof(double));           // U = K^-1 k_c
+  g->qpart.ensure((size_t)nb * std::max<int64_t>(std::max<int64_t>(CH, g->chunk), Mp) * sizeof(double));
+  g->sc.ensure((size_t)std::max<int64_t>(CH, g->chunk) * sizeof(double));
+  double* d_v = g->out_dev(wipv, C, g->o_wipv);
+  double* d_s = g->out_dev(wipstd, C, g->o_wipstd);
+  double* d_dv = g->out_dev(dwipv, (size_t)C * d, g->o_mean);
+  double* d_ds = g->out_dev(dwipstd, (size_t)C * d, g->o_var);
+  const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+  for (int64_t c0 = 0; c0 < C; c0 += CH) {
+    const int64_t nc = std::min<int64_t>(CH, C - c0), ncp = round_up(nc, TILE);
+    g->scale(cin + c0 * d, nc, ncp, g->hyp, g->CsT.d(), CH);
+    g->kernel_matrix_cross(g->XsT.d(), Np, g->N, Np, g->CsT.d(), CH, nc, ncp, g->hyp, g->kXC.d(), CH);
+    hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, g->stream,
+                       (const double*)g->Linv.d(), Np, nb, (const double*)g->kXC.d(), CH, g->pv.d(), CH, g->qpart.d(), CH,
+                       (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, g->stream,
+                       (const double*)g->qpart.d(), CH, nb, nc, kself, 1, g->sc.d(), (double*)nullptr);
+    hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, g->stream,
+                       (const double*)g->Linv.d(), Np, nb, (const double*)g->pv.d(), CH, g->ps.d(), CH);
+#define WG(KE, DC)                                                                                                   \
+  hipLaunchKernelGGL((k_wip_grad<KE, DC>), dim3((unsigned)nc), dim3(256), 0, g->stream, (const double*)g->XsT.d(), Np,  \
+                     g->N, (const double*)g->CsT.d(), CH, (const double*)g->ZsT.d(), Mp, M, (const double*)g->WZ.d(),  \
+                     Mp, (const double*)g->ps.d(), CH, (const double*)g->sc.d(), (const double*)g->basez.d(), g->hyp,  \
+                     y_std * y_std, d_v ? d_v + c0 : nullptr, d_s ? d_s + c0 : nullptr, d_dv ? d_dv + c0 * d : nullptr, \
+                     d_ds ? d_ds + c0 * d : nullptr)
+    if (g->hyp.kern == 0) {
+      if (dcap == 8) WG(0, 8); else if (dcap == 16) WG(0, 16); else WG(0, 32);
+    } else {
+      if (dcap == 8) WG(1, 8); else if (dcap == 16) WG(1, 16); else WG(1, 32);
+    }
+#undef WG
+    LAUNCH_CHECK();
+  }
+  g->out_finish(wipv, C, g->o_wipv);
+  g->out_finish(wipstd, C, g->o_wipstd);
+  g->out_finish(dwipv, (size_t)C * d, g->o_mean);
+  g->out_finish(dwipstd, (size_t)C * d, g->o_var);
+  g->sync();
+  return BOBE_OK;
+  API_END
+}
+
 int bobe_gp_acq_ei(bobe_gp_t* g, const double* Xq, int64_t C, double best_y, double zeta, int mode, double* out) {
   API_BEGIN
   if (!g || !Xq || !out) throw Err(BOBE_ERR_ARG, "NULL argument");

@@ -524,6 +524,171 @@ __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__
   }
 }
 
+// ---- WIPV / WIPStd and their gradients w.r.t. the candidate coordinates ---------------------------------------
+// (what the reference gets from jax.grad of WIPV.fun / WIPStd.fun in the local refinement, acquisition.py:403-412)
+// One workgroup per candidate c.  With s = kself - k_c^T K^-1 k_c, u = K^-1 k_c, W = K^-1 K(X,Z):
+//   cross_z      = k(z,x) - sum_n W[n][z] k(x_n,x)
+//   var+_z       = base_z - cross_z^2 / s                       (floors of gp.py:574-575; floored terms have zero gradient)
+//   d cross_z/dx_j = [G_z (s_zj - s_xj) - sum_n W[n][z] G_n (s_nj - s_xj)] / ls_j,   d s/dx_j = -2 sum_n u_n G_n (s_nj - s_xj) / ls_j
+//   d var+_z/dx_j = -2 cross_z/s * d cross_z/dx_j + cross_z^2/s^2 * d s/dx_j
+// (s_a = a / ls, G = dk/d(-r^2/2): k itself for RBF, the Matern-5/2 factor otherwise).  Fixed summation order.
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_wip_grad(const double* __restrict__ XsT, int64_t ldx, int64_t n,
+                                                  const double* __restrict__ CsT, int64_t ldc,
+                                                  const double* __restrict__ ZsT, int64_t ldz, int64_t m,
+                                                  const double* __restrict__ W, int64_t ldw,
+                                                  const double* __restrict__ U, int64_t ldu,
+                                                  const double* __restrict__ sc, const double* __restrict__ basez, Hyper h,
+                                                  double ystd2, double* __restrict__ wipv, double* __restrict__ wipstd,
+                                                  double* __restrict__ dwipv, double* __restrict__ dwipstd) {
+  constexpr int NT = 128;
+  __shared__ double T[DCAP][NT];      // G_n (s_nj - s_xj) of the staged training points
+  __shared__ double kcv[NT];          // k(x_n, x)
+  __shared__ double dsred[NT];
+  __shared__ double ds[DCAP];         // sum_n u_n T[j][n]
+  __shared__ double red[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t c = blockIdx.x;
+  double xc[DCAP];
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) xc[j] = (j < h.d) ? CsT[j * ldc + c] : 0.0;
+  const double s = sc[c];
+  const bool sbad = !(s >= 0.0);
+
+  // stage one chunk of training points: T, kcv (threads 0..127), returns this thread's u_n
+  auto stage = [&](int64_t n0) -> double {
+    double un = 0.0;
+    if (t < NT) {
+      const int64_t nn = n0 + t;
+      double df[DCAP];
+      double r2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) {
+        df[j] = (j < h.d && nn < n) ? XsT[j * ldx + nn] - xc[j] : 0.0;
+        r2 += df[j] * df[j];
+      }
+      const double kv = (nn < n) ? kern_eval<KERN>(r2, h.kvar) : 0.0;
+      const double g = (nn < n) ? kern_grad_factor<KERN>(r2, h.kvar, kv) : 0.0;
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) T[j][t] = g * df[j];
+      kcv[t] = kv;
+      un = (nn < n) ? U[nn * ldu + c] : 0.0;
+    }
+    return un;
+  };
+
+  // pass 0: ds_j = sum_n u_n T[j][n]
+  double dsa[DCAP];
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) dsa[j] = 0.0;
+  for (int64_t n0 = 0; n0 < n; n0 += NT) {
+    __syncthreads();
+    const double un = stage(n0);
+    if (t < NT) {
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) dsa[j] += un * T[j][t];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) {
+    if (j < h.d) {                     // uniform
+      __syncthreads();
+      if (t < NT) dsred[t] = dsa[j];
+      __syncthreads();
+      if (t == 0) {
+        double a = 0.0;
+        for (int q = 0; q < NT; ++q) a += dsred[q];
+        ds[j] = a;
+      }
+    }
+  }
+  __syncthreads();
+
+  // z passes: one integration point per thread and pass
+  double sv = 0.0, ss = 0.0, gv[DCAP], gs[DCAP];
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) gv[j] = gs[j] = 0.0;
+  for (int64_t zb = 0; zb < m; zb += 256) {
+    const int64_t z = zb + t;
+    const bool live = z < m;
+    double acck = 0.0, accw[DCAP];
+#pragma unroll
+    for (int j = 0; j < DCAP; ++j) accw[j] = 0.0;
+    for (int64_t n0 = 0; n0 < n; n0 += NT) {
+      __syncthreads();
+      (void)stage(n0);
+      __syncthreads();
+      if (live) {
+        const int nn_end = (n - n0 < NT) ? (int)(n - n0) : NT;
+        for (int nn = 0; nn < nn_end; ++nn) {
+          const double w = W[(n0 + nn) * ldw + z];
+          acck = __builtin_fma(w, kcv[nn], acck);
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) accw[j] = __builtin_fma(w, T[j][nn], accw[j]);
+        }
+      }
+    }
+    if (live) {
+      double dz[DCAP];
+      double r2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) {
+        dz[j] = (j < h.d) ? ZsT[j * ldz + z] - xc[j] : 0.0;
+        r2 += dz[j] * dz[j];
+      }
+      const double kz = kern_eval<KERN>(r2, h.kvar);
+      const double gz = kern_grad_factor<KERN>(r2, h.kvar, kz);
+      const double cross = kz - acck;
+      double v = basez[z] - (cross * cross) / s;
+      bool floored = sbad;
+      if (v != v) floored = true;
+      if (v < NOISE_FLOOR) floored = true;
+      if (floored) v = NOISE_FLOOR;
+      const double vs = v * ystd2;
+      const double sq = sqrt(vs);
+      sv += vs;
+      ss += sq;
+      if (!floored) {
+        const double a1 = -2.0 * cross / s, a2 = (cross * cross) / (s * s);
+#pragma unroll
+        for (int j = 0; j < DCAP; ++j) {
+          if (j < h.d) {
+            const double dcross = (gz * dz[j] - accw[j]) / h.ls[j];
+            const double dsj = -2.0 * ds[j] / h.ls[j];
+            const double dv = (a1 * dcross + a2 * dsj) * ystd2;
+            gv[j] += dv;
+            gs[j] += dv / (2.0 * sq);
+          }
+        }
+      }
+    }
+  }
+  // block reductions in a fixed order: lanes by butterfly, then the four waves
+  auto block_sum = [&](double x) -> double {
+    const double wsum = wave_sum(x);
+    __syncthreads();
+    if (lane == 0) red[wave] = wsum;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  const double inv_m = 1.0 / (double)m;
+  const double tv = block_sum(sv), ts = block_sum(ss);
+  if (t == 0) {
+    if (wipv) wipv[c] = tv * inv_m;
+    if (wipstd) wipstd[c] = ts * inv_m;
+  }
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) {
+    if (j < h.d) {                     // uniform
+      const double a = block_sum(gv[j]), b = block_sum(gs[j]);
+      if (t == 0) {
+        if (dwipv) dwipv[c * h.d + j] = a * inv_m;
+        if (dwipstd) dwipstd[c * h.d + j] = b * inv_m;
+      }
+    }
+  }
+}
+
 // mode 0: EI, 1: LogEI.  out = +EI / +logEI (the reference minimises the negative)
 __global__ void k_ei(const double* __restrict__ mu, const double* __restrict__ var, int64_t n, double best_y, double zeta,
                      int mode, double* __restrict__ out) {

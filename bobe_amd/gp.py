@@ -451,6 +451,20 @@ class GP:
                                             1 if log_ei else 0, _lib.ptr(out)), "bobe_gp_acq_ei")
         return out
 
+    def wip_grad(self, candidates, mc_points):
+        """(wipv, wipstd, dwipv/dx, dwipstd/dx) of the candidates — values and input gradients of ``WIPV.fun`` /
+        ``WIPStd.fun`` (acquisition.py:438-465), the gradient being what the reference takes with ``jax.grad`` in the
+        local refinement (acquisition.py:403-412).  Physical units (the y_std factors of gp.py:576 included)."""
+        cand = _lib.as_f64(np.atleast_2d(candidates))
+        z = _lib.as_f64(np.atleast_2d(mc_points))
+        c = cand.shape[0]
+        wipv, wipstd = np.empty(c), np.empty(c)
+        dv, ds = np.empty((c, self.ndim)), np.empty((c, self.ndim))
+        _lib.check(self._lib.bobe_gp_wip_grad(self._h, _lib.ptr(cand), c, _lib.ptr(z), z.shape[0], float(self.y_std),
+                                              _lib.ptr(wipv), _lib.ptr(wipstd), _lib.ptr(dv), _lib.ptr(ds)),
+                   "bobe_gp_wip_grad")
+        return wipv, wipstd, dv, ds
+
     def predict_grad(self, x, mean_only=False):
         """Standardised (mean, var, dmean/dx, dvar/dx) of ``predict_single`` (gp.py:476-489) for C points: what the
         reference gets by JAX autodiff through the GP (acquisition.py:246-253, samplers.py:268-276).

@@ -114,6 +114,13 @@ int bobe_gp_wip_sweep(bobe_gp_t* gp, const double* cand, int64_t C, const double
 int bobe_gp_fantasy_var(bobe_gp_t* gp, const double* cand, int64_t C, const double* Z, int64_t M, double y_std,
                         double* out);
 
+/* WIPV.fun / WIPStd.fun (acquisition.py:438-440, 463-465) of C candidates TOGETHER WITH their gradients with respect
+ * to the candidate coordinates - what the reference obtains with jax.grad in the local refinement of
+ * get_next_point (acquisition.py:403-412).  wipv, wipstd: C (may be NULL); dwipv, dwipstd: C x d (may be NULL).
+ * Integration points whose fantasy variance sits at the 1e-12 floor contribute no gradient (gradient of where). */
+int bobe_gp_wip_grad(bobe_gp_t* gp, const double* cand, int64_t C, const double* Z, int64_t M, double y_std,
+                     double* wipv, double* wipstd, double* dwipv, double* dwipstd);
+
 /* EI.fun / LogEI.fun (acquisition.py:226-253, 318-330) for C points: out[c] = +EI (mode 0) or
  * +log EI (mode 1); best_y, zeta in standardised units. */
 int bobe_gp_acq_ei(bobe_gp_t* gp, const double* Xq, int64_t C, double best_y, double zeta, int mode, double* out);

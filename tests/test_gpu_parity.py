@@ -805,3 +805,32 @@ def test_first_order_fit_paths():
                                  dict(opts), 60, 3)
     assert fv == pytest.approx(fs, rel=1e-12)                                # same arithmetic, batched evaluations
     assert -r["mll"] == pytest.approx(fs, rel=1e-12)
+
+
+@pytest.mark.parametrize("kernel,d,m", [("rbf", 3, 70), ("matern", 5, 300), ("rbf", 12, 33)])
+def test_wip_gradient_against_values_and_central_differences(kernel, d, m):
+    """bobe_gp_wip_grad: the scores equal the sweep's, the gradients equal central differences of the ORACLE's
+    WIPV / WIPStd (the reference differentiates the same functions with jax.grad, acquisition.py:403-412)."""
+    n = 160
+    X, y = smooth_data(n, d, seed=17)
+    ls = np.full(d, 0.6) * (1 + 0.05 * np.arange(d))
+    gp, og = both(X, 2.0 * y + 0.5, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.4)
+    rng = np.random.default_rng(5)
+    cand, Z = rng.uniform(0.1, 0.9, size=(9, d)), rng.uniform(size=(m, d))
+    wv, ws, dv, dsd = gp.wip_grad(cand, Z)
+    r = gp.wip_sweep(cand, Z)
+    assert np.allclose(wv, r["wipv"], rtol=1e-10) and np.allclose(ws, r["wipstd"], rtol=1e-10)
+    e = 1e-5
+    for c in range(3):
+        for j in range(d):
+            xp, xm = cand[c].copy(), cand[c].copy()
+            xp[j] += e
+            xm[j] -= e
+            ro_p, ro_m = O.wip_sweep(og, xp[None, :], Z), O.wip_sweep(og, xm[None, :], Z)
+            fd_v = (ro_p["wipv"][0] - ro_m["wipv"][0]) / (2 * e)
+            fd_s = (ro_p["wipstd"][0] - ro_m["wipstd"][0]) / (2 * e)
+            assert dv[c, j] == pytest.approx(fd_v, rel=2e-5, abs=1e-9 * og.y_std ** 2)
+            assert dsd[c, j] == pytest.approx(fd_s, rel=2e-5, abs=1e-9 * og.y_std)
+    # a candidate on top of a training point: s ~ noise, every fantasy variance is at or near its floor -> finite output
+    wv0, ws0, dv0, ds0 = gp.wip_grad(X[:2], Z)
+    assert np.all(np.isfinite(wv0)) and np.all(np.isfinite(dv0)) and np.all(np.isfinite(ds0))
