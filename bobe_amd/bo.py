@@ -148,6 +148,8 @@ class BOBE:
             refit_threshold, n_restarts, maxiter = max(40, fit_n_points), 4, 200
         refit = self.n_points_since_last_fit >= refit_threshold
         self.gp.update(new_pts_u, new_vals)
+        if getattr(self.gp, "not_pd", False):        # the new point made K numerically singular at the old
+            refit = True                             # hyper-parameters (NaN factor, like XLA): refit now
         if refit:
             gp_fit(self.gp, n_restarts=n_restarts, maxiters=maxiter, rng=self.np_rng)
             self.n_points_since_last_fit = 0

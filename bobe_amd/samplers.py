@@ -100,6 +100,11 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
 
     live = rng.uniform(size=(nlive, ndim))
     live_logl = loglike(live)
+    if not np.all(np.isfinite(live_logl)):               # a NaN surrogate (factor not positive definite): no evidence
+        log.warning("nested sampling skipped: the surrogate returns non-finite values")
+        nan = float("nan")
+        return ({"x": live, "weights": np.ones(nlive), "logl": live_logl, "best": live[0], "method": "nested"},
+                {"mean": nan, "dlogz_sampler": nan, "upper": nan, "lower": nan, "var": nan, "std": nan}, False)
     ncall = nlive
     dead_x, dead_logl = [], []
     logz = -np.inf

@@ -25,7 +25,8 @@ def test_two_rank_bo_run_retraces_single_process(tmp_path):
            os.path.join(ROOT, "tests", "workers", "dist_bo_worker.py"), str(out)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    two = json.load(open(out))
+    with open(out) as fh:
+        two = json.load(fh)
     assert two["n"] == single["n"]
     # same acquisition choices (the shard merge keeps argmin semantics) and the same fitted hyper-parameters
     # (the union of the ranks' restarts is the single-process restart set; max-by-mll picks the same optimum)
