@@ -1,4 +1,6 @@
-"""CPU regression: the oracle reproduces the committed golden vectors (tests/golden/make_golden.py)."""
+"""CPU regression: the oracle reproduces the committed golden vectors (tests/golden/make_golden.py), and — once
+somebody with the reference's environment has run tests/golden/make_reference_golden.py and committed its ref_*.npz —
+the reference's own outputs (those files are compared with tolerances that allow for XLA-vs-LAPACK rounding)."""
 import glob
 import os
 
@@ -34,4 +36,4 @@ def test_oracle_matches_golden(path):
     assert np.allclose(sw["wipv"], g["wipv"], rtol=1e-9, atol=1e-15)
     assert np.allclose(sw["wipstd"], g["wipstd"], rtol=1e-9, atol=1e-15)
     assert sw["argmin_v"] == int(g["argmin_v"]) and sw["argmin_s"] == int(g["argmin_s"])
-    assert len(GOLDEN) == 3
+    assert len(GOLDEN) >= 3
