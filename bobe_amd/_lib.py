@@ -65,6 +65,7 @@ SIGNATURES = [
     ("bobe_debug_linv", C.c_int, [C.c_void_p, C.c_void_p]),
     ("bobe_debug_time_potrf", C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     ("bobe_debug_time_potrf_batch", C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
+    ("bobe_debug_time_potrf_lockstep", C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
     ("bobe_gp_set_chunk", C.c_int, [C.c_void_p, C.c_int64]),
     ("bobe_gp_profile_select", C.c_int, [C.c_void_p, C.c_int]),
     ("bobe_gp_profile_read", C.c_int, [C.c_void_p, c_double_p, c_int64_p]),

@@ -58,6 +58,19 @@ def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.r
     return res
 
 
+def refit_policy(n_train_before: int, n_since_last_fit: int, n_new: int, fit_n_points: int):
+    """The size classes of ``update_gp`` (bo.py:632-655) -> (refit, n_restarts, maxiter, points since the last fit).
+    Strict '<' on both sides as in the reference: N == 200 and N >= 750 both land in the last branch."""
+    n_since = n_since_last_fit + n_new
+    if n_train_before < 200:
+        refit_threshold, maxiter, n_restarts = min(2, fit_n_points), 1000, 8
+    elif 200 < n_train_before < 750:
+        refit_threshold, n_restarts, maxiter = fit_n_points, 4, 500
+    else:
+        refit_threshold, n_restarts, maxiter = max(40, fit_n_points), 4, 200
+    return n_since >= refit_threshold, n_restarts, maxiter, n_since
+
+
 class BOBE:
     """``BOBE(loglikelihood, param_list, param_bounds, ...).run(acq=...)`` with the GP on a MI355X."""
 
@@ -67,7 +80,7 @@ class BOBE:
                  n_sobol_init: int = 16, init_train_x=None, init_train_y=None, resume: bool = False, resume_file=None,
                  save_dir: str = ".", save: bool = False, save_step: int = 5, optimizer: str = "scipy",
                  acq: str = "WIPV", use_clf: bool = False, clf_type: str = "svm", clf_nsigma_threshold: float = 20,
-                 clf_use_size: int = 10, clf_update_step: int = 1, minus_inf: float = -1e5,
+                 clf_use_size: int = 10, clf_update_step: int = 1, minus_inf: float = -1e10,
                  seed: Optional[int] = None, verbosity: str = "INFO", device: int = 0):
         """Keywords of the reference constructor (bo.py:69-96) plus ``device``.  ``loglikelihood`` must be a callable
         on physical parameters (Cobaya likelihoods and ``resume`` belong to the parts that are not built, DESIGN.md 7);
@@ -103,8 +116,7 @@ class BOBE:
         if init_train_x is not None and init_train_y is not None:
             pts = np.vstack([np.atleast_2d(np.asarray(init_train_x, dtype=np.float64)), pts])
             vals = np.vstack([np.asarray(init_train_y, dtype=np.float64).reshape(-1, 1), vals])
-        kw = dict(noise=1e-8, kernel="rbf", lengthscale_bounds=[0.01, 10], kernel_variance_bounds=[1e-4, 1e8],
-                  optimizer=optimizer)
+        kw = dict(optimizer=optimizer)               # everything else: the GP's own defaults, as bo.py:584-605 leaves them
         kw.update(gp_kwargs or {})
         t0 = time.time()
         x_u = scale_to_unit(pts, self.param_bounds)
@@ -136,17 +148,10 @@ class BOBE:
         return out
 
     def update_gp(self, new_pts_u: np.ndarray, new_vals: np.ndarray, fit_n_points: int) -> None:
-        """bo.py:620-668 — refit thresholds by training-set size (strict '<' as in the reference)."""
+        """bo.py:620-676 — count, decide (``refit_policy``), ``gp.update``, multi-restart fit, classifier retrain."""
         t0 = time.time()
-        self.n_points_since_last_fit += new_pts_u.shape[0]
-        n = self.gp.train_x.shape[0]
-        if n < 200:
-            refit_threshold, maxiter, n_restarts = min(2, fit_n_points), 1000, 8
-        elif 200 < n < 750:
-            refit_threshold, n_restarts, maxiter = fit_n_points, 4, 500
-        else:
-            refit_threshold, n_restarts, maxiter = max(40, fit_n_points), 4, 200
-        refit = self.n_points_since_last_fit >= refit_threshold
+        refit, n_restarts, maxiter, self.n_points_since_last_fit = refit_policy(
+            self.gp.train_x.shape[0], self.n_points_since_last_fit, new_pts_u.shape[0], fit_n_points)
         self.gp.update(new_pts_u, new_vals)
         if getattr(self.gp, "not_pd", False):        # the new point made K numerically singular at the old
             refit = True                             # hyper-parameters (NaN factor, like XLA): refit now
@@ -154,87 +159,161 @@ class BOBE:
             gp_fit(self.gp, n_restarts=n_restarts, maxiters=maxiter, rng=self.np_rng)
             self.n_points_since_last_fit = 0
         self.timing["GP Training"] += time.time() - t0
+        if hasattr(self.gp, "train_classifier"):     # bo.py:673-676: the labels move with the best value seen
+            t0 = time.time()
+            self.gp.train_classifier()
+            self.timing["Classifier Training"] = self.timing.get("Classifier Training", 0.0) + time.time() - t0
 
-    def run(self, acq=None, min_evals: int = 0, max_evals: int = 250, max_gp_size: int = 1200,
-            fit_n_points: int = 10, batch_size: int = 1, mc_points_size: int = 64, num_mc_samples: int = 1024,
-            mc_points_method: str = "NUTS", logz_threshold: Optional[float] = None, ns_n_points: int = 10,
-            convergence_n_iters: int = 1, do_final_ns: bool = False, acq_threshold: Optional[float] = None,
-            zeta_ei: float = 0.01, verbose: bool = False, ei_goal: Optional[float] = None, num_hmc_warmup: int = 512,
-            num_hmc_samples: int = 512, thinning: int = 4, num_chains: int = 4) -> dict:
-        """BO loop.  With ``logz_threshold`` the run also stops once nested sampling on the surrogate gives
-        (logZ_upper - logZ_lower)/2 < threshold ``convergence_n_iters`` times in a row (bo.py:886-891, 1283-1311);
-        the check runs every ``ns_n_points`` new evaluations after ``min_evals``."""
-        from .samplers import nested_sampling
+    def _mc_samples(self, method, num_hmc_warmup, num_hmc_samples, thinning, num_chains, num_mc_samples):
+        if method == "NUTS":                         # bo.py:1243-1255: HMC settings of run()
+            return get_mc_samples(self.gp, warmup_steps=num_hmc_warmup, num_samples=num_hmc_samples, thinning=thinning,
+                                  method="NUTS", num_chains=num_chains, np_rng=self.np_rng)
+        return get_mc_samples(self.gp, num_samples=num_mc_samples, method=method, np_rng=self.np_rng)
+
+    def run(self, acq=None, min_evals: int = 200, max_evals: int = 1500, max_gp_size: int = 1200,
+            logz_threshold: float = 0.01, convergence_n_iters: int = 1, do_final_ns: bool = False,
+            fit_n_points: int = 10, ns_n_points: int = 10, batch_size: int = 1, num_hmc_warmup: int = 512,
+            num_hmc_samples: int = 512, mc_points_size: int = 64, thinning: int = 4, num_chains: int = 4,
+            mc_points_method: str = "NUTS", zeta_ei: float = 0.01, ei_goal: float = 1e-10,
+            num_mc_samples: int = 1024, acq_threshold: Optional[float] = None, verbose: bool = False) -> dict:
+        """``BOBE.run`` (bo.py:967-1172): the keywords and defaults of the reference (plus ``num_mc_samples`` for the
+        'uniform' / 'NS' integration-point methods and an optional ``acq_threshold`` stop).
+
+        WIPV / WIPStd (bo.py:1226-1385): integration samples once before the loop; per iteration a kriging-believer
+        batch, likelihood evaluations, ``update_gp``; when ``ns_n_points`` new evaluations have accumulated past
+        ``min_evals`` AND the last acquisition value is <= ``logz_threshold``, nested sampling on the surrogate —
+        its equal-weight samples become the next integration samples and (upper - lower)/2 < threshold,
+        ``convergence_n_iters`` times in a row, ends the run ("LogZ converged", bo.py:886-934); otherwise fresh
+        integration samples.  EI / LogEI (bo.py:1174-1224): one point per iteration, log-EI goal."""
+        from .samplers import nested_sampling, resample_equal
         acq = acq if acq is not None else self.default_acq
         if isinstance(acq, (tuple, list)):                       # the reference accepts a tuple of stages: first one
             acq = acq[0]
         acq_fn = _ACQ[acq.lower()]()
         is_wip = acq.lower() in ("wipv", "wipstd")
         acq_hist: List[float] = []
-        logz: Optional[dict] = None
-        samples: dict = {}
-        converged, n_ok, since_ns = False, 0, 0
-        reason, it = None, 0
+        logz: dict = {}
+        ns_samples: Optional[dict] = None
+        ns_success = False
+        converged, counter, n_since_ns = False, 0, 0
+        reason, it = "Max evaluation budget reached", 0          # bo.py:1093
+        self.n_points_since_last_fit = 0
         self.timing.setdefault("Nested Sampling", 0.0)
-        # the reference counts objective evaluations (bo.py:1198, 765-775): a proposal the GP rejects as a duplicate
-        # still counts, so the loop ends by max_evals even when nothing new is accepted
+        self.timing.setdefault("MCMC Sampling", 0.0)
         current_evals = self.gp.npoints
-        while current_evals < max_evals and self.gp.npoints < max_gp_size:
+        mc_args = (mc_points_method, num_hmc_warmup, num_hmc_samples, thinning, num_chains, num_mc_samples)
+
+        def check_logz(lz) -> bool:                              # bo.py:871-934 (the KL bookkeeping is results-manager work)
+            nonlocal counter
+            delta = (lz["upper"] - lz["lower"]) / 2.0
+            if delta < logz_threshold:
+                counter += 1
+                return counter >= convergence_n_iters
+            counter = 0
+            return False
+
+        def check_budget() -> Optional[str]:                     # bo.py:757-775
+            if current_evals >= max_evals:
+                return "Maximum evaluations reached"
+            if self.gp.train_x.shape[0] >= max_gp_size:
+                return "Maximum GP size reached"
+            return None
+
+        if is_wip:
+            t0 = time.time()
+            mc = self._mc_samples(*mc_args)
+            self.timing["MCMC Sampling"] += time.time() - t0
+        while not converged:
             it += 1
             t0 = time.time()
             if is_wip:
-                if mc_points_method == "NUTS":               # bo.py:1243-1250: HMC settings of run()
-                    mc = get_mc_samples(self.gp, warmup_steps=num_hmc_warmup, num_samples=num_hmc_samples,
-                                        thinning=thinning, method="NUTS", num_chains=num_chains, np_rng=self.np_rng)
-                else:
-                    mc = get_mc_samples(self.gp, num_samples=num_mc_samples, method=mc_points_method,
-                                        np_rng=self.np_rng)
-                samples = mc
+                n_since_ns += batch_size
+                ns_flag = n_since_ns >= ns_n_points and current_evals >= min_evals
                 kwargs = {"mc_samples": mc, "mc_points_size": mc_points_size}
                 new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=batch_size, acq_kwargs=kwargs, n_restarts=1,
                                                     maxiter=100, early_stop_patience=10, rng=self.np_rng)  # bo.py:1274
+                n_new = batch_size
             else:
-                kwargs = {"zeta": zeta_ei, "best_y": float(np.max(self.gp.train_y))}
-                new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=1, acq_kwargs=kwargs, n_restarts=20,
-                                                    maxiter=250, rng=self.np_rng)
+                kwargs = {"zeta": zeta_ei, "best_y": float(np.max(self.gp.train_y)) if self.gp.train_y.size else 0.0}
+                new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=1, acq_kwargs=kwargs, n_restarts=50,
+                                                    maxiter=1000, early_stop_patience=50, rng=self.np_rng)  # bo.py:1194
+                n_new = 1
             new_u = np.atleast_2d(new_u)
+            vals = np.atleast_1d(vals)
             self.timing["Acquisition Optimization"] += time.time() - t0
             acq_hist.append(float(np.mean(vals)))
             new_vals = self._evaluate(scale_from_unit(new_u, self.param_bounds))
+            current_evals += n_new                               # a proposal the GP rejects as a duplicate still counts
             self.update_gp(new_u, new_vals, fit_n_points)
             if verbose:
-                log.info(f"N={self.gp.npoints} acq={acq_hist[-1]:.3e}")
+                log.info(f"Iteration {it}: N={self.gp.npoints} acq={acq_hist[-1]:.3e}")
+            if is_wip:
+                if ns_flag and float(vals[-1]) <= logz_threshold:            # bo.py:1283-1311
+                    t0 = time.time()
+                    ns_samples, lz, ns_success = nested_sampling(self.gp, mode="convergence", dlogz=0.01,
+                                                                 equal_weights=False, rng=self.np_rng)
+                    self.timing["Nested Sampling"] += time.time() - t0
+                    if ns_success:
+                        eq_x, eq_l = resample_equal(ns_samples["x"], ns_samples["logl"], ns_samples["weights"],
+                                                    rng=self.np_rng)
+                        mc = {"x": eq_x, "logl": eq_l, "weights": np.ones(eq_x.shape[0]), "method": "NS",
+                              "best": ns_samples["best"]}
+                        logz = lz
+                        converged = check_logz(lz)
+                        if converged:
+                            reason = "LogZ converged"
+                    n_since_ns = 0
+                else:                                                        # bo.py:1313-1324
+                    t0 = time.time()
+                    mc = self._mc_samples(*mc_args)
+                    self.timing["MCMC Sampling"] += time.time() - t0
+                if acq_threshold is not None and acq_hist[-1] <= acq_threshold and not converged:
+                    reason = "Acquisition threshold reached"
+                    break
+            else:                                                            # bo.py:838-866, 1208-1218
+                goal_val = float(vals[-1])
+                if acq.lower() == "ei":
+                    goal_val = float(np.log(goal_val + 1e-100))
+                if goal_val < np.log(ei_goal):
+                    counter += 1
+                    if counter >= convergence_n_iters:
+                        converged, reason = True, f"{acq_fn.name.upper()} goal reached"
+                else:
+                    counter = 0
             if self.save and it % self.save_step == 0:
                 import os
                 self.gp.save(os.path.join(self.save_dir, f"{self.likelihood_name}_gp"))
-            current_evals += new_u.shape[0]
-            if acq_threshold is not None and is_wip and acq_hist[-1] <= acq_threshold:
-                reason = "Acquisition threshold reached"
+            if converged:
                 break
-            if ei_goal is not None and not is_wip and current_evals >= min_evals:          # bo.py:1208-1215
-                goal_val = np.exp(acq_hist[-1]) if acq.lower() == "logei" else acq_hist[-1]
-                if goal_val < ei_goal:
-                    converged, reason = True, f"{acq_fn.name.upper()} goal reached"
-                    break
-            since_ns += new_u.shape[0]
-            if logz_threshold is not None and current_evals >= min_evals and since_ns >= ns_n_points:
-                t0 = time.time()
-                _, logz, ok = nested_sampling(self.gp, mode="convergence", rng=self.np_rng)
-                self.timing["Nested Sampling"] += time.time() - t0
-                since_ns = 0
-                delta = (logz["upper"] - logz["lower"]) / 2.0                    # bo.py:886-891
-                n_ok = n_ok + 1 if (ok and delta < logz_threshold) else 0
-                if n_ok >= convergence_n_iters:
-                    converged, reason = True, "LogZ converged"
-                    break
-        if do_final_ns or (logz_threshold is not None and logz is None):
+            budget = check_budget()
+            if budget is not None:
+                reason = budget
+                break
+        if is_wip and do_final_ns and not converged:                         # bo.py:1345-1366
             t0 = time.time()
-            ns_samples, logz, _ = nested_sampling(self.gp, mode="convergence", rng=self.np_rng)
-            samples = ns_samples if isinstance(ns_samples, dict) else samples
+            gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng)
+            self.timing["GP Training"] += time.time() - t0
+            t0 = time.time()
+            ns_samples, lz, ns_success = nested_sampling(self.gp, mode="convergence", dlogz=0.01, rng=self.np_rng)
             self.timing["Nested Sampling"] += time.time() - t0
-        if reason is None:                                       # bo.py:769-774
-            reason = "Maximum GP size reached" if self.gp.npoints >= max_gp_size and max_gp_size <= max_evals \
-                else "Maximum evaluations reached"
+            if ns_success:
+                logz = lz
+                if check_logz(lz):
+                    converged, reason = True, "LogZ converged"
+        samples: dict = {}
+        if is_wip:                                                           # bo.py:1368-1385
+            if ns_samples is not None and ns_success:
+                x_u, weights, logl = ns_samples["x"], ns_samples["weights"], ns_samples["logl"]
+            else:
+                t0 = time.time()
+                hm = get_mc_samples(self.gp, warmup_steps=512, num_samples=2000 * self.ndim, thinning=4, method="NUTS",
+                                    np_rng=self.np_rng)
+                self.timing["MCMC Sampling"] += time.time() - t0
+                x_u = hm["x"]
+                weights = hm["weights"] if "weights" in hm else np.ones(hm["x"].shape[0])
+                logl = hm["logp"] if "logp" in hm else hm.get("logl")
+            samples = {"x": scale_from_unit(np.asarray(x_u), self.param_bounds), "weights": np.asarray(weights),
+                       "logl": np.asarray(logl)}
         if self.save:
             import os
             self.gp.save(os.path.join(self.save_dir, f"{self.likelihood_name}_gp"))
@@ -245,12 +324,10 @@ class BOBE:
                    "param_labels": self.param_labels, "acquisition_history": list(acq_hist),
                    "timing": dict(self.timing), "converged": converged, "termination_reason": reason,
                    "gp_training_set_size": int(self.gp.npoints)}
-        # keys of the reference's results dict (bo.py:827-836): EI / LogEI runs carry empty 'samples' and 'logz'
+        # keys of the reference's results dict (bo.py:827-836); the rest are conveniences of this driver
         return {"gp": self.gp, "likelihood": self.loglikelihood, "results_manager": manager,
-                "best_val": float(y[ibest, 0]), "best_pt": best_x,
-                "termination_reason": reason,
-                "samples": (samples if is_wip else {}),
-                "best_x": best_x,
-                "n_evals": int(self.gp.npoints), "acq_history": acq_hist, "timing": dict(self.timing),
+                "best_val": float(y[ibest, 0]), "best_pt": best_x, "logz": logz, "termination_reason": reason,
+                "samples": samples,
+                "best_x": best_x, "n_evals": int(self.gp.npoints), "acq_history": acq_hist, "timing": dict(self.timing),
                 "lengthscales": np.array(self.gp.lengthscales), "kernel_variance": float(self.gp.kernel_variance),
-                "logz": (logz if logz is not None else {}), "converged": converged}
+                "converged": converged}

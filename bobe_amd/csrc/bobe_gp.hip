@@ -102,7 +102,8 @@ void configure_kernels_once() {
   allow_big_lds(k_potf2<false, false>, POTF2_SMEM_BYTES);
   allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
   allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
-  allow_big_lds(k_panel_fused, FUSED_SMEM_BYTES);
+  allow_big_lds(k_chol_step<false>, STEP_SMEM_BYTES);
+  allow_big_lds(k_chol_panel<false>, POTF2_SMEM_BYTES);
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_syrk_trail<64, SYRK64_BK>, SYRK64_SMEM);
@@ -134,16 +135,16 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, superpanel, superpanel_batch, fused_panel, mll_slots, own_queues, graph_max_n; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, mll_slots, own_queues, graph_max_n, lockstep_min_n; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 1, 1, 0, 4, 1, 2048};   // fused panel off: the hand-off costs exceed the overlap gain
+    Tuning v{512, 600, 1200, 0, 1, 4, 1, 2048, 1024};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
-    if (const char* e = std::getenv("BOBE_SUPERPANEL")) v.superpanel = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("BOBE_SUPERPANEL_BATCH")) v.superpanel_batch = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("BOBE_FUSED_PANEL")) v.fused_panel = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_CHOL_LEGACY")) v.chol_legacy = std::atoi(e);   // always potf2 / trsm / syrk launches
+    if (const char* e = std::getenv("BOBE_CHOL_LOOKAHEAD")) v.chol_lookahead = std::atoi(e);   // 0: no fused step for B = 1
+    if (const char* e = std::getenv("BOBE_LOCKSTEP_MIN_N")) v.lockstep_min_n = std::atoi(e);
     if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
     if (const char* e = std::getenv("BOBE_OWN_QUEUES")) v.own_queues = std::atoi(e);
     if (const char* e = std::getenv("BOBE_GRAPH_MAX_N")) v.graph_max_n = std::atoi(e);
@@ -215,6 +216,21 @@ struct bobe_gp {
     std::swap(eg, s.eg);
     in_slot = !in_slot;
   }
+  // Lock-step batch workspace (bobe_gp_mll_batch from lockstep_min_n points up): the B evaluations of a batch go
+  // through ONE launch sequence on the handle's stream, every kernel taking the slot from its last grid dimension;
+  // slot b lives at offset b * stride of each of these contiguous buffers.
+  struct BatchWs {
+    int cap = 0;
+    int64_t Np = 0;
+    DBuf A, Linv, Tmp, XsT, w, alpha, part, gpart, res, info, hyp;
+    Hyper* h_hyp = nullptr;      // pinned [BOBE_MAX_MLL_SLOTS]
+    double* h_res = nullptr;     // pinned [BOBE_MAX_MLL_SLOTS][128]
+    int* h_info = nullptr;       // pinned [BOBE_MAX_MLL_SLOTS]
+  } bw;
+  int64_t gpart_stride() const { return (int64_t)(2 * nb) * (2 * nb + 1) / 2 * (MAX_D + 1); }
+  void ensure_batch(int B);
+  void mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad);
+  int mll_lockstep_collect(int B, double* mll, double* grad, int* status);
   std::mutex submit_mutex;          // serialises bobe_gp_mll_submit (the slot swap is not re-entrant)
   void ensure_slots(int n);
   void mll_enqueue(const Hyper& h, bool want_grad);
@@ -268,17 +284,23 @@ struct bobe_gp {
 
   void build_probs();
   void alloc_for_n();
+  // Batched forms (B > 1): slot b of a batch works on base + b * stride of every matrix / vector it is given and
+  // reads its hyper-parameters from hdev[b]; B = 1 with zero strides is the plain call.
   void scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo,
-             const Hyper* hdev = nullptr);
+             const Hyper* hdev = nullptr, int B = 1, int64_t bsO = 0);
   void kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT, int64_t ldb,
                            int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo);
-  void assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev = nullptr);
-  void syrk(double* a, int k0, int k1, int first, int colmode);
-  void potrf(double* a, double* linv);
-  void trtri(const double* a, double* linv);
+  void assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev = nullptr, int B = 1,
+                    int64_t bsX = 0, int64_t bsA = 0);
+  void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0);
+  void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0);
+  void potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL);
+  void trtri(const double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
   int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
-            const Hyper* hdev = nullptr);
-  void solve_alpha(const double* linv, double* wv, double* al);
+            const Hyper* hdev = nullptr, double* gp_out = nullptr, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
+            int64_t bsX = 0, int64_t bsP = 0);
+  void solve_alpha(const double* linv, double* wv, double* al, double* prt, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
+                   int64_t bsP = 0);
   void factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al,
                    const Hyper* hdev = nullptr);
   int read_info();
@@ -341,13 +363,14 @@ void bobe_gp::alloc_for_n() {
   gpart.ensure((size_t)(2 * nb) * (2 * nb + 1) / 2 * (MAX_D + 1) * sizeof(double));
   res.ensure(128 * sizeof(double));
   info.ensure(sizeof(int));
+  flags.ensure((size_t)nb * sizeof(int));
   build_probs();
 }
 
 void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo,
-                    const Hyper* hdev) {
-  hipLaunchKernelGGL(k_scale_coords, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, stream, in, n, npad, h, out, ldo,
-                     hdev);
+                    const Hyper* hdev, int B, int64_t bsO) {
+  hipLaunchKernelGGL(k_scale_coords, dim3((unsigned)((npad + 255) / 256), (unsigned)B), dim3(256), 0, stream, in, n, npad,
+                     h, out, ldo, hdev, bsO);
   LAUNCH_CHECK();
 }
 
@@ -375,14 +398,15 @@ void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, d
 void bobe_gp::kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT,
                                   int64_t ldb, int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo) {
   const dim3 grid((unsigned)(nbpad / TILE), (unsigned)(napad / TILE));
-  KM_DISPATCH(false, grid, AT, lda, na, BT, ldb, nbv, h, out, ldo, (const Hyper*)nullptr);
+  KM_DISPATCH(false, grid, AT, lda, na, BT, ldb, nbv, h, out, ldo, (const Hyper*)nullptr, (int64_t)0, (int64_t)0);
   LAUNCH_CHECK();
 }
 
-void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev) {
-  const dim3 grid((unsigned)(nb * (nb + 1) / 2));
+void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev, int B, int64_t bsX,
+                           int64_t bsA) {
+  const dim3 grid((unsigned)(nb * (nb + 1) / 2), (unsigned)B);
   prof_begin(BOBE_PROF_KXX);
-  KM_DISPATCH(true, grid, xst, Np, N, xst, Np, N, h, a, Np, hdev);
+  KM_DISPATCH(true, grid, xst, Np, N, xst, Np, N, h, a, Np, hdev, bsX, bsA);
   prof_end(BOBE_PROF_KXX);
   LAUNCH_CHECK();
 }
@@ -392,8 +416,9 @@ void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a, const H
 // Trailing update with the panels of 128-blocks [k0, k1): colmode 0 = every lower tile from 128-block `first`
 // on, colmode 1 = only 128-block column `first` (rows from `first` down).  A tile's time is set by its MFMAs
 // per wave (512 / 128 / 32 per 128 of K): small trailing matrices take the smallest tile that still fills the
-// chip, large ones the cheapest by a rounds x tile-time estimate.
-void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode) {
+// chip, large ones the cheapest by a rounds x tile-time estimate.  (Tile shape does not change the bits: every
+// element accumulates its K range in the same order, four k per MFMA.)
+void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int64_t bsA) {
   const Tuning& tu = tuning();
   const int rem = nb - first;                 // 128-blocks in the trailing matrix
   if (rem <= 0 || k1 <= k0) return;
@@ -404,56 +429,81 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode) {
   // 64x64 tiles with BK = 16 (36 KB of LDS, four workgroups per CU) have the best saturated throughput of all
   // variants at every K (tools/ubench_syrk.hip); when they would leave most of the chip idle, a single-panel
   // update takes 32x32 tiles, which stage the whole K = 128 panel in one LDS buffer
-  if (kb == 1 && t64 < tu.syrk32_below) {
-    hipLaunchKernelGGL((k_syrk_trail<32, SYRK32_BK>), dim3(t32), dim3(256), SYRK32_SMEM, stream, a, Np, k0, k1, first,
-                       colmode, n32);
+  if (kb == 1 && B * t64 < tu.syrk32_below) {
+    hipLaunchKernelGGL((k_syrk_trail<32, SYRK32_BK>), dim3(t32, B), dim3(256), SYRK32_SMEM, stream, a, Np, k0, k1, first,
+                       colmode, n32, bsA);
     return;
   }
-  hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(t64), dim3(256), SYRK64_SMEM, stream, a, Np, k0, k1, first,
-                     colmode, n64);
+  hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(t64, B), dim3(256), SYRK64_SMEM, stream, a, Np, k0, k1, first,
+                     colmode, n64, bsA);
 }
 
-// Blocked Cholesky, NB = 128, in super-panels of W blocks: inside a super-panel [k0, k1) the factorisation is
-// left-looking (block column j is brought up to date with the panels k0..j-1 just before it is factored), and
-// the trailing matrix is updated once per super-panel with all W panels (K = 128 W), which cuts the passes over
-// the trailing matrix by W and gives the update tiles a K long enough to reach the GEMM core's steady state.
-void bobe_gp::potrf(double* a, double* linv) {
+// Blocked right-looking Cholesky (NB = 128) of B matrices in lock step on one stream; every launch carries the slot
+// in its last grid dimension.  Per step k:
+//   panel k   diagonal factor + solve of the rows below.  One launch (k_chol_panel: every 64-row workgroup factors
+//             the diagonal block itself) while all B * 2 * (nb-1-k) workgroups fit on the chip at once, else the
+//             k_potf2 + k_trsm_panel pair (one factorisation per slot).
+//   update    A22 -= L21 L21^T on the lower tiles (k_syrk_trail).
+// A batch shares the latency-bound panel chain (32 x ~40 us at N = 4096, the same for 1 or 8 matrices) and gives the
+// update 4-8x the tiles: 35 % of the fp64 MFMA peak with four in flight, 42 % with eight, against 15 % alone and 22 %
+// for four on private streams (whose 150 KB-LDS panel kernels wait for a CU the others' update tiles keep occupied).
+// A LONE factorisation (B = 1) is chain-bound at every step and takes the one-step lookahead form instead:
+//   1. k_syrk_trail (colmode 1): block column k receives panel k-1 - the only part of the update panel k waits for;
+//   2. k_chol_step: panel k side by side with the rest of the update by panel k-1, in one launch.
+// Every matrix element sees the same operation sequence in all three forms (same bits).
+void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL) {
   const Tuning& tu = tuning();
-  const int W = std::max(1, in_slot ? tu.superpanel_batch : tu.superpanel);
-  // fused panel launch: potf2(k) publishes its sub-panels to the co-resident panel solvers of the same launch
-  const bool fused = tu.fused_panel && nb > 1 && (1 + 2 * (nb - 1)) <= num_cus;
-  if (fused) {
-    flags.ensure((size_t)nb * sizeof(int));
-    HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)nb * sizeof(int), stream));
+  if (B > 1 || tu.chol_legacy || !tu.chol_lookahead) {
+    potrf_legacy(a, linv, info_dev, B, bsA, bsL);
+    return;
   }
-  for (int k0 = 0; k0 < nb; k0 += W) {
-    const int k1 = std::min(k0 + W, nb);
-    for (int k = k0; k < k1; ++k) {
-      const int rem = nb - k - 1;
-      if (k > k0) {
-        prof_begin(BOBE_PROF_SYRK);
-        syrk(a, k0, k, k, 1);
-        prof_end(BOBE_PROF_SYRK);
-      }
+  for (int k = 0; k < nb; ++k) {
+    const int rem = nb - 1 - k;
+    if (k > 0) {
+      prof_begin(BOBE_PROF_SYRK);
+      syrk(a, k - 1, k, k, 1, B, bsA);
+      prof_end(BOBE_PROF_SYRK);
+    }
+    const int npanel = rem > 0 ? 2 * rem : 1;                 // 64 rows of the panel per workgroup
+    const int n64 = 2 * rem;
+    const int ntiles = k > 0 ? n64 * (n64 + 1) / 2 : 0;       // per slot
+    const int grid = B * npanel + (B * ntiles + 3) / 4;
+    prof_begin(BOBE_PROF_POTF2);
+    hipLaunchKernelGGL(k_chol_step<false>, dim3(grid), dim3(STEP_THREADS), STEP_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
+                       k, B, npanel, ntiles, info_dev, (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE),
+                       (unsigned long long*)nullptr);
+    prof_end(BOBE_PROF_POTF2);
+  }
+  LAUNCH_CHECK();
+}
+
+// panel and update as separate launches (see above)
+void bobe_gp::potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL) {
+  const Tuning& tu = tuning();
+  for (int k = 0; k < nb; ++k) {
+    const int rem = nb - k - 1;
+    const int nvalid = (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE);
+    const int npanel = rem > 0 ? 2 * rem : 1;
+    if (!tu.chol_legacy && B * npanel <= std::max(num_cus, 1)) {
       prof_begin(BOBE_PROF_POTF2);
-      if (fused && rem > 0)
-        hipLaunchKernelGGL(k_panel_fused, dim3(1 + 2 * rem), dim3(256), FUSED_SMEM_BYTES, stream, a, Np, linv, Np, k,
-                           static_cast<int*>(info.p), static_cast<int*>(flags.p));
-      else
-        hipLaunchKernelGGL((k_potf2<true, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k,
-                           static_cast<int*>(info.p), (unsigned long long*)nullptr,
-                           (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE));
+      hipLaunchKernelGGL(k_chol_panel<false>, dim3(npanel, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
+                         k, npanel, info_dev, nvalid, (unsigned long long*)nullptr);
       prof_end(BOBE_PROF_POTF2);
-      if (rem > 0 && !fused) {
+    } else {
+      prof_begin(BOBE_PROF_POTF2);
+      hipLaunchKernelGGL((k_potf2<true, false>), dim3(B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k, info_dev,
+                         (unsigned long long*)nullptr, nvalid, bsA, bsL);
+      prof_end(BOBE_PROF_POTF2);
+      if (rem > 0) {
         prof_begin(BOBE_PROF_TRSM);
-        hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rem), dim3(256), TRSM_SMEM_BYTES, stream, a, Np,
-                           (const double*)linv, Np, k, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rem, B), dim3(256), TRSM_SMEM_BYTES, stream, a, Np,
+                           (const double*)linv, Np, k, (unsigned long long*)nullptr, bsA, bsL);
         prof_end(BOBE_PROF_TRSM);
       }
     }
-    if (k1 < nb) {
+    if (rem > 0) {
       prof_begin(BOBE_PROF_SYRK);
-      syrk(a, k0, k1, k1, 0);
+      syrk(a, k, k + 1, k + 1, 0, B, bsA);
       prof_end(BOBE_PROF_SYRK);
     }
   }
@@ -461,25 +511,26 @@ void bobe_gp::potrf(double* a, double* linv) {
 }
 
 // Linv = L^-1: diagonal 128-blocks in one batched launch, then recursive doubling (two GEMM launches per level)
-void bobe_gp::trtri(const double* a, double* linv) {
+void bobe_gp::trtri(const double* a, double* linv, double* tmp, int B, int64_t bsA, int64_t bsL, int64_t bsT) {
   const Tuning& tu = tuning();
   prof_begin(BOBE_PROF_TRTRI);
-  hipLaunchKernelGGL(k_trti_diag, dim3(nb), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np);
+  hipLaunchKernelGGL(k_trti_diag, dim3(nb, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, bsA, bsL);
   prof_end(BOBE_PROF_TRTRI);
   for (int dd = (int)depths.size() - 1; dd >= 0; --dd) {
     const Depth& D = depths[dd];
     const TriProb* pr = static_cast<const TriProb*>(probs.p) + D.first;
     prof_begin(BOBE_PROF_TRTRI);
-    if (D.nblocks < tu.trtri64_below) {
-      hipLaunchKernelGGL(k_trtri_T<64>, dim3(2 * D.nblocks), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
-                         (const double*)linv, Np, Tmp.d(), Np, pr, D.count);
-      hipLaunchKernelGGL(k_trtri_R<64>, dim3(2 * D.nblocks), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
-                         (const double*)Tmp.d(), Np, pr, D.count);
+    // (64x64 tiles while a level has too few 128x128 tiles to fill the chip; a tile's K order is the same either way)
+    if (B * D.nblocks < tu.trtri64_below) {
+      hipLaunchKernelGGL(k_trtri_T<64>, dim3(2 * D.nblocks, B), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
+                         (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT);
+      hipLaunchKernelGGL(k_trtri_R<64>, dim3(2 * D.nblocks, B), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
+                         (const double*)tmp, Np, pr, D.count, bsL, bsT);
     } else {
-      hipLaunchKernelGGL(k_trtri_T<128>, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, a, Np,
-                         (const double*)linv, Np, Tmp.d(), Np, pr, D.count);
-      hipLaunchKernelGGL(k_trtri_R<128>, dim3(D.nblocks), dim3(256), GEMM_SMEM_BYTES, stream, linv, Np,
-                         (const double*)Tmp.d(), Np, pr, D.count);
+      hipLaunchKernelGGL(k_trtri_T<128>, dim3(D.nblocks, B), dim3(256), GEMM_SMEM_BYTES, stream, a, Np,
+                         (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT);
+      hipLaunchKernelGGL(k_trtri_R<128>, dim3(D.nblocks, B), dim3(256), GEMM_SMEM_BYTES, stream, linv, Np,
+                         (const double*)tmp, Np, pr, D.count, bsL, bsT);
     }
     prof_end(BOBE_PROF_TRTRI);
   }
@@ -488,17 +539,18 @@ void bobe_gp::trtri(const double* a, double* linv) {
 
 // K^-1 tiles fused with the gradient partial sums (optionally stores K^-1's lower tiles); returns #partials
 int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
-                   const Hyper* hdev) {
+                   const Hyper* hdev, double* gp_out, int B, int64_t bsL, int64_t bsV, int64_t bsX, int64_t bsP) {
   const Tuning& tu = tuning();
   // (the tile size fixes the order of the gradient's partial sums: it depends on N only, so that an evaluation
-  // returns the same bits on every slot)
+  // returns the same bits alone, on a slot and in a batch)
   const bool small = nb * (nb + 1) / 2 < tu.lauum64_below;
   const int nt = small ? 2 * nb : nb;
   const int ntiles = nt * (nt + 1) / 2;
+  double* gpo = gp_out ? gp_out : gpart.d();
 #define LG(KE, DC, TT)                                                                                          \
-  hipLaunchKernelGGL((k_lauum_grad<KE, DC, TT>), dim3(ntiles), dim3(256),                                       \
+  hipLaunchKernelGGL((k_lauum_grad<KE, DC, TT>), dim3(ntiles, B), dim3(256),                                    \
                      (TT == 128 ? GEMM_SMEM_BYTES : GEMM64_SMEM_BYTES), stream, linv, Np, Np, N, al, xst, Np, h, \
-                     gpart.d(), kinv_out, Np, hdev)
+                     gpo, kinv_out, Np, hdev, bsL, bsV, bsX, bsP)
 #define LGD(KE, TT)                                                                 \
   do {                                                                              \
     if (dcap == 8) LG(KE, 8, TT); else if (dcap == 16) LG(KE, 16, TT); else LG(KE, 32, TT); \
@@ -516,12 +568,14 @@ int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const d
   return ntiles;
 }
 
-void bobe_gp::solve_alpha(const double* linv, double* wv, double* al) {
-  hipLaunchKernelGGL(k_gemv_lower, dim3((unsigned)(Np / 4)), dim3(256), 0, stream, linv, Np, Np, (const double*)y.d(), wv);
-  hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(Np / 64), (unsigned)nb), dim3(256), 0, stream, linv, Np, 1,
-                     (const double*)wv, part.d(), Np);
-  hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, stream, (const double*)part.d(),
-                     Np, nb, 1, Np, al);
+void bobe_gp::solve_alpha(const double* linv, double* wv, double* al, double* prt, int B, int64_t bsL, int64_t bsV,
+                          int64_t bsP) {
+  hipLaunchKernelGGL(k_gemv_lower, dim3((unsigned)(Np / 4), (unsigned)B), dim3(256), 0, stream, linv, Np, Np,
+                     (const double*)y.d(), wv, bsL, bsV);
+  hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(Np / 64), (unsigned)nb, (unsigned)B), dim3(256), 0, stream, linv, Np, 1,
+                     (const double*)wv, prt, Np, bsL, bsV, bsP);
+  hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((Np + 255) / 256), (unsigned)B), dim3(256), 0, stream,
+                     (const double*)prt, Np, nb, 1, Np, al, bsP, bsV);
   LAUNCH_CHECK();
 }
 
@@ -530,9 +584,9 @@ void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, 
   scale(X.d(), N, Np, h, xst, Np, hdev);
   assemble_kxx(h, xst, a, hdev);
   HIPCHK(hipMemsetAsync(info.p, 0x7f, sizeof(int), stream));
-  potrf(a, linv);
-  trtri(a, linv);
-  solve_alpha(linv, wv, al);
+  potrf(a, linv, static_cast<int*>(info.p));
+  trtri(a, linv, Tmp.d());
+  solve_alpha(linv, wv, al, part.d());
 }
 
 int bobe_gp::read_info() {
@@ -558,6 +612,7 @@ void bobe_gp::ensure_slots(int n) {
     sl.gpart.ensure((size_t)(2 * nb) * (2 * nb + 1) / 2 * (MAX_D + 1) * sizeof(double));
     sl.res.ensure(128 * sizeof(double));
     sl.info.ensure(sizeof(int));
+    sl.flags.ensure((size_t)nb * sizeof(int));
   }
 }
 
@@ -609,7 +664,7 @@ void bobe_gp::mll_enqueue(const Hyper& h, bool want_grad) {
   // graph (N = 64 / 512 / 2048 with four in flight: 42 / 107 / 419 us per evaluation instead of 66 / 141 / 553).
   // A lone evaluation on the handle's stream is NOT faster as a graph (125 vs 107 us at N = 64) and stays a
   // plain launch sequence; so does everything while a kernel class is being timed (events are not captured).
-  if (!in_slot || N > tu.graph_max_n || prof_tag != 0 || tu.fused_panel) {
+  if (!in_slot || N > tu.graph_max_n || prof_tag != 0) {
     mll_enqueue_body(h, want_grad, nullptr);
     return;
   }
@@ -650,7 +705,6 @@ int bobe_gp::slot_collect(Slot& sl, double* mll, double* grad) {
   const double* hr = sl.h_res;
   int inf;
   std::memcpy(&inf, hr + 100, sizeof(int));
-  if (inf < 0) throw Err(BOBE_ERR_HIP, "fused panel launch timed out waiting for the factorisation (set BOBE_FUSED_PANEL=0)");
   if (inf != 0x7f7f7f7f) {
     *mll = std::nan("");
     if (grad)
@@ -668,7 +722,6 @@ int bobe_gp::mll_collect(double* mll, double* grad) {
   sync();
   int inf;
   std::memcpy(&inf, h_res + 100, sizeof(int));
-  if (inf < 0) throw Err(BOBE_ERR_HIP, "fused panel launch timed out waiting for the factorisation (set BOBE_FUSED_PANEL=0)");
   if (inf != 0x7f7f7f7f) {
     *mll = std::nan("");
     if (grad)
@@ -680,6 +733,78 @@ int bobe_gp::mll_collect(double* mll, double* grad) {
   if (grad)
     for (int j = 0; j <= d; ++j) grad[j] = h_res[2 + j];
   return BOBE_OK;
+}
+
+void bobe_gp::ensure_batch(int B) {
+  if (!bw.h_hyp) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bw.h_hyp), BOBE_MAX_MLL_SLOTS * sizeof(Hyper), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bw.h_res), BOBE_MAX_MLL_SLOTS * 128 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bw.h_info), BOBE_MAX_MLL_SLOTS * sizeof(int), hipHostMallocDefault));
+  }
+  const size_t mat = (size_t)Np * Np * sizeof(double), vec = (size_t)Np * sizeof(double);
+  const size_t nB = (size_t)B;
+  bw.A.ensure(nB * mat); bw.Linv.ensure(nB * mat); bw.Tmp.ensure(nB * mat);
+  bw.XsT.ensure(nB * d * vec); bw.w.ensure(nB * vec); bw.alpha.ensure(nB * vec);
+  bw.part.ensure(nB * nb * vec);
+  bw.gpart.ensure(nB * (size_t)gpart_stride() * sizeof(double));
+  bw.res.ensure(nB * 128 * sizeof(double));
+  bw.info.ensure(BOBE_MAX_MLL_SLOTS * sizeof(int));
+  bw.hyp.ensure(BOBE_MAX_MLL_SLOTS * sizeof(Hyper));
+  bw.cap = std::max(bw.cap, B);
+  bw.Np = Np;
+}
+
+// B value(+gradient) evaluations in lock step: the pipeline of mll_enqueue_body with every launch widened by the
+// slot dimension.  Results land in the pinned bw.h_res[b*128 + ...] / bw.h_info[b] (layout of mll_enqueue_body).
+void bobe_gp::mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad) {
+  ensure_batch(B);
+  const int64_t mat = Np * Np, vec = Np, xs = (int64_t)d * Np, prt = (int64_t)nb * Np, gps = gpart_stride();
+  for (int b = 0; b < B; ++b) bw.h_hyp[b] = hs[b];
+  HIPCHK(hipMemcpyAsync(bw.hyp.p, bw.h_hyp, (size_t)B * sizeof(Hyper), hipMemcpyHostToDevice, stream));
+  const Hyper* hdev = static_cast<const Hyper*>(bw.hyp.p);
+  int* inf = static_cast<int*>(bw.info.p);
+  scale(X.d(), N, Np, hs[0], bw.XsT.d(), Np, hdev, B, xs);
+  assemble_kxx(hs[0], bw.XsT.d(), bw.A.d(), hdev, B, xs, mat);
+  HIPCHK(hipMemsetAsync(inf, 0x7f, (size_t)B * sizeof(int), stream));
+  potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat);
+  trtri(bw.A.d(), bw.Linv.d(), bw.Tmp.d(), B, mat, mat, mat);
+  solve_alpha(bw.Linv.d(), bw.w.d(), bw.alpha.d(), bw.part.d(), B, mat, vec, prt);
+  hipLaunchKernelGGL(k_mll_terms, dim3(B), dim3(256), 0, stream, (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np,
+                     bw.res.d(), vec, mat, (int64_t)128);
+  if (want_grad) {
+    const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+    const int ntiles = lauum(hs[0], bw.Linv.d(), bw.alpha.d(), bw.XsT.d(), nullptr, dcap, hdev, bw.gpart.d(), B, mat, vec,
+                             xs, gps);
+    hipLaunchKernelGGL(k_grad_reduce, dim3(d + 1, B), dim3(64), 0, stream, (const double*)bw.gpart.d(), ntiles, dcap + 1, d,
+                       dcap, bw.res.d() + 2, gps, (int64_t)128);
+  }
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(bw.h_res, bw.res.p, (size_t)B * 128 * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(bw.h_info, inf, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+}
+
+int bobe_gp::mll_lockstep_collect(int B, double* mll, double* grad, int* status) {
+  sync();
+  int worst = BOBE_OK;
+  for (int b = 0; b < B; ++b) {
+    const double* hr = bw.h_res + (size_t)b * 128;
+    double* gb = grad ? grad + (size_t)b * (d + 1) : nullptr;
+    int st = BOBE_OK;
+    if (bw.h_info[b] != 0x7f7f7f7f) {
+      mll[b] = std::nan("");
+      if (gb)
+        for (int j = 0; j <= d; ++j) gb[j] = std::nan("");
+      g_err = "kernel matrix not positive definite at column " + std::to_string(bw.h_info[b] - 1);
+      st = BOBE_NOT_PD;
+      worst = st;
+    } else {
+      mll[b] = -0.5 * hr[0] - hr[1] - 0.5 * (double)N * std::log(2.0 * M_PI);
+      if (gb)
+        for (int j = 0; j <= d; ++j) gb[j] = hr[2 + j];
+    }
+    if (status) status[b] = st;
+  }
+  return worst;
 }
 
 // Z-side quantities of the sweep: ZsT, kXZ, V_Z = Linv kXZ, base_z = kself - |V_Z[:,z]|^2, W_Z = Linv^T V_Z
@@ -929,6 +1054,14 @@ void bobe_gp_destroy(bobe_gp_t* g) {
     if (sl->ev) (void)hipEventDestroy(sl->ev);
     delete sl;
   }
+  {
+    DBuf* bb[] = {&g->bw.A, &g->bw.Linv, &g->bw.Tmp, &g->bw.XsT, &g->bw.w, &g->bw.alpha, &g->bw.part, &g->bw.gpart,
+                  &g->bw.res, &g->bw.info, &g->bw.hyp};
+    for (DBuf* b : bb) b->release();
+    if (g->bw.h_hyp) (void)hipHostFree(g->bw.h_hyp);
+    if (g->bw.h_res) (void)hipHostFree(g->bw.h_res);
+    if (g->bw.h_info) (void)hipHostFree(g->bw.h_info);
+  }
   if (g->ev_batch) (void)hipEventDestroy(g->ev_batch);
   if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
@@ -1015,7 +1148,6 @@ int bobe_gp_factor(bobe_gp_t* g) {
   g->use();
   g->factor_into(g->hyp, g->XsT.d(), g->A.d(), g->Linv.d(), g->w.d(), g->alpha.d());
   const int inf = g->read_info();
-  if (inf < 0) throw Err(BOBE_ERR_HIP, "fused panel launch timed out waiting for the factorisation (set BOBE_FUSED_PANEL=0)");
   g->factored = true;
   g->not_pd = (inf != 0x7f7f7f7f);
   if (g->not_pd) {
@@ -1054,8 +1186,25 @@ int bobe_gp_mll_batch(bobe_gp_t* g, int64_t B, const double* ls, const double* k
   if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
   g->use();
   const int d = g->d;
-  const int width = std::max(1, std::min<int>(tuning().mll_slots, BOBE_MAX_MLL_SLOTS));
   int worst = BOBE_OK;
+  if (B >= 2 && g->N >= tuning().lockstep_min_n && g->prof_tag == 0) {
+    // GPU-bound sizes: the evaluations advance in lock step through one batched launch sequence
+    for (int64_t b0 = 0; b0 < B; b0 += BOBE_MAX_MLL_SLOTS) {
+      const int nbat = (int)std::min<int64_t>(BOBE_MAX_MLL_SLOTS, B - b0);
+      Hyper hs[BOBE_MAX_MLL_SLOTS];
+      for (int i = 0; i < nbat; ++i) {
+        hs[i] = g->hyp;
+        for (int j = 0; j < d; ++j) hs[i].ls[j] = ls[(b0 + i) * d + j];
+        hs[i].kvar = kvar[b0 + i];
+      }
+      g->mll_lockstep_enqueue(nbat, hs, grad != nullptr);
+      const int st = g->mll_lockstep_collect(nbat, mll + b0, grad ? grad + b0 * (d + 1) : nullptr,
+                                             status ? status + b0 : nullptr);
+      if (st != BOBE_OK) worst = st;
+    }
+    return worst;
+  }
+  const int width = std::max(1, std::min<int>(tuning().mll_slots, BOBE_MAX_MLL_SLOTS));
   for (int64_t b0 = 0; b0 < B; b0 += width) {
     const int nbat = (int)std::min<int64_t>(width, B - b0);
     static const bool trace = std::getenv("BOBE_TRACE") != nullptr;
@@ -1447,7 +1596,7 @@ int bobe_gp_set_chol(bobe_gp_t* g, const double* L, const double* alpha) {
     hipLaunchKernelGGL((k_potf2<false, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, g->stream, g->A.d(), Np, g->Linv.d(), Np,
                        k, static_cast<int*>(g->info.p), (unsigned long long*)nullptr);
   LAUNCH_CHECK();
-  g->trtri(g->A.d(), g->Linv.d());
+  g->trtri(g->A.d(), g->Linv.d(), g->Tmp.d());
   g->sync();
   g->factored = true;
   g->not_pd = false;
@@ -1598,7 +1747,7 @@ int bobe_debug_time_potrf(bobe_gp_t* g, int reps, double* ms) {
     g->assemble_kxx(g->hyp, g->XsT2.d(), g->A2.d());
     HIPCHK(hipMemsetAsync(g->info.p, 0x7f, sizeof(int), g->stream));
     HIPCHK(hipEventRecord(e0, g->stream));
-    g->potrf(g->A2.d(), g->Linv2.d());
+    g->potrf(g->A2.d(), g->Linv2.d(), static_cast<int*>(g->info.p));
     HIPCHK(hipEventRecord(e1, g->stream));
     HIPCHK(hipEventSynchronize(e1));
     float t = 0.f;
@@ -1641,7 +1790,7 @@ int bobe_debug_time_potrf_batch(bobe_gp_t* g, int B, int reps, double* ms) {
       HIPCHK(hipStreamWaitEvent(sl.stream, e0, 0));
       g->swap_slot(sl);
       try {
-        g->potrf(g->A2.d(), g->Linv2.d());
+        g->potrf(g->A2.d(), g->Linv2.d(), static_cast<int*>(g->info.p));
       } catch (...) {
         g->swap_slot(sl);
         throw;
@@ -1659,6 +1808,41 @@ int bobe_debug_time_potrf_batch(bobe_gp_t* g, int B, int reps, double* ms) {
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   for (auto& e : done) (void)hipEventDestroy(e);
+  *ms = total / reps;
+  return BOBE_OK;
+  API_END
+}
+
+// B factorisations advancing in lock step through one batched launch sequence (the fit's restarts from
+// lockstep_min_n points up): device time of the whole batch, averaged over reps
+int bobe_debug_time_potrf_lockstep(bobe_gp_t* g, int B, int reps, double* ms) {
+  API_BEGIN
+  if (!g || !ms || reps < 1 || B < 1 || B > BOBE_MAX_MLL_SLOTS) throw Err(BOBE_ERR_ARG, "bad argument");
+  if (!g->have_data) throw Err(BOBE_ERR_STATE, "call bobe_gp_set_data first");
+  g->use();
+  g->ensure_batch(B);
+  const int64_t mat = g->Np * g->Np, xs = (int64_t)g->d * g->Np;
+  for (int b = 0; b < B; ++b) g->bw.h_hyp[b] = g->hyp;
+  HIPCHK(hipMemcpyAsync(g->bw.hyp.p, g->bw.h_hyp, (size_t)B * sizeof(Hyper), hipMemcpyHostToDevice, g->stream));
+  const Hyper* hdev = static_cast<const Hyper*>(g->bw.hyp.p);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  double total = 0.0;
+  g->scale(g->X.d(), g->N, g->Np, g->hyp, g->bw.XsT.d(), g->Np, hdev, B, xs);
+  for (int r = 0; r < reps; ++r) {
+    g->assemble_kxx(g->hyp, g->bw.XsT.d(), g->bw.A.d(), hdev, B, xs, mat);
+    HIPCHK(hipMemsetAsync(g->bw.info.p, 0x7f, (size_t)B * sizeof(int), g->stream));
+    HIPCHK(hipEventRecord(e0, g->stream));
+    g->potrf(g->bw.A.d(), g->bw.Linv.d(), static_cast<int*>(g->bw.info.p), B, mat, mat);
+    HIPCHK(hipEventRecord(e1, g->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    total += t;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   *ms = total / reps;
   return BOBE_OK;
   API_END

@@ -1,11 +1,14 @@
 // Blocked Cholesky, triangular inverse and K^-1/gradient kernels (gfx950).  Included by kernels.hpp.
 //
-// Right-looking blocked Cholesky with NB = 128:
-//   k_potf2        one workgroup factors the 128x128 diagonal block in LDS and leaves the inverses of
-//                  its eight 16x16 diagonal sub-blocks in the diagonal block of Linv
-//   k_trsm_panel   L21 = A21 L11^-T, register resident: each wave keeps 16 rows x 128 columns as eight
-//                  transposed 16x16 MFMA accumulators and substitutes block column by block column
-//   k_syrk_trail   A22 -= L21 L21^T on the lower tiles (128x128 or 64x64 tiles)
+// Right-looking blocked Cholesky with NB = 128, one-step lookahead inside a single launch, batched over slots:
+//   k_chol_step    step k of every factorisation of the batch in ONE launch: the panel workgroups factor the
+//                  diagonal block (k,k) in LDS (each one redundantly: no hand-off) and solve their 64 rows of
+//                  block column k, while the other workgroups apply panel k-1 to the trailing tiles right of
+//                  block column k (four 64x64 tiles per 1024-thread workgroup)
+//   k_syrk_trail   A22 -= L21 L21^T on lower tiles; between two steps it brings block column k up to date
+//   k_potf2 / k_trsm_panel   the two halves of a panel as separate launches (restore path, diagnostics,
+//                  BOBE_CHOL_LEGACY=1)
+// Every kernel takes the slot of a batch from its last grid dimension and offsets its matrices by a slot stride.
 // Triangular inverse (needed by alpha, predictions and the gradient):
 //   k_trti_diag    all diagonal 128x128 blocks at once (one workgroup each)
 //   k_trtri_T/R    recursive doubling over 128-blocks, two GEMM launches per level
@@ -113,60 +116,19 @@ __device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0
   }
 }
 
-// Hand-off of the fused panel launch (k_panel_fused), in the write-through form of cdna_hip_programming.md
-// Guideline 16 / MI355X_MICROARCH.md "Valid forms": EVERY published byte is stored with an agent-scope (sc1,
-// write-through) store and loaded with an agent-scope (sc1, L1-bypassing) load; the one storing wave drains its
-// stores (s_waitcnt vmcnt(0)) before its lane 0 stores the flag; consumers poll the flag with sc1 loads and load
-// the data only after the poll has matched (plus a workgroup barrier for the non-polling waves).  No fences.
-__device__ __forceinline__ void st_agent(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_agent(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Publish sub-panel p of the block being factored: rows 16p..16p+15, columns < 16p of L and the 16x16 inverse
-// invD_p, then flag = p+1.  Called by ONE wave.
-__device__ __forceinline__ void potf2_publish(const double* S, const double* Dall, double* __restrict__ Ab, int64_t lda,
-                                              double* __restrict__ Ib, int64_t ldl, int p, int* flag, int lane) {
-  const int o = 16 * p;
-  for (int i = 0; i < 16; ++i)
-    for (int c = lane; c < o; c += 64) st_agent(Ab + (int64_t)(o + i) * lda + c, S[(o + i) * PLD + c]);
-  {
-    const int rr = lane >> 2, c0 = (lane & 3) * 4;
-    const double* src = Dall + (p * 16 + rr) * POTF2_DLD + c0;
-    double* dst = Ib + (int64_t)(o + rr) * ldl + o + c0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) st_agent(dst + c, src[c]);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_store(flag, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <bool FACTOR, bool STAMP, bool PUB>
-__device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv, int64_t ldl,
-                                           int blk, int* __restrict__ info, unsigned long long* __restrict__ stamps,
-                                           int* flag, int nvalid = TILE) {
-  extern __shared__ double S[];
-  double* Dall = S + TILE * PLD;  // [8][16][POTF2_DLD]: inverses of the 16x16 diagonal sub-blocks
-  // columns >= nvalid of a ragged last block are the identity padding: their sub-steps are skipped (L = I,
-  // inverse = I, and the rows of the panel below them are zero, so no update is lost)
-  const int nsteps = FACTOR ? ((nvalid + 15) >> 4) : 0;
+// The factor loop proper, on a block already staged in LDS (S: [128][PLD], lower part valid; Dall: [8][16][POTF2_DLD]).
+// Called by the first 256 threads of a workgroup (waves 0..3); colbase = global index of the block's first column
+// (for *info).  Leaves L (lower; the diagonal 16x16 tiles zero-filled above the diagonal) in S and the inverses of
+// the eight diagonal 16x16 sub-blocks in Dall.  Ends with a barrier.
+// NW = waves of the workgroup that take part (4 for the 256-thread kernels, 16 in k_chol_step): wave 0 owns the
+// serial leaf, the others share the deferred updates and the row solves (which tile a wave gets does not change any
+// tile's arithmetic).
+template <bool STAMP, int NW = 4>
+__device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int nsteps, int colbase, int* __restrict__ info,
+                                                 unsigned long long* __restrict__ stamps) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
-  double* Ab = A + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
-  double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
-  BOBE_STAMP(0);
-  block_load<true>(S, Ab, lda);
-  if (FACTOR && nsteps < 8)
-    for (int e = t; e < (8 - nsteps) * 16 * 16; e += 256) {
-      const int pp = nsteps + (e >> 8), rr = (e >> 4) & 15, cc = e & 15;
-      Dall[(pp * 16 + rr) * POTF2_DLD + cc] = (rr == cc) ? 1.0 : 0.0;
-    }
-  __syncthreads();
-  BOBE_STAMP(1);
-
   for (int p = 0; p < nsteps; ++p) {
     const int o = 16 * p;
     double* Dv = Dall + p * 16 * POTF2_DLD;
@@ -200,28 +162,27 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, 
 #pragma unroll
         for (int c = 0; c < 16; ++c) Dv[c * POTF2_DLD + li] = r[c];
       }
-      if (bad && lane == 0) atomicMin(info, blk * TILE + o + 1);
+      if (bad && lane == 0) atomicMin(info, colbase + o + 1);
       }
     } else if (p > 0) {
-      // fused launch: wave 3 first hands sub-panel p-1 (final since the last barrier) to the panel solvers
-      if (PUB && wave == 3) potf2_publish(S, Dall, Ab, lda, Ib, ldl, p - 1, flag, lane);
       // ---- phase A, waves 1..3: deferred updates of step p-1: every tile (ti, tj), p <= tj <= ti <= 7,
       //      except the diagonal tile (p, p), which wave 0 updated right after the previous phase B ----
       const int op = o - 16;
       const int nt = 8 - p;                 // tiles p..7
       const int ntiles = nt * (nt + 1) / 2 - 1;
-      for (int q = wave - 1; q < ntiles; q += 6) {
+      constexpr int NU = NW - 1;            // updater waves
+      for (int q = wave - 1; q < ntiles; q += 2 * NU) {
         int a0, b0, a1, b1;
         tri_decode_small(q + 1, a0, b0);    // index 0 is (p, p): skipped
-        const bool two = (q + 3) < ntiles;
-        tri_decode_small(two ? q + 4 : q + 1, a1, b1);
+        const bool two = (q + NU) < ntiles;
+        tri_decode_small(two ? q + NU + 1 : q + 1, a1, b1);
         potf2_update2(S, op, p + a0, p + b0, p + a1, p + b1, two, lane);
       }
     }
     __syncthreads();
     BOBE_STAMP(3 + 3 * p);
     // ---- phase B: rows below, X^T = inv(Lpp) * A^T per 16-row tile ----
-    for (int tt = p + 1 + wave; tt < 8; tt += 4) {
+    for (int tt = p + 1 + wave; tt < 8; tt += NW) {
       v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -240,17 +201,53 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, 
     if (p + 1 < nsteps && wave == 0) potf2_update2(S, o, p + 1, p + 1, p + 1, p + 1, false, lane);
   }
   __syncthreads();
-  BOBE_STAMP(26);
-  if (FACTOR && PUB && wave == 3) potf2_publish(S, Dall, Ab, lda, Ib, ldl, 7, flag, lane);   // last sub-panel first
-  if (FACTOR) {
-    block_store_lower(S, Ab, lda);
-    // the eight 16x16 inverses: thread t -> sub-block t>>5, row (t>>1)&15, half row t&1
-    const int bb = t >> 5, rr = (t >> 1) & 15, hh = t & 1;
-    const double* src = Dall + (bb * 16 + rr) * POTF2_DLD + 8 * hh;
-    double* dst = Ib + (int64_t)(16 * bb + rr) * ldl + 16 * bb + 8 * hh;
+}
+
+// stage-in of a diagonal block for the factor loop: lower part of the block, identity inverses for the padding steps
+__device__ __forceinline__ void potf2_stage_in(double* S, double* Dall, const double* __restrict__ Ab, int64_t lda,
+                                               int nsteps) {
+  const int t = threadIdx.x;
+  block_load<true>(S, Ab, lda);
+  if (nsteps < 8)
+    for (int e = t; e < (8 - nsteps) * 16 * 16; e += 256) {
+      const int pp = nsteps + (e >> 8), rr = (e >> 4) & 15, cc = e & 15;
+      Dall[(pp * 16 + rr) * POTF2_DLD + cc] = (rr == cc) ? 1.0 : 0.0;
+    }
+}
+
+// write-back: L (lower, zeros above) to the block, the eight 16x16 inverses to the same positions of Linv's block
+__device__ __forceinline__ void potf2_stage_out(const double* S, const double* Dall, double* __restrict__ Ab, int64_t lda,
+                                                double* __restrict__ Ib, int64_t ldl) {
+  const int t = threadIdx.x;
+  block_store_lower(S, Ab, lda);
+  // thread t -> sub-block t>>5, row (t>>1)&15, half row t&1
+  const int bb = t >> 5, rr = (t >> 1) & 15, hh = t & 1;
+  const double* src = Dall + (bb * 16 + rr) * POTF2_DLD + 8 * hh;
+  double* dst = Ib + (int64_t)(16 * bb + rr) * ldl + 16 * bb + 8 * hh;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) dst[c] = src[c];
-  }
+  for (int c = 0; c < 8; ++c) dst[c] = src[c];
+}
+
+template <bool FACTOR, bool STAMP>
+__device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv, int64_t ldl,
+                                           int blk, int* __restrict__ info, unsigned long long* __restrict__ stamps,
+                                           int nvalid = TILE) {
+  extern __shared__ double S[];
+  double* Dall = S + TILE * PLD;  // [8][16][POTF2_DLD]: inverses of the 16x16 diagonal sub-blocks
+  // columns >= nvalid of a ragged last block are the identity padding: their sub-steps are skipped (L = I,
+  // inverse = I, and the rows of the panel below them are zero, so no update is lost)
+  const int nsteps = FACTOR ? ((nvalid + 15) >> 4) : 0;
+  const int t = threadIdx.x;
+  double* Ab = A + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
+  double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
+  BOBE_STAMP(0);
+  if (FACTOR) potf2_stage_in(S, Dall, Ab, lda, nsteps);
+  else block_load<true>(S, Ab, lda);
+  __syncthreads();
+  BOBE_STAMP(1);
+  if (FACTOR) potf2_factor_lds<STAMP>(S, Dall, nsteps, blk * TILE, info, stamps);
+  BOBE_STAMP(26);
+  if (FACTOR) potf2_stage_out(S, Dall, Ab, lda, Ib, ldl);
   BOBE_STAMP(27);
   if (!FACTOR && t < 128) {
     // given L (restore path): inverses of the eight 16x16 diagonal sub-blocks, one column per thread
@@ -272,18 +269,23 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, 
 template <bool FACTOR, bool STAMP = false>
 __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                int64_t ldl, int blk, int* __restrict__ info,
-                                               unsigned long long* __restrict__ stamps = nullptr, int nvalid = TILE) {
-  potf2_body<FACTOR, STAMP, false>(A, lda, Linv, ldl, blk, info, stamps, nullptr, nvalid);
+                                               unsigned long long* __restrict__ stamps = nullptr, int nvalid = TILE,
+                                               int64_t bsA = 0, int64_t bsL = 0) {
+  const int slot = blockIdx.x;
+  potf2_body<FACTOR, STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, blk, info + slot, stamps, nvalid);
 }
 
 // ---- inverse of every diagonal 128x128 block (grid = nb) --------------------------------------------
 // in: L[blk][blk] (lower) and the 16x16 diagonal inverses left in Linv[blk][blk] by k_potf2.
 // out: Linv[blk][blk] = L[blk][blk]^-1 (lower, zeros above).
 __global__ __launch_bounds__(256) void k_trti_diag(const double* __restrict__ L, int64_t lda,
-                                                   double* __restrict__ Linv, int64_t ldl) {
+                                                   double* __restrict__ Linv, int64_t ldl, int64_t bsA = 0,
+                                                   int64_t bsL = 0) {
   extern __shared__ double S[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int blk = blockIdx.x;
+  L += blockIdx.y * bsA;
+  Linv += blockIdx.y * bsL;
   const double* Lb = L + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
   double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
   block_load(S, Lb, lda);
@@ -345,8 +347,11 @@ constexpr int TRSM_SMEM_BYTES = (TILE * PLD + 8 * 16 * TRSM_DLD) * 8;    // 150,
 template <bool STAMP = false>
 __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int64_t lda,
                                                     const double* __restrict__ Dinv, int64_t ldl, int k,
-                                                    unsigned long long* __restrict__ stamps = nullptr) {
+                                                    unsigned long long* __restrict__ stamps = nullptr,
+                                                    int64_t bsA = 0, int64_t bsL = 0) {
   extern __shared__ double S[];
+  A += blockIdx.y * bsA;
+  Dinv += blockIdx.y * bsL;
   BOBE_STAMP(0);
   double* D = S + TILE * PLD;   // [8][16][TRSM_DLD]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -424,108 +429,145 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
   BOBE_STAMP(3);
 }
 
-// ---- fused panel launch: potf2(k) (workgroup 0) + streaming panel solve (workgroups 1..2*rem) -------------
-// The solvers are the same register-resident algorithm as k_trsm_panel, but instead of waiting for the whole
-// L_kk they consume its 16-column sub-panels as workgroup 0 publishes them (flag value p+1 = sub-panels 0..p
-// are in global memory; write-through hand-off, see st_agent / ld_agent above), so only the last sub-step is
-// left when the factorisation finishes.  All workgroups
-// of the launch are co-resident (grid <= 1 + 2*(nb-1) <= #CUs, one workgroup per CU by LDS size), the
-// producer never waits for a consumer, and every spin is bounded (timeout -> *info = -1, results invalid).
-constexpr int FUSED_LROW = 16 * PLD;                                  // one staged 16-row tile of L_kk
-constexpr int FUSED_CONS_DOUBLES = 64 * PLD + 2 * FUSED_LROW + 2 * 16 * POTF2_DLD;
-constexpr int FUSED_SMEM_BYTES = (POTF2_SMEM_BYTES > FUSED_CONS_DOUBLES * 8) ? POTF2_SMEM_BYTES : FUSED_CONS_DOUBLES * 8;
+// ---- one step of the batched factorisation: panel k  ||  trailing update with panel k-1 -----------------------
+// Grid (1-D, 1024 threads, STEP_SMEM_BYTES of LDS = one workgroup per CU):
+//   workgroups [0, nbatch*npanel): PANEL.  slot = wg / npanel, pw = wg % npanel, npanel = 2*(nb-1-k), at least 1; only
+//       the first 256 threads stay.
+//       Every panel workgroup stages block (k,k) in LDS and factors it itself (the factor is needed by all of them
+//       and takes as long on one CU as on sixty: recomputing it replaces a kernel boundary and a global round
+//       trip); pw = 0 also writes L_kk and the 16x16 inverses back.  Its four waves then solve rows
+//       (k+1)*128 + 64*pw + 16*wave .. +15 of block column k exactly like k_trsm_panel (same MFMA sequence, same
+//       bits), reading L_kk and the inverses from the workgroup's LDS; the rows are fetched into registers in
+//       accumulator layout BEFORE the factor loop, so their latency is hidden.
+//       Precondition: block column k is up to date with panels 0..k-1 (the k_syrk_trail colmode-1 launch before).
+//   the other workgroups: TRAILING UPDATE with panel k-1 of the lower 64x64 tiles right of block column k (tiles start
+//       at 128-block k+1; ntiles per slot, nbatch slots): four consecutive tiles per workgroup, one per 256-thread
+//       group with its own 36 KB LDS slice - the per-CU residency of four 256-thread k_syrk_trail<64,16> workgroups.
+//       All groups run the same K loop (K = 128), so the workgroup-wide barriers of gemm_tile line up; a group
+//       without a tile recomputes the last tile and does not store.
+// MEASURED (tools/ubench_upd.hip, profiles/r02_*): four tiles in one 1024-thread workgroup update at 33-36 TFLOP/s,
+// four 256-thread workgroups per CU at 48 - with static or queued tiles, hardware or per-group LDS barriers, either
+// wave-to-group mapping.  The fused step therefore only pays for a LONE factorisation (chain-bound at every step:
+// 1.72 vs 1.94 ms at N = 4096); batches go through the separate launches below, in lock step.
+// The two halves touch disjoint data: the panel writes block column k, the update reads block column k-1 and writes
+// tiles whose column is >= 128 (k+1).  Panel workgroups have the lowest indices, so they are dispatched first and the
+// update fills the CUs they leave (and theirs, once they are done); the launch lasts max(panel chain, update)
+// instead of their sum.
+constexpr int STEP_THREADS = 1024;
+constexpr int STEP_TILE_SMEM_DOUBLES = gemm_smem_doubles_exact<KC, KC, 64, 64, 16>();       // 4608 doubles = 36,864 B
+constexpr int STEP_SMEM_BYTES = POTF2_SMEM_BYTES;                                           // 150,528 B
+static_assert(4 * STEP_TILE_SMEM_DOUBLES * 8 <= STEP_SMEM_BYTES, "four update tiles must fit beside each other");
 
-__device__ __forceinline__ void trsm_stream_body(double* __restrict__ A, int64_t lda, const double* __restrict__ Dinv,
-                                                 int64_t ldl, int k, int wg, int* flag, int* __restrict__ info) {
+template <bool STAMP>
+__device__ __forceinline__ void chol_panel_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
+                                                int64_t ldl, int k, int pw, bool has_rows, int* __restrict__ info,
+                                                int nvalid, unsigned long long* __restrict__ stamps) {
   extern __shared__ double S[];
-  double* Xs = S;                              // [64][PLD]   row transposes (start / end)
-  double* Lp = S + 64 * PLD;                   // [2][16][PLD] staged row tiles of L_kk (double-buffered)
-  double* Dp = Lp + 2 * FUSED_LROW;            // [2][16][POTF2_DLD] staged invD_p
-  __shared__ int ok;
+  double* Dall = S + TILE * PLD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)wg * 64 + wave * 16;
-  const int64_t col0 = (int64_t)k * TILE;
-  const double* Lkk = A + col0 * lda + col0;
-  const double* Dk = Dinv + col0 * ldl + col0;
   const int g = lane >> 4, li = lane & 15;
+  const int nsteps = (nvalid + 15) >> 4;
+  const int64_t col0 = (int64_t)k * TILE;
+  double* Ab = A + col0 * lda + col0;
+  double* Ib = Linv + col0 * ldl + col0;
+  BOBE_STAMP(0);
+  potf2_stage_in(S, Dall, Ab, lda, nsteps);
+  // (keep the block's 64 staging registers and the 64 of X from being live together: 128 VGPRs per thread is all a
+  // 1024-thread workgroup gets)
+  __builtin_amdgcn_sched_barrier(0);
+  // this wave's 16 rows of the panel, straight into transposed-accumulator layout
+  // (lane (li, g), register r of tile p = A[row li][16p + g + 4r]); in flight during the whole factor loop
+  const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)pw * 64 + wave * 16;
   double* Aw = A + row0 * lda + col0;
-  double* Sw = Xs + (wave * 16) * PLD;
-  // this wave's 16 rows -> LDS slab -> transposed accumulators (no dependence on the factorisation)
-  {
-    v2d xr[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) xr[i] = *reinterpret_cast<const v2d*>(Aw + (int64_t)i * lda + 2 * lane);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) *reinterpret_cast<v2d*>(Sw + i * PLD + 2 * lane) = xr[i];
-  }
   v4d X[8];
+  if (has_rows) {
 #pragma unroll
-  for (int p = 0; p < 8; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[p][r] = Sw[li * PLD + 16 * p + g + 4 * r];
+      for (int r = 0; r < 4; ++r) X[p][r] = Aw[(int64_t)li * lda + 16 * p + g + 4 * r];
+  }
+  __syncthreads();
+  BOBE_STAMP(1);
+  potf2_factor_lds<STAMP, 4>(S, Dall, nsteps, (int)col0, info, stamps);
+  BOBE_STAMP(26);
+  if (pw == 0) potf2_stage_out(S, Dall, Ab, lda, Ib, ldl);
+  BOBE_STAMP(27);
+  if (!has_rows) return;
+  // X^T_p = invD_p * (A^T_p - sum_{q<p} L_kk[p][q] X^T_q), the MFMA sequence of k_trsm_panel
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
-    // wait for sub-panel p: lane 0 polls the flag with sc1 loads; the other waves load after the barrier
-    if (t == 0) {
-      int spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p + 1 && spins < (1 << 24)) {
-        __builtin_amdgcn_s_sleep(2);
-        ++spins;
-      }
-      ok = spins < (1 << 24);
-    }
-    __syncthreads();
-    if (!ok) {
-      if (t == 0) atomicMin(info, -1);
-      return;
-    }
-    double* Lb = Lp + (p & 1) * FUSED_LROW;
-    double* Db = Dp + (p & 1) * 16 * POTF2_DLD;
-    if (p > 0) {   // row tile p of L_kk, columns < 16p: thread t -> row t>>4, 8 columns from 8*(t&15)
-      const int rr = t >> 4, c0 = 8 * (t & 15);
-      if (c0 < 16 * p) {
-        const double* src = Lkk + (int64_t)(16 * p + rr) * lda + c0;
-        double v[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = ld_agent(src + c);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) Lb[rr * PLD + c0 + c] = v[c];
-      }
-    }
-    Db[(t >> 4) * POTF2_DLD + (t & 15)] = ld_agent(Dk + (int64_t)(16 * p + (t >> 4)) * ldl + 16 * p + (t & 15));
-    __syncthreads();
     v4d x = X[p];
 #pragma unroll
     for (int q = 0; q < p; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double av = -Lb[li * PLD + 16 * q + g + 4 * r];
+        const double av = -S[(16 * p + li) * PLD + 16 * q + g + 4 * r];
         x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[q][r], x, 0, 0, 0);
       }
     v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double av = Db[li * POTF2_DLD + g + 4 * r];
+      const double av = Dall[(p * 16 + li) * POTF2_DLD + g + 4 * r];
       y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, x[r], y, 0, 0, 0);
     }
     X[p] = y;
   }
-  // results back through the slab (each wave touches only its own 16 rows of Xs)
+  __syncthreads();   // every wave is done with L_kk (and pw 0 with writing it back): reuse the block as transposer
+  BOBE_STAMP(28);
+  double* Sw = S + (wave * 16) * PLD;
 #pragma unroll
   for (int p = 0; p < 8; ++p)
 #pragma unroll
     for (int r = 0; r < 4; ++r) Sw[li * PLD + 16 * p + g + 4 * r] = X[p][r];
+  // (each wave reads back only its own slab: no barrier needed, the wave's LDS accesses are ordered)
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     *reinterpret_cast<v2d*>(Aw + (int64_t)i * lda + 2 * lane) = *reinterpret_cast<const v2d*>(Sw + i * PLD + 2 * lane);
+  BOBE_STAMP(29);
 }
 
-__global__ __launch_bounds__(256) void k_panel_fused(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                                     int64_t ldl, int k, int* __restrict__ info, int* flags) {
-  if (blockIdx.x == 0)
-    potf2_body<true, false, true>(A, lda, Linv, ldl, k, info, nullptr, flags + k);
-  else
-    trsm_stream_body(A, lda, Linv, ldl, k, (int)blockIdx.x - 1, flags + k, info);
+// panel k of every slot as ONE 256-thread launch (grid = npanel x nbatch): the body above without an update half.
+// Replaces the k_potf2 + k_trsm_panel pair when all nbatch*npanel workgroups fit on the chip at once (the redundant
+// factorisations then cost nothing and one kernel boundary plus the L_kk round trip through global memory go away).
+template <bool STAMP = false>
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
+                                                    double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
+                                                    int npanel, int* __restrict__ info, int nvalid,
+                                                    unsigned long long* __restrict__ stamps = nullptr) {
+  const int slot = blockIdx.y;
+  chol_panel_body<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel > 1, info + slot, nvalid,
+                         stamps);
+}
+
+template <bool STAMP = false>
+__global__ __launch_bounds__(STEP_THREADS) void k_chol_step(double* __restrict__ A, int64_t lda, int64_t bsA,
+                                                            double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
+                                                            int nbatch, int npanel, int ntiles,
+                                                            int* __restrict__ info, int nvalid,
+                                                            unsigned long long* __restrict__ stamps = nullptr) {
+  extern __shared__ double smem[];
+  const int wg = blockIdx.x;
+  if (wg < nbatch * npanel) {
+    if (threadIdx.x >= 256) return;     // (a barrier waits only for the waves still alive)
+    const int slot = wg / npanel, pw = wg - slot * npanel;
+    chol_panel_body<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, pw, npanel > 1, info + slot, nvalid, stamps);
+    return;
+  }
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int total = nbatch * ntiles;
+  int tl = (wg - nbatch * npanel) * 4 + grp;
+  const bool live = tl < total;
+  if (!live) tl = total - 1;
+  const int slot = tl / ntiles;
+  double* As = A + slot * bsA;
+  int a, b;
+  tri_decode(tl - slot * ntiles, a, b);
+  const int64_t base = (int64_t)(k + 1) * TILE;
+  v4d acc[2][2];
+  load_tile<64, 64>(acc, As, lda, base + (int64_t)a * 64, base + (int64_t)b * 64, tid);
+  gemm_tile<KC, KC, 64, 64, 16, true>(acc, As, lda, base + (int64_t)a * 64, As, lda, base + (int64_t)b * 64,
+                                      (int64_t)(k - 1) * TILE, (int64_t)k * TILE, smem + grp * STEP_TILE_SMEM_DOUBLES, tid);
+  if (live) store_tile<64, 64>(acc, As, lda, base + (int64_t)a * 64, base + (int64_t)b * 64, 1.0, 0.0, tid);
 }
 
 // ---- trailing update: A[i][j] -= sum_{k0 <= k < k1} L[i][k] L[j][k]^T over lower T x T tiles ---------------
@@ -534,8 +576,9 @@ __global__ __launch_bounds__(256) void k_panel_fused(double* __restrict__ A, int
 // tile columns b < 128/T, rows b <= a < n, grid = S n - S(S-1)/2 with S = 128/T.
 template <int T, int BK>
 __global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k0, int k1, int first,
-                                                    int colmode, int n) {
+                                                    int colmode, int n, int64_t bsA = 0) {
   extern __shared__ double smem[];
+  A += blockIdx.y * bsA;
   int a, b;
   if (colmode == 0) {
     tri_decode(blockIdx.x, a, b);
@@ -592,8 +635,12 @@ template <int T>
 __global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L, int64_t ldl,
                                                     const double* __restrict__ Linv, int64_t ldi,
                                                     double* __restrict__ Tmp, int64_t ldt,
-                                                    const TriProb* __restrict__ probs, int nprob) {
+                                                    const TriProb* __restrict__ probs, int nprob, int64_t bsA = 0,
+                                                    int64_t bsL = 0, int64_t bsT = 0) {
   extern __shared__ double smem[];
+  L += blockIdx.y * bsA;
+  Linv += blockIdx.y * bsL;
+  Tmp += blockIdx.y * bsT;
   TriProb p;
   int e[2];
   if (!tri_find<T>(probs, nprob, blockIdx.x, p, e[0], e[1])) return;
@@ -612,8 +659,11 @@ __global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L
 template <int T>
 __global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, int64_t ldi,
                                                     const double* __restrict__ Tmp, int64_t ldt,
-                                                    const TriProb* __restrict__ probs, int nprob) {
+                                                    const TriProb* __restrict__ probs, int nprob, int64_t bsL = 0,
+                                                    int64_t bsT = 0) {
   extern __shared__ double smem[];
+  Linv += blockIdx.y * bsL;
+  Tmp += blockIdx.y * bsT;
   TriProb p;
   int e[2];
   if (!tri_find<T>(probs, nprob, blockIdx.x, p, e[0], e[1])) return;
@@ -638,9 +688,15 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(const double* __restrict_
                                                        int64_t n, const double* __restrict__ alpha,
                                                        const double* __restrict__ XsT, int64_t ldx, Hyper h,
                                                        double* __restrict__ partial, double* __restrict__ Kinv,
-                                                       int64_t ldk, const Hyper* __restrict__ hp = nullptr) {
+                                                       int64_t ldk, const Hyper* __restrict__ hp = nullptr,
+                                                       int64_t bsL = 0, int64_t bsV = 0, int64_t bsX = 0,
+                                                       int64_t bsP = 0) {
   extern __shared__ double smem[];
-  if (hp) h = *hp;
+  if (hp) h = hp[blockIdx.y];
+  Linv += blockIdx.y * bsL;
+  alpha += blockIdx.y * bsV;
+  XsT += blockIdx.y * bsX;
+  partial += blockIdx.y * bsP;
   int ti, tj;
   tri_decode(blockIdx.x, ti, tj);
   v4d acc[T / 32][T / 32];

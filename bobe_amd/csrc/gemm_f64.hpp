@@ -125,16 +125,50 @@ __device__ __forceinline__ void acc_zero(v4d (&acc)[FM][FN]) {
 
 // acc += A(m0.., k) * B(n0.., k) for k in [kbeg, kend); (kend - kbeg) must be a multiple of BK
 // (K ranges are multiples of 128 for the 128x128 callers and of 64 for the 64x64 callers).
-// smem: gemm_smem_doubles<TM,TN,BK>() doubles.  All 256 threads must call.
+// smem: gemm_smem_doubles<TM,TN,BK>() doubles.  All 256 threads must call.  `tid` (0..255) is the thread's index
+// inside its 256-thread tile group: threadIdx.x for the one-tile-per-workgroup kernels; k_chol_step runs four tile
+// groups in one 1024-thread workgroup (each with its own smem slice; the barriers inside are workgroup-wide, so
+// every group must run the same number of K-steps).
 // NEGA: accumulate -A*B (the A fragment is negated on the way into the MFMA).
-template <int LA, int LB, int TM = 128, int TN = 128, int BK = BK128, bool NEGA = false>
+// Barrier policies of gemm_tile.  WgSync: the whole workgroup computes one tile.  GroupSync: the workgroup holds
+// several independent 256-thread tile groups (k_chol_step); a group synchronises its four waves on a counter in
+// LDS (release-add, acquire-spin by lane 0 of each wave), so the groups drift apart like separate workgroups do and
+// one group's loads hide behind another's MFMAs.  The spin is bounded; on timeout *failed is set and the caller's
+// results are invalid (reported through the factorisation's info word).
+struct WgSync {
+  __device__ __forceinline__ void sync() { __syncthreads(); }
+};
+struct GroupSync {
+  int* ctr;      // LDS, zero-initialised, one per group
+  int gen;       // barriers passed
+  int* failed;   // LDS flag
+  __device__ __forceinline__ void sync() {
+    ++gen;
+    if ((threadIdx.x & 63) == 0) {
+      __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int spins = 0;
+      while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * gen) {
+        if (++spins > (1 << 22)) {
+          *failed = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+};
+
+template <int LA, int LB, int TM = 128, int TN = 128, int BK = BK128, bool NEGA = false, class SYNC = WgSync>
 __device__ __forceinline__ void gemm_tile(v4d (&acc)[TM / 32][TN / 32], const double* __restrict__ A, int64_t lda,
                                           int64_t m0, const double* __restrict__ B, int64_t ldb, int64_t n0,
-                                          int64_t kbeg, int64_t kend, double* smem) {
+                                          int64_t kbeg, int64_t kend, double* smem, int tid = threadIdx.x,
+                                          SYNC* sy = nullptr) {
+  WgSync wg_default;
   constexpr int FM = TM / 32, FN = TN / 32;
   constexpr int IA = Img<LA, TM, BK>::doubles;
   constexpr int IB = Img<LB, TN, BK>::doubles;
-  const int t = threadIdx.x;
+  const int t = tid;
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wm = (wave >> 1) * (TM / 2);
@@ -145,7 +179,7 @@ __device__ __forceinline__ void gemm_tile(v4d (&acc)[TM / 32][TN / 32], const do
   stage_load<LB, TN, BK>(rb, B, ldb, n0, kbeg, t);
   stage_store<LA, TM, BK>(ra, smem, t);
   stage_store<LB, TN, BK>(rb, smem + IA, t);
-  __syncthreads();
+  if (sy) sy->sync(); else wg_default.sync();
   int buf = 0;
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = (k0 + BK) < kend;
@@ -176,34 +210,34 @@ __device__ __forceinline__ void gemm_tile(v4d (&acc)[TM / 32][TN / 32], const do
       stage_store<LA, TM, BK>(ra, na, t);
       stage_store<LB, TN, BK>(rb, na + IA, t);
     }
-    __syncthreads();
+    if (sy) sy->sync(); else wg_default.sync();
     buf ^= 1;
   }
 }
 
 // Coordinates of accumulator element (i, j, r) of this lane inside the TM x TN tile.
 template <int TM = 128>
-__device__ __forceinline__ int acc_row(int i, int r) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ int acc_row(int i, int r, int tid = threadIdx.x) {
+  const int t = tid;
   return ((t >> 6) >> 1) * (TM / 2) + 16 * i + ((t & 63) >> 4) + 4 * r;
 }
 template <int TN = 128>
-__device__ __forceinline__ int acc_col(int j) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ int acc_col(int j, int tid = threadIdx.x) {
+  const int t = tid;
   return ((t >> 6) & 1) * (TN / 2) + 16 * j + (t & 15);
 }
 
 // C[m0+row][n0+col] = alpha*acc + beta*C   (row-major C, ldc)
 template <int TM = 128, int TN = 128>
 __device__ __forceinline__ void store_tile(const v4d (&acc)[TM / 32][TN / 32], double* __restrict__ C, int64_t ldc,
-                                           int64_t m0, int64_t n0, double alpha, double beta) {
+                                           int64_t m0, int64_t n0, double alpha, double beta, int tid = threadIdx.x) {
 #pragma unroll
   for (int i = 0; i < TM / 32; ++i)
 #pragma unroll
     for (int j = 0; j < TN / 32; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        double* q = C + (m0 + acc_row<TM>(i, r)) * ldc + n0 + acc_col<TN>(j);
+        double* q = C + (m0 + acc_row<TM>(i, r, tid)) * ldc + n0 + acc_col<TN>(j, tid);
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v += beta * (*q);
         *q = v;
@@ -213,13 +247,13 @@ __device__ __forceinline__ void store_tile(const v4d (&acc)[TM / 32][TN / 32], d
 // acc = C[m0+row][n0+col]  (issued early so the loads overlap the operand staging)
 template <int TM = 128, int TN = 128>
 __device__ __forceinline__ void load_tile(v4d (&acc)[TM / 32][TN / 32], const double* __restrict__ C, int64_t ldc,
-                                          int64_t m0, int64_t n0) {
+                                          int64_t m0, int64_t n0, int tid = threadIdx.x) {
 #pragma unroll
   for (int i = 0; i < TM / 32; ++i)
 #pragma unroll
     for (int j = 0; j < TN / 32; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = C[(m0 + acc_row<TM>(i, r)) * ldc + n0 + acc_col<TN>(j)];
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = C[(m0 + acc_row<TM>(i, r, tid)) * ldc + n0 + acc_col<TN>(j, tid)];
 }
 
 // map a linear index to a lower-triangular tile (i >= j), row-major enumeration: t = i(i+1)/2 + j

@@ -64,9 +64,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ---- coordinate scaling: out[j*ldo + i] = in[i*d + j] / ls[j]  (0 for i >= n) ------------
 // (hp, when given, overrides h with the device-resident hyper-parameters: a captured graph replays with new values)
+// Batched launches: blockIdx.y = slot picks hp[slot] and offsets `out` by bsO doubles per slot.
 __global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t npad, Hyper h,
-                               double* __restrict__ out, int64_t ldo, const Hyper* __restrict__ hp = nullptr) {
-  if (hp) h = *hp;
+                               double* __restrict__ out, int64_t ldo, const Hyper* __restrict__ hp = nullptr,
+                               int64_t bsO = 0) {
+  if (hp) h = hp[blockIdx.y];
+  out += blockIdx.y * bsO;
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= npad) return;
   for (int j = 0; j < h.d; ++j) out[j * ldo + i] = (i < n) ? in[i * h.d + j] / h.ls[j] : 0.0;
@@ -85,10 +88,15 @@ template <int KERN, bool SQUARE, int DCAP, bool FULL>
 __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ AT, int64_t lda, int64_t na,
                                                        const double* __restrict__ BT, int64_t ldb, int64_t nb,
                                                        Hyper h, double* __restrict__ out, int64_t ldo,
-                                                       const Hyper* __restrict__ hp = nullptr) {
-  if (hp) h = *hp;
+                                                       const Hyper* __restrict__ hp = nullptr, int64_t bsX = 0,
+                                                       int64_t bsO = 0) {
+  if (hp) h = hp[SQUARE ? blockIdx.y : 0];
   int ti, tj;
   if (SQUARE) {
+    // batched assembly of K(X,X): blockIdx.y = slot (its own scaled coordinates, hyper-parameters and output)
+    AT += blockIdx.y * bsX;
+    BT += blockIdx.y * bsX;
+    out += blockIdx.y * bsO;
     tri_decode(blockIdx.x, ti, tj);
   } else {
     ti = blockIdx.y;
@@ -254,7 +262,10 @@ __global__ __launch_bounds__(256) void k_wip_score(const double* __restrict__ cr
 // ---- matrix-vector products ---------------------------------------------------------------------
 // w[i] = sum_{k <= i} M[i][k] y[k]   (one wave per row, fixed summation order)
 __global__ __launch_bounds__(256) void k_gemv_lower(const double* __restrict__ M, int64_t ld, int64_t np,
-                                                    const double* __restrict__ y, double* __restrict__ w) {
+                                                    const double* __restrict__ y, double* __restrict__ w,
+                                                    int64_t bsM = 0, int64_t bsW = 0) {
+  M += blockIdx.y * bsM;      // batched: blockIdx.y = slot (y is shared by the slots)
+  w += blockIdx.y * bsW;
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= np) return;
@@ -268,7 +279,10 @@ __global__ __launch_bounds__(256) void k_gemv_lower(const double* __restrict__ M
 // where rb_min = (lower ? c/128 : 0).  grid.x = column strips of 64, grid.y = row blocks.
 __global__ __launch_bounds__(256) void k_gemv_t_part(const double* __restrict__ M, int64_t ld, int lower,
                                                      const double* __restrict__ w, double* __restrict__ part,
-                                                     int64_t ldp) {
+                                                     int64_t ldp, int64_t bsM = 0, int64_t bsW = 0, int64_t bsP = 0) {
+  M += blockIdx.z * bsM;      // batched: blockIdx.z = slot
+  w += blockIdx.z * bsW;
+  part += blockIdx.z * bsP;
   __shared__ double red[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + cx;
@@ -286,7 +300,9 @@ __global__ __launch_bounds__(256) void k_gemv_t_part(const double* __restrict__ 
 
 // out[c] = sum_{rb=rb0(c)}^{nrb-1} part[rb*ldp + c]   (fixed order)
 __global__ void k_colsum_parts(const double* __restrict__ part, int64_t ldp, int nrb, int lower, int64_t ncols,
-                               double* __restrict__ out) {
+                               double* __restrict__ out, int64_t bsP = 0, int64_t bsO = 0) {
+  part += blockIdx.y * bsP;   // batched: blockIdx.y = slot
+  out += blockIdx.y * bsO;
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncols) return;
   double s = 0.0;
@@ -297,7 +313,11 @@ __global__ void k_colsum_parts(const double* __restrict__ part, int64_t ldp, int
 // ---- scalar reductions ------------------------------------------------------------------------------
 // res[0] = sum_i w_i^2 ; res[1] = sum_i log L_ii        (single workgroup, fixed order)
 __global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
-                                                   int64_t np, double* __restrict__ res) {
+                                                   int64_t np, double* __restrict__ res, int64_t bsW = 0,
+                                                   int64_t bsL = 0, int64_t bsR = 0) {
+  w += blockIdx.x * bsW;      // batched: blockIdx.x = slot
+  L += blockIdx.x * bsL;
+  res += blockIdx.x * bsR;
   __shared__ double r0[4], r1[4];
   double a = 0.0, b = 0.0;
   for (int64_t i = threadIdx.x; i < np; i += 256) {
@@ -320,7 +340,10 @@ __global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w,
 // res[j] = 0.5 * sum_tiles partial[tile*stride + src(j)]: one wave per component, lane-strided partial
 // sums combined by a fixed butterfly (deterministic).  grid = d+1 blocks of 64 threads.
 __global__ __launch_bounds__(64) void k_grad_reduce(const double* __restrict__ partial, int ntiles, int stride, int d,
-                                                    int dcap, double* __restrict__ res) {
+                                                    int dcap, double* __restrict__ res, int64_t bsP = 0,
+                                                    int64_t bsR = 0) {
+  partial += blockIdx.y * bsP;   // batched: blockIdx.y = slot
+  res += blockIdx.y * bsR;
   const int j = blockIdx.x;
   const int src = (j == d) ? dcap : j;
   double s = 0.0;

@@ -162,6 +162,8 @@ int bobe_debug_linv(bobe_gp_t* gp, double* Linv);
 int bobe_debug_time_potrf(bobe_gp_t* gp, int reps, double* ms);
 /* B factorisations in flight at once (one evaluation slot each); *ms = device time for all B together */
 int bobe_debug_time_potrf_batch(bobe_gp_t* gp, int B, int reps, double* ms);
+/* the same B factorisations advancing in lock step through one batched launch sequence on the handle's stream */
+int bobe_debug_time_potrf_lockstep(bobe_gp_t* gp, int B, int reps, double* ms);
 /* Per-kernel-class device timing with HIP events recorded on the handle's stream around every launch
  * of the selected class (0 = off).  read() synchronises, returns the summed milliseconds and the
  * number of launches since the last select()/read(), and resets the counters. */
