@@ -4,19 +4,26 @@
 One *cycle* (SURVEY.md 8d / BASELINE.md section 2) =
     20 x [K(X,X) assembly + Cholesky + alpha + log-marginal-likelihood + analytic gradient]
        at the fixed theta schedule: the fit's 4 restarts (GP.fit / optim.py:335-354, independent L-BFGS-B runs)
-       x 5 evaluations each; every restart runs in its own host thread on its own evaluation slot of the library
-       (bobe_gp_mll_submit / bobe_gp_mll_wait), as GP.fit does (--fit-concurrency 1 = one bobe_gp_mll after the
-       other; --fit-mode batch = lock-step rounds through bobe_gp_mll_batch)
+       x 5 evaluations each.  --fit-mode slots: every restart in its own host thread on its own evaluation slot
+       (bobe_gp_mll_submit / bobe_gp_mll_wait, what GP.fit does); --fit-mode batch: lock-step rounds through
+       bobe_gp_mll_batch (one batched launch sequence per round); --fit-concurrency 1: one after the other.
   + 1 x refactor at the last theta    (bobe_gp_factor)
   + 1 x sweep: posterior mean & variance of all C candidates, WIPV and WIPStd scores against the
         M = 512 integration points, argmin of both  (bobe_gp_wip_sweep)
 All inputs are resident in HBM before the timed region; outputs stay in HBM (only the d+2 MLL
 scalars and the two argmins cross PCIe, as they do in the BO loop).
 
-Multi-GPU (one process per GPU, torch.distributed / RCCL): weak scaling.  Every rank holds the full
-factor and runs the 20 evaluations of its own restarts (the reference shards restarts over ranks,
-BOBE/pool.py:298-326), sweeps its own shard of the N_gpus x C candidate set, and the ranks exchange
-(min score, global index) with one all-gather; value = cycles completed by all ranks / wall time.
+Multi-GPU (one process per GPU, torch.distributed / RCCL).  ``--gpus N`` without a torchrun environment starts the
+N ranks itself (a child ``python -m torch.distributed.run``, before this process touches the GPU) and exits with its
+status; under torchrun it insists that WORLD_SIZE == N.
+  weak  (--config headline, default): every rank holds the full factor, runs the 20 evaluations of its own restarts
+        and sweeps its own 65 536 candidates (rows [rank*C, (rank+1)*C) of the Sobol set); value = cycles of all
+        ranks / wall time.
+  strong (--config shard = BASELINE.json configs[3]): ONE cycle over 262 144 candidates split into contiguous shards
+        (np.array_split bounds), the fit's 4 restarts split over the ranks the way the reference's MPI pool splits
+        them (BOBE/pool.py:298-326); value = cycles / wall time.
+Either way the ranks exchange (min score, global index) with one all-gather per sweep and (best mll, theta) with one
+per fit.
 
 Prints ONE JSON line (rank 0).
 """
@@ -26,6 +33,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,64 +45,100 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD spec; = 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
+SHARD_TOTAL_CANDIDATES = 262144
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="headline", choices=["tiny", "small", "headline", "large"])
+    ap.add_argument("--config", default="headline", choices=["tiny", "small", "headline", "large", "shard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-class", default="trimul", help="kernel class timed with HIP events for the roofline")
-    ap.add_argument("--fit-concurrency", type=int, default=4,
-                    help="restarts of the fit evaluated together per bobe_gp_mll_batch call (1 = sequential)")
+    ap.add_argument("--fit-concurrency", type=int, default=4, help="restarts of the fit in flight together (1 = sequential)")
     ap.add_argument("--fit-mode", default="slots", choices=["slots", "batch"],
                     help="slots: one thread + evaluation slot per restart, no barrier; batch: lock-step rounds")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk of the sweep (0 = library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a single GPU")
-    return ap.parse_args()
+    ap.add_argument("--shard-candidates", type=int, default=SHARD_TOTAL_CANDIDATES,
+                    help="total candidates of --config shard (tests use a smaller set)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(X, y, cand, Z, thetas, noise, sample_c=2048):
-    """Oracle ("port") timed on the host cores on a bounded sample of the same cycle; extrapolated linearly."""
-    from oracle import bobe_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        nthreads = os.cpu_count() or 1
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks(args) -> int:
+    """--gpus N from a plain shell: start the N ranks as a child torchrun.  Runs BEFORE torch / HIP are touched in
+    this process (a process that has initialised the GPU must not be replaced or forked on this pool)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_baseline(X, y, cand, Z, thetas, noise, gpu_check, sample_c=4096, samples=5):
+    """The cycle on the host cores (oracle/cpu_port.py, kind "port": the same rank-1 algorithm on torch-CPU fp64 ->
+    LAPACK/BLAS, all threads): one warm-up, then the MEDIAN of ``samples`` value+gradient evaluations, one refactor,
+    one sweep of a ``sample_c``-candidate sample; extrapolated linearly to the full cycle."""
+    from oracle import cpu_port as P
     d = X.shape[1]
+    ls0, kv0 = np.exp(thetas[0, :d]), float(np.exp(thetas[0, d]))
+    mll0, g0 = P.cycle_value_and_grad(X, y, ls0, kv0, noise)              # warm-up (also the parity reference)
+    t_vg = []
+    for _ in range(samples):
+        t0 = time.perf_counter()
+        P.cycle_value_and_grad(X, y, ls0, kv0, noise)
+        t_vg.append(time.perf_counter() - t0)
+    ls1, kv1 = np.exp(thetas[-1, :d]), float(np.exp(thetas[-1, d]))
+    P.factor(X, y, ls1, kv1, noise)
     t0 = time.perf_counter()
-    O.cycle_value_and_grad(X, y, np.exp(thetas[0, :d]), float(np.exp(thetas[0, d])), noise)
-    t_vg = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    gp = O.OracleGP(X, y, noise=noise, kernel="rbf", lengthscales=np.exp(thetas[-1, :d]),
-                    kernel_variance=float(np.exp(thetas[-1, d])))
+    f = P.factor(X, y, ls1, kv1, noise)
     t_fac = time.perf_counter() - t0
     sc = min(sample_c, cand.shape[0])
+    P.wip_sweep(f, cand[:min(sc, 512)], Z, chunk=512)
     t0 = time.perf_counter()
-    O.wip_sweep(gp, cand[:sc], Z, chunk=sc)
+    sw = P.wip_sweep(f, cand[:sc], Z, chunk=2048)
     t_sw = time.perf_counter() - t0
-    cyc = len(thetas) * t_vg + t_fac + t_sw * (cand.shape[0] / sc)
-    return {"value": 1.0 / cyc, "unit": "cycles/s", "cores": int(nthreads), "kind": "port",
-            "sample": f"1 of {len(thetas)} value+grad ({t_vg:.2f}s), 1 refactor ({t_fac:.2f}s), "
-                      f"{sc} of {cand.shape[0]} candidates ({t_sw:.2f}s); extrapolated linearly; "
-                      f"NumPy/SciPy-OpenBLAS fp64"}
+    vg = float(np.median(t_vg))
+    cyc = len(thetas) * vg + t_fac + t_sw * (cand.shape[0] / sc)
+    host = P.host_description()
+    par = {}
+    if gpu_check is not None:
+        par = {"rel_dmll_theta0": abs(gpu_check["mll0"] - mll0) / abs(mll0),
+               "rel_dgrad_theta0": float(np.max(np.abs(gpu_check["grad0"] - g0)) / np.max(np.abs(g0))),
+               "sample_wipstd_max_rel": float(np.max(np.abs(gpu_check["wipstd"][:sc] - sw["wipstd"]) / np.abs(sw["wipstd"]))),
+               "sample_argmin_equal": bool(int(np.argmin(gpu_check["wipstd"][:sc])) == sw["argmin_s"])}
+    return {"value": 1.0 / cyc, "unit": "cycles/s", "cores": host["threads"], "kind": "port",
+            "sample": f"median of {samples} value+grad after 1 warm-up ({vg:.3f}s; min {min(t_vg):.3f}, max {max(t_vg):.3f}) "
+                      f"x {len(thetas)}, 1 refactor ({t_fac:.3f}s), {sc} of {cand.shape[0]} candidates ({t_sw:.3f}s) "
+                      f"extrapolated linearly; same rank-1 sweep algorithm as the GPU",
+            "host": host, "seconds_per_cycle": cyc, "parity_vs_gpu": par}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}` "
+                         f"or plain `python bench.py --gpus {args.gpus}`")
     import torch
     import torch.distributed as dist
     from bobe_amd import _lib
     from bobe_amd.gp import GP
     from bobe_amd.synthetic import CONFIGS, synthetic_problem, theta_schedule
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback)")
     if args.backend == "gloo":
@@ -104,14 +149,24 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == args.backend
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     coll_dev = dev if args.backend == "nccl" else None   # where the all-gather payload lives
-    from bobe_amd.dist_sweep import merge_argmin, merge_best_fit
+    from bobe_amd.dist_sweep import merge_argmin, merge_best_fit, shard_bounds
 
-    N, d, Cn, M = CONFIGS[args.config]
+    strong = args.config == "shard"
+    if strong:
+        N, d, _, M = CONFIGS["headline"]
+        c_total = int(args.shard_candidates)
+        c_lo, c_hi = shard_bounds(c_total, world, rank)
+    else:
+        N, d, c_per, M = CONFIGS[args.config]
+        c_total = world * c_per
+        c_lo, c_hi = rank * c_per, (rank + 1) * c_per
+    Cn = c_hi - c_lo
     noise = 1e-6
-    X, y, cand, Z = synthetic_problem(N, d, Cn, M, noise=noise, cand_offset=rank * Cn)
+    X, y, cand, Z = synthetic_problem(N, d, Cn, M, noise=noise, cand_offset=c_lo)
     thetas = theta_schedule(d)
     gp = GP(X, y, noise=noise, kernel="rbf", lengthscales=np.full(d, 0.6), kernel_variance=1.0, device=local)
     lib, h = gp._lib, gp._h
@@ -133,46 +188,56 @@ def main():
     av, asd, mv, ms = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
     last = {}
 
-    R = max(1, args.fit_concurrency)
+    R_total = max(1, args.fit_concurrency)              # restarts of the fit (= evaluations in flight on one GPU)
+    # restarts this rank runs: all of them (weak: its own fit), or its np.array_split share (strong: pool.py:298-326)
+    my_restarts = list(range(R_total)) if not strong else list(range(*shard_bounds(R_total, world, rank)))
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=max(1, R))
+    pool = ThreadPoolExecutor(max_workers=max(1, R_total))
     ls_all = np.ascontiguousarray(np.exp(thetas[:, :d]))
     kv_all = np.ascontiguousarray(np.exp(thetas[:, d]))
-    mll_b = np.empty(len(thetas))
+    mll_b = np.full(len(thetas), -np.inf)
     grad_b = np.empty((len(thetas), d + 1))
 
-    def fit_evals():
-        """the 20 value+gradient evaluations; returns (best mll, its theta, last mll)"""
-        best = (-np.inf, None)
-        if R == 1:
-            for k, th in enumerate(thetas):
-                _lib.check(lib.bobe_gp_mll(h, _lib.ptr(ls_all[k]), float(kv_all[k]), C.byref(mll), _lib.ptr(grad)), "mll")
-                mll_b[k] = mll.value
-        elif args.fit_mode == "slots":
-            def chain(r):                            # restart r: its evaluations, one after the other, on slot r
+    def fit_evals(restarts, mode):
+        """the value+gradient evaluations of ``restarts`` (restart r owns thetas r, r+R, r+2R, ...)"""
+        ks = [[k for k in range(r, len(thetas), R_total)] for r in restarts]
+        if not ks:
+            return (-np.inf, thetas[0])
+        if len(restarts) == 1 or mode == "sequential":
+            for chain_k in ks:
+                for k in chain_k:
+                    _lib.check(lib.bobe_gp_mll(h, _lib.ptr(ls_all[k]), float(kv_all[k]), C.byref(mll), _lib.ptr(grad)), "mll")
+                    mll_b[k] = mll.value
+                    grad_b[k] = grad
+        elif mode == "slots":
+            def chain(slot, chain_k):                # a restart: its evaluations one after the other on its slot
                 m_, g_ = C.c_double(), np.empty(d + 1)
-                for k in range(r, len(thetas), R):
-                    _lib.check(lib.bobe_gp_mll_submit(h, r, _lib.ptr(ls_all[k]), float(kv_all[k]), 1), "mll_submit")
-                    _lib.check(lib.bobe_gp_mll_wait(h, r, C.byref(m_), _lib.ptr(g_)), "mll_wait")
+                for k in chain_k:
+                    _lib.check(lib.bobe_gp_mll_submit(h, slot, _lib.ptr(ls_all[k]), float(kv_all[k]), 1), "mll_submit")
+                    _lib.check(lib.bobe_gp_mll_wait(h, slot, C.byref(m_), _lib.ptr(g_)), "mll_wait")
                     mll_b[k] = m_.value
                     grad_b[k] = g_
-            futs = [pool.submit(chain, r) for r in range(R)]
-            for f in futs:
+            for f in [pool.submit(chain, s, ck) for s, ck in enumerate(ks)]:
                 f.result()
-        else:
-            for k0 in range(0, len(thetas), R):      # round k0/R of the R restarts
-                nb_ = min(R, len(thetas) - k0)
-                _lib.check(lib.bobe_gp_mll_batch(h, nb_, _lib.ptr(ls_all[k0:k0 + nb_]), _lib.ptr(kv_all[k0:k0 + nb_]),
-                                                 _lib.ptr(mll_b[k0:k0 + nb_]), _lib.ptr(grad_b[k0:k0 + nb_]), None),
+        else:                                        # lock-step rounds: evaluation j of every restart together
+            for j in range(max(len(ck) for ck in ks)):
+                idx = np.array([ck[j] for ck in ks if j < len(ck)])
+                lsr, kvr = np.ascontiguousarray(ls_all[idx]), np.ascontiguousarray(kv_all[idx])
+                mr, gr = np.empty(len(idx)), np.empty((len(idx), d + 1))
+                _lib.check(lib.bobe_gp_mll_batch(h, len(idx), _lib.ptr(lsr), _lib.ptr(kvr), _lib.ptr(mr), _lib.ptr(gr), None),
                            "mll_batch")
-        for k, th in enumerate(thetas):
-            if mll_b[k] > best[0]:
-                best = (float(mll_b[k]), th)
-        return best
+                mll_b[idx] = mr
+                grad_b[idx] = gr
+        mine = [k for ck in ks for k in ck if np.isfinite(mll_b[k])]      # a NaN (K not positive definite) never wins
+        if not mine:
+            return (-np.inf, thetas[0])
+        kb = max(mine, key=lambda k: mll_b[k])
+        return (float(mll_b[kb]), thetas[kb])
+
+    fit_mode = "sequential" if R_total == 1 else args.fit_mode
 
     def cycle():
-        best = fit_evals()
-        mll.value = float(mll_b[-1])
+        best = fit_evals(my_restarts, fit_mode)
         _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")
         _lib.check(lib.bobe_gp_factor(h), "factor")
         _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
@@ -180,9 +245,12 @@ def main():
                                          C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
         # the path's exchange step: one all-gather of (min score, global index) — lowest global index wins
         # ties (jnp.argmin) — and one of (best mll, theta) for the restart-sharded fit (pool.py:322-326)
-        gmin, gidx = merge_argmin(ms.value, rank * Cn + asd.value, device=coll_dev)
+        gmin, gidx = merge_argmin(ms.value, c_lo + asd.value, device=coll_dev)
         bmll, bth = merge_best_fit(best[0], best[1], device=coll_dev)
-        last.update(mll=mll.value, best_mll=float(bmll), argmin=int(gidx), min_wipstd=float(gmin))
+        if os.environ.get("BENCH_DEBUG"):
+            print(f"[rank {rank}] restarts {my_restarts} local best {best[0]!r} merged {bmll!r} mll_b {np.round(mll_b, 3).tolist()}",
+                  file=sys.stderr, flush=True)
+        last.update(best_mll=float(bmll), argmin=int(gidx), min_wipstd=float(gmin))
 
     def barrier():
         if world > 1:
@@ -208,32 +276,37 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    fit_ms = {}
-    if rank == 0:               # the fit alone, both ways (outside the timed region)
-        for r_ in sorted({1, R}):
-            R_keep, R = R, r_
-            fit_evals()
-            lib.bobe_gp_sync(h)
-            t1 = time.perf_counter()
-            fit_evals()
-            lib.bobe_gp_sync(h)
-            fit_ms["concurrency_%d" % r_] = (time.perf_counter() - t1) * 1e3
-            R = R_keep
-    sub_ms, lbfgs = {}, None
-    if rank == 0:               # the other two sub-times of a cycle and a real L-BFGS-B fit, untimed region
+    def timed(fn, reps=2):
+        fn()
         lib.bobe_gp_sync(h)
         t1 = time.perf_counter()
-        _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")
-        _lib.check(lib.bobe_gp_factor(h), "factor")
+        for _ in range(reps):
+            fn()
         lib.bobe_gp_sync(h)
-        t2 = time.perf_counter()
-        _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
-                                         _lib.ptr(out_wipstd), _lib.ptr(out_mean), _lib.ptr(out_var),
-                                         C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
-        lib.bobe_gp_sync(h)
-        t3 = time.perf_counter()
-        sub_ms = {"fit": fit_ms.get("concurrency_%d" % R), "refactor": (t2 - t1) * 1e3, "sweep": (t3 - t2) * 1e3}
-        if args.config != "tiny":
+        return (time.perf_counter() - t1) * 1e3 / reps
+
+    fit_ms, sub_ms, lbfgs, gpu_check = {}, {}, None, None
+    if rank == 0:               # secondary measurements, outside the timed region: the three phases of a cycle on rank 0
+        all_r = list(range(R_total))
+        fit_ms["sequential"] = timed(lambda: fit_evals(all_r, "sequential"), 1)
+        if R_total > 1:
+            fit_ms[f"slots_{R_total}"] = timed(lambda: fit_evals(all_r, "slots"))
+            fit_ms[f"lockstep_{R_total}"] = timed(lambda: fit_evals(all_r, "batch"))
+        if strong and world > 1:
+            fit_ms["this_rank_share"] = timed(lambda: fit_evals(my_restarts, fit_mode))
+
+        def refactor():
+            _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")
+            _lib.check(lib.bobe_gp_factor(h), "factor")
+
+        def sweep():
+            _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
+                                             _lib.ptr(out_wipstd), _lib.ptr(out_mean), _lib.ptr(out_var),
+                                             C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
+        key = "sequential" if R_total == 1 else (f"slots_{R_total}" if args.fit_mode == "slots" else f"lockstep_{R_total}")
+        sub_ms = {"fit": fit_ms[key], "refactor": timed(refactor), "sweep": timed(sweep)}
+        gpu_check = {"mll0": float(mll_b[0]), "grad0": grad_b[0].copy(), "wipstd": out_wipstd.cpu().numpy()}
+        if args.config not in ("tiny",):
             # GP.fit as the BO loop calls it for N >= 750 (bo.py:651-653): 4 restarts (pool.py:277-286 recipe), maxiter 200
             from bobe_amd.bo import gp_fit
             calls = [0]
@@ -244,21 +317,27 @@ def main():
                 return orig(*a, **k)
             gp.mll_data = counted
             t4 = time.perf_counter()
-            r_fit = gp_fit(gp, maxiters=200, n_restarts=4, rng=np.random.default_rng(7))
+            r_fit = gp_fit(gp, maxiters=200, n_restarts=4, rng=np.random.default_rng(7), distributed=False)
             t5 = time.perf_counter()
             gp.mll_data = orig
-            _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")   # back to the cycle's state
-            _lib.check(lib.bobe_gp_factor(h), "factor")
+            refactor()                                   # back to the cycle's state
             lbfgs = {"restarts": 4, "maxiter": 200, "seconds": t5 - t4, "evaluations": calls[0],
                      "ms_per_evaluation": (t5 - t4) * 1e3 / max(calls[0], 1), "mll": float(r_fit["mll"])}
     if rank == 0:
-        # Cholesky GF/s: mean device time of the factorisation alone (HIP events on the handle's stream)
-        potrf_ms = C.c_double()
-        lib.bobe_debug_time_potrf(h, 3, C.byref(potrf_ms))
-        potrf_b_ms = C.c_double()
-        if R > 1:
-            _lib.check(lib.bobe_debug_time_potrf_batch(h, min(R, 8), 3, C.byref(potrf_b_ms)), "time_potrf_batch")
-        Np = (N + 127) // 128 * 128
+        # Cholesky: mean device time of the factorisation alone (HIP events on the handle's stream): a lone one, B
+        # advancing in lock step through one batched launch sequence, and (round 1's form) B on private streams
+        chol = {}
+        ms_ = C.c_double()
+        _lib.check(lib.bobe_debug_time_potrf(h, 3, C.byref(ms_)), "time_potrf")
+        potrf_ms = ms_.value
+        flops_potrf = N ** 3 / 3.0
+        for B in (4, 8):
+            _lib.check(lib.bobe_debug_time_potrf_lockstep(h, B, 3, C.byref(ms_)), "time_potrf_lockstep")
+            chol[f"lockstep_{B}"] = {"in_flight": B, "ms_all": ms_.value, "gflops": B * flops_potrf / (ms_.value * 1e-3) / 1e9,
+                                     "frac_of_fp64_mfma_peak": B * flops_potrf / (ms_.value * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+        _lib.check(lib.bobe_debug_time_potrf_batch(h, 4, 3, C.byref(ms_)), "time_potrf_batch")
+        chol["streams_4"] = {"in_flight": 4, "ms_all": ms_.value, "gflops": 4 * flops_potrf / (ms_.value * 1e-3) / 1e9,
+                             "frac_of_fp64_mfma_peak": 4 * flops_potrf / (ms_.value * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
         chunk = args.chunk or 8192
         # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 per candidate, triangular) fused with
         # the cross-covariance rows W_Z^T K(X,C) (2 N M per candidate)
@@ -277,33 +356,46 @@ def main():
             roof = {"bound": "mfma", "kernel": "k_" + args.profile_class, "achieved": ach,
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(launches.value),
-                    "flops_per_launch": flops_per_launch}
+                    "flops_per_launch": flops_per_launch,
+                    "note": "largest single kernel of the cycle by time (the sweep's GEMM); the fit phase is priced in roofline_fit"}
+        # the fit phase as a whole: 20 value+gradient evaluations = 20 N^3 flops (potrf N^3/3 + inverse N^3/3 + K^-1/gradient N^3/3)
+        fit_s = sub_ms["fit"] * 1e-3
+        fit_ach = len(thetas) * float(N) ** 3 / fit_s / 1e12
+        roof_fit = {"bound": "mfma", "phase": f"fit: {len(thetas)} x value+gradient ({key})", "achieved": fit_ach,
+                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fit_ach / FP64_MFMA_PEAK_TFLOPS,
+                    "flops": len(thetas) * float(N) ** 3, "ms": sub_ms["fit"],
+                    "share_of_cycle": sub_ms["fit"] / (sub_ms["fit"] + sub_ms["refactor"] + sub_ms["sweep"]),
+                    "potrf_ms_alone": potrf_ms, "potrf_frac_of_peak_alone": flops_potrf / (potrf_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+        cfg_name = {"headline": "(BASELINE.json configs[2])", "small": "(BASELINE.json configs[1])",
+                    "shard": "(BASELINE.json configs[3])"}.get(args.config, "(not a BASELINE.json config)")
         out = {
-            "metric": "GP fit+acquisition cycles/sec at N=4096 d=8, 65536 cands; Cholesky GF/s",
-            "value": world * args.steps / elapsed, "unit": "cycles/s", "n_gpus": world, "steps": args.steps,
+            "metric": f"GP fit+acquisition cycles/sec at N={N} d={d}, {c_total if strong else Cn} cands; Cholesky GF/s",
+            "value": (1 if strong else world) * args.steps / elapsed, "unit": "cycles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic RBF GP N={N} d={d}, {Cn} candidates per GPU, M={M}, fp64 "
-                                   + {"headline": "(BASELINE.json configs[2])", "small": "(BASELINE.json configs[1])"}.get(
-                                       args.config, "(not a BASELINE.json config)"),
-                       "N": N, "d": d, "candidates_per_gpu": Cn, "M": M, "evals_per_cycle": len(thetas),
-                       "fit": f"{R} restarts x {len(thetas) // R} value+gradient evaluations, restarts concurrent ({args.fit_mode})"
-                              if R > 1 else f"{len(thetas)} sequential value+gradient evaluations",
-                       "parallelism": f"candidate-sharded x{world}"},
-            "cholesky_gflops": (N ** 3 / 3.0) / (potrf_ms.value * 1e-3) / 1e9,
-            "cholesky_ms": potrf_ms.value,
-            "cholesky_concurrent": ({"in_flight": min(R, 8), "ms_all": potrf_b_ms.value,
-                                     "gflops": min(R, 8) * (N ** 3 / 3.0) / (potrf_b_ms.value * 1e-3) / 1e9,
-                                     "frac_of_fp64_mfma_peak": min(R, 8) * (N ** 3 / 3.0) / (potrf_b_ms.value * 1e-3) / 1e12
-                                     / FP64_MFMA_PEAK_TFLOPS} if R > 1 else None),
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic RBF GP N={N} d={d}, "
+                                   + (f"{c_total} candidates split over {world} GPU(s)" if strong else f"{Cn} candidates per GPU")
+                                   + f", M={M}, fp64 {cfg_name}",
+                       "N": N, "d": d, "candidates_per_gpu": Cn, "candidates_total": c_total, "M": M,
+                       "evals_per_cycle": len(thetas),
+                       "fit": (f"{R_total} restarts x {len(thetas) // R_total} value+gradient evaluations, restarts concurrent ({args.fit_mode})"
+                               + (f", split over the ranks (this rank: restarts {my_restarts})" if strong and world > 1 else ""))
+                       if R_total > 1 else f"{len(thetas)} sequential value+gradient evaluations",
+                       "parallelism": f"candidate-sharded x{world}" + (", restart-sharded fit" if strong else ""),
+                       "backend": args.backend if world > 1 else None},
+            "cholesky_gflops": flops_potrf / (potrf_ms * 1e-3) / 1e9,
+            "cholesky_ms": potrf_ms,
+            "cholesky_concurrent": chol["lockstep_4"],
+            "cholesky": chol,
             "fit_ms": fit_ms,
             "sub_ms": sub_ms,
             "lbfgs_fit": lbfgs,
             "check": last,
             "roofline": roof,
+            "roofline_fit": roof_fit,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(X, y, cand, Z, thetas, noise)
+            out["cpu_baseline"] = cpu_baseline(X, y, cand, Z, thetas, noise, gpu_check)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -58,6 +58,8 @@ SIGNATURES = [
                                  C.c_double, C.c_int, C.c_void_p]),
     ("bobe_gp_get_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_set_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("bobe_gp_clone_state", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("bobe_gp_append", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ("bobe_gp_npoints", C.c_int64, [C.c_void_p]),
     ("bobe_debug_gemm", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),

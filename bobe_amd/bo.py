@@ -30,14 +30,15 @@ _ACQ = {"wipv": WIPV, "wipstd": WIPStd, "ei": EI, "logei": LogEI}
 
 
 def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.random.Generator] = None,
-           group=None) -> dict:
+           group=None, distributed: bool = True) -> dict:
     """``MPI_Pool.gp_fit`` (pool.py:268-328): x0 row 0 = log(current hp), further rows uniform in the log-bounds;
     fit; adopt the best hyper-parameters (refactors on the GPU).
 
     With an initialised ``torch.distributed`` group of G > 1 ranks (one process per GPU, every rank running the
     same loop with the same seed) the restarts are split over the ranks the way the reference's MPI pool splits
     them (``np.array_split``, pool.py:298-326): each rank runs its chunk — concurrently, on the evaluation slots of
-    its own GPU — then one all-gather of (mll, theta) and max-by-mll; every rank adopts the same theta."""
+    its own GPU — then one all-gather of (mll, theta) and max-by-mll; every rank adopts the same theta.
+    ``distributed=False`` keeps the fit on this rank (no collective: for calls that not every rank makes)."""
     rng = np.random.default_rng() if rng is None else rng
     n_params = gp.hyperparam_bounds.shape[1]
     init = np.log(gp.get_hyperparams())
@@ -46,7 +47,7 @@ def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.r
                                           size=(n_restarts - 1, n_params))])
     else:
         x0 = np.atleast_2d(init)
-    world, rank, coll_dev = dist_info(group, gp.device)
+    world, rank, coll_dev = dist_info(group, gp.device) if distributed else (1, 0, None)
     if world > 1 and x0.shape[0] > 1:
         lo, hi = shard_bounds(x0.shape[0], world, rank)
         res = gp.fit(x0=x0[lo:hi], maxiter=maxiters) if hi > lo else {"mll": -np.inf, "params": init}

@@ -158,7 +158,7 @@ class GPwithClassifier(GP):
         return super().get_random_point(rng=rng, nstd=nstd)
 
     @classmethod
-    def from_state_dict(cls, state, device: int = 0):
+    def from_state_dict(cls, state, device: int = 0, _clone_of=None):
         """clf_gp.py:322-386: rebuilt from the CLASSIFIER data set (the GP subset is re-derived by the thresholds),
         hyper-parameters from the state (the GP is factored again on the GPU, as the reference recomputes it),
         classifier parameters and flags restored without retraining."""
@@ -185,9 +185,9 @@ class GPwithClassifier(GP):
             g._clf_predict_func = get_svm_predict_proba_fn(g.clf_params)
         return g
 
-    def state_dict(self):
+    def state_dict(self, with_factor: bool = True):
         """clf_gp.py:279-320: base GP state + classifier data / configuration / parameters."""
-        state = super().state_dict()
+        state = super().state_dict(with_factor=with_factor)
         state.update({"train_x_clf": np.array(self.train_x_clf), "train_y_clf": np.array(self.train_y_clf),
                       "clf_type": self.clf_type, "clf_settings": self.clf_settings, "clf_use_size": self.clf_use_size,
                       "clf_update_step": self.clf_update_step, "probability_threshold": self.probability_threshold,

@@ -167,7 +167,7 @@ struct bobe_gp {
   bool have_data = false, factored = false, not_pd = false;
   int64_t chunk = 8192;
 
-  DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs, flags;
+  DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs, flags, diag;
   int num_cus = 0;
   // sweep / predict workspace
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
@@ -189,7 +189,7 @@ struct bobe_gp {
   };
   struct Slot {
     hipStream_t stream = nullptr;
-    DBuf XsT2, A2, Linv2, Tmp, alpha2, w2, part, gpart, res, info, flags;
+    DBuf XsT2, A2, Linv2, Tmp, alpha2, w2, part, gpart, res, info, flags, diag;
     EvalGraph eg;
     double* h_res = nullptr;
     hipEvent_t ev = nullptr;
@@ -211,7 +211,7 @@ struct bobe_gp {
     std::swap(stream, s.stream);
     std::swap(XsT2, s.XsT2); std::swap(A2, s.A2); std::swap(Linv2, s.Linv2); std::swap(Tmp, s.Tmp);
     std::swap(alpha2, s.alpha2); std::swap(w2, s.w2); std::swap(part, s.part); std::swap(gpart, s.gpart);
-    std::swap(res, s.res); std::swap(info, s.info); std::swap(flags, s.flags);
+    std::swap(res, s.res); std::swap(info, s.info); std::swap(flags, s.flags); std::swap(diag, s.diag);
     std::swap(h_res, s.h_res);
     std::swap(eg, s.eg);
     in_slot = !in_slot;
@@ -222,7 +222,7 @@ struct bobe_gp {
   struct BatchWs {
     int cap = 0;
     int64_t Np = 0;
-    DBuf A, Linv, Tmp, XsT, w, alpha, part, gpart, res, info, hyp;
+    DBuf A, Linv, Tmp, XsT, w, alpha, part, gpart, res, info, hyp, diag;
     Hyper* h_hyp = nullptr;      // pinned [BOBE_MAX_MLL_SLOTS]
     double* h_res = nullptr;     // pinned [BOBE_MAX_MLL_SLOTS][128]
     int* h_info = nullptr;       // pinned [BOBE_MAX_MLL_SLOTS]
@@ -293,8 +293,8 @@ struct bobe_gp {
   void assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev = nullptr, int B = 1,
                     int64_t bsX = 0, int64_t bsA = 0);
   void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0);
-  void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0);
-  void potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL);
+  void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0, double* dg = nullptr);
+  void potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg);
   void trtri(const double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
   int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
             const Hyper* hdev = nullptr, double* gp_out = nullptr, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
@@ -364,6 +364,7 @@ void bobe_gp::alloc_for_n() {
   res.ensure(128 * sizeof(double));
   info.ensure(sizeof(int));
   flags.ensure((size_t)nb * sizeof(int));
+  diag.ensure((size_t)nb * TILE * TILE * sizeof(double));
   build_probs();
 }
 
@@ -451,10 +452,12 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
 //   1. k_syrk_trail (colmode 1): block column k receives panel k-1 - the only part of the update panel k waits for;
 //   2. k_chol_step: panel k side by side with the rest of the update by panel k-1, in one launch.
 // Every matrix element sees the same operation sequence in all three forms (same bits).
-void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL) {
+void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
   const Tuning& tu = tuning();
+  if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches (B = 1)
+  const int64_t bsD = (int64_t)nb * TILE * TILE;
   if (B > 1 || tu.chol_legacy || !tu.chol_lookahead) {
-    potrf_legacy(a, linv, info_dev, B, bsA, bsL);
+    potrf_legacy(a, linv, info_dev, B, bsA, bsL, dg);
     return;
   }
   for (int k = 0; k < nb; ++k) {
@@ -470,24 +473,28 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
     const int grid = B * npanel + (B * ntiles + 3) / 4;
     prof_begin(BOBE_PROF_POTF2);
     hipLaunchKernelGGL(k_chol_step<false>, dim3(grid), dim3(STEP_THREADS), STEP_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
-                       k, B, npanel, ntiles, info_dev, (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE),
+                       k, B, npanel, ntiles, info_dev, (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE), dg, bsD,
                        (unsigned long long*)nullptr);
     prof_end(BOBE_PROF_POTF2);
   }
+  hipLaunchKernelGGL(k_copy_diag, dim3(nb, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD, 0);
   LAUNCH_CHECK();
 }
 
 // panel and update as separate launches (see above)
-void bobe_gp::potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL) {
+void bobe_gp::potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
   const Tuning& tu = tuning();
+  const int64_t bsD = (int64_t)nb * TILE * TILE;
+  int first_aside = nb;                                       // first step whose L_kk was left in the scratch blocks
   for (int k = 0; k < nb; ++k) {
     const int rem = nb - k - 1;
     const int nvalid = (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE);
     const int npanel = rem > 0 ? 2 * rem : 1;
     if (!tu.chol_legacy && B * npanel <= std::max(num_cus, 1)) {
+      first_aside = std::min(first_aside, k);
       prof_begin(BOBE_PROF_POTF2);
       hipLaunchKernelGGL(k_chol_panel<false>, dim3(npanel, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
-                         k, npanel, info_dev, nvalid, (unsigned long long*)nullptr);
+                         k, npanel, info_dev, nvalid, dg, bsD, (unsigned long long*)nullptr);
       prof_end(BOBE_PROF_POTF2);
     } else {
       prof_begin(BOBE_PROF_POTF2);
@@ -507,6 +514,9 @@ void bobe_gp::potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_
       prof_end(BOBE_PROF_SYRK);
     }
   }
+  if (first_aside < nb)    // (B * npanel only shrinks with k: every step from first_aside on took the one-launch panel)
+    hipLaunchKernelGGL(k_copy_diag, dim3(nb - first_aside, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD,
+                       first_aside);
   LAUNCH_CHECK();
 }
 
@@ -613,6 +623,7 @@ void bobe_gp::ensure_slots(int n) {
     sl.res.ensure(128 * sizeof(double));
     sl.info.ensure(sizeof(int));
     sl.flags.ensure((size_t)nb * sizeof(int));
+    sl.diag.ensure((size_t)nb * TILE * TILE * sizeof(double));
   }
 }
 
@@ -749,6 +760,7 @@ void bobe_gp::ensure_batch(int B) {
   bw.gpart.ensure(nB * (size_t)gpart_stride() * sizeof(double));
   bw.res.ensure(nB * 128 * sizeof(double));
   bw.info.ensure(BOBE_MAX_MLL_SLOTS * sizeof(int));
+  bw.diag.ensure(nB * (size_t)nb * TILE * TILE * sizeof(double));
   bw.hyp.ensure(BOBE_MAX_MLL_SLOTS * sizeof(Hyper));
   bw.cap = std::max(bw.cap, B);
   bw.Np = Np;
@@ -766,7 +778,7 @@ void bobe_gp::mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad) {
   scale(X.d(), N, Np, hs[0], bw.XsT.d(), Np, hdev, B, xs);
   assemble_kxx(hs[0], bw.XsT.d(), bw.A.d(), hdev, B, xs, mat);
   HIPCHK(hipMemsetAsync(inf, 0x7f, (size_t)B * sizeof(int), stream));
-  potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat);
+  potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat, bw.diag.d());
   trtri(bw.A.d(), bw.Linv.d(), bw.Tmp.d(), B, mat, mat, mat);
   solve_alpha(bw.Linv.d(), bw.w.d(), bw.alpha.d(), bw.part.d(), B, mat, vec, prt);
   hipLaunchKernelGGL(k_mll_terms, dim3(B), dim3(256), 0, stream, (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np,
@@ -1025,7 +1037,7 @@ void bobe_gp_destroy(bobe_gp_t* g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   DBuf* bufs[] = {&g->X, &g->y, &g->XsT, &g->XsT2, &g->A, &g->Linv, &g->A2, &g->Linv2, &g->Tmp, &g->alpha, &g->w,
-                  &g->alpha2, &g->w2, &g->part, &g->gpart, &g->res, &g->info, &g->probs, &g->flags, &g->in_stage, &g->z_stage,
+                  &g->alpha2, &g->w2, &g->part, &g->gpart, &g->res, &g->info, &g->probs, &g->flags, &g->diag, &g->in_stage, &g->z_stage,
                   &g->CsT, &g->ZsT, &g->kXC, &g->kXZ, &g->VZ, &g->WZ, &g->basez, &g->sc, &g->qpart, &g->pv, &g->ps,
                   &g->o_mean, &g->o_var, &g->o_wipv, &g->o_wipstd, &g->o_misc, &g->kin_a, &g->kin_b, &g->kout};
   for (DBuf* b : bufs) b->release();
@@ -1048,7 +1060,7 @@ void bobe_gp_destroy(bobe_gp_t* g) {
   for (bobe_gp::Slot* sl : g->slots) {
     free_eg(sl->eg);
     DBuf* sb[] = {&sl->XsT2, &sl->A2, &sl->Linv2, &sl->Tmp, &sl->alpha2, &sl->w2, &sl->part, &sl->gpart, &sl->res,
-                  &sl->info, &sl->flags};
+                  &sl->info, &sl->flags, &sl->diag};
     for (DBuf* b : sb) b->release();
     if (sl->h_res) (void)hipHostFree(sl->h_res);
     if (sl->ev) (void)hipEventDestroy(sl->ev);
@@ -1056,7 +1068,7 @@ void bobe_gp_destroy(bobe_gp_t* g) {
   }
   {
     DBuf* bb[] = {&g->bw.A, &g->bw.Linv, &g->bw.Tmp, &g->bw.XsT, &g->bw.w, &g->bw.alpha, &g->bw.part, &g->bw.gpart,
-                  &g->bw.res, &g->bw.info, &g->bw.hyp};
+                  &g->bw.res, &g->bw.info, &g->bw.hyp, &g->bw.diag};
     for (DBuf* b : bb) b->release();
     if (g->bw.h_hyp) (void)hipHostFree(g->bw.h_hyp);
     if (g->bw.h_res) (void)hipHostFree(g->bw.h_res);
@@ -1216,6 +1228,9 @@ int bobe_gp_mll_batch(bobe_gp_t* g, int64_t B, const double* ls, const double* k
       g->mll_enqueue(h, grad != nullptr);
     } else {
       g->ensure_slots(nbat);
+      for (int i = 0; i < nbat; ++i)
+        if (g->slots[i]->busy)
+          throw Err(BOBE_ERR_STATE, "an evaluation submitted with bobe_gp_mll_submit is still in flight on a slot this batch needs");
       const std::vector<hipStream_t>& sts = g->slot_stream_set();
       // the batch streams start after everything already queued on the handle's stream (data uploads)
       HIPCHK(hipEventRecord(g->ev_batch, g->stream));
@@ -1280,6 +1295,8 @@ int bobe_gp_mll_submit(bobe_gp_t* g, int slot, const double* ls, double kvar, in
   for (int j = 0; j < g->d; ++j) h.ls[j] = ls[j];
   h.kvar = kvar;
   bobe_gp::Slot& sl = *g->slots[slot];
+  if (sl.busy)      // its pinned inputs / workspace / results are still in use by the evaluation not yet collected
+    throw Err(BOBE_ERR_STATE, "slot already has an evaluation in flight: call bobe_gp_mll_wait first");
   sl.stream = sts[slot];
   // ordered after whatever is queued on the handle's stream (data uploads); the event is private to the slot
   if (!sl.ev) HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
@@ -1302,11 +1319,19 @@ int bobe_gp_mll_submit(bobe_gp_t* g, int slot, const double* ls, double kvar, in
 int bobe_gp_mll_wait(bobe_gp_t* g, int slot, double* mll, double* grad) {
   API_BEGIN
   if (!g || !mll) throw Err(BOBE_ERR_ARG, "NULL argument");
-  if (slot < 0 || slot >= (int)g->slots.size() || !g->slots[slot]->busy)
-    throw Err(BOBE_ERR_STATE, "no evaluation was submitted to this slot");
+  bobe_gp::Slot* slp = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g->submit_mutex);    // (the slot table grows under this mutex)
+    if (slot < 0 || slot >= (int)g->slots.size() || !g->slots[slot]->busy)
+      throw Err(BOBE_ERR_STATE, "no evaluation was submitted to this slot");
+    slp = g->slots[slot];
+  }
   HIPCHK(hipSetDevice(g->device));
-  bobe_gp::Slot& sl = *g->slots[slot];
-  sl.busy = false;
+  bobe_gp::Slot& sl = *slp;
+  struct Release {                                        // the slot is free again once its stream has drained
+    bobe_gp::Slot& s;
+    ~Release() { s.busy = false; }
+  } release{sl};
   return g->slot_collect(sl, mll, sl.want_grad ? grad : nullptr);
   API_END
 }
@@ -1604,6 +1629,170 @@ int bobe_gp_set_chol(bobe_gp_t* g, const double* L, const double* alpha) {
   API_END
 }
 
+int bobe_gp_clone_state(bobe_gp_t* dst, bobe_gp_t* src) {
+  API_BEGIN
+  if (!dst || !src) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (dst == src) return BOBE_OK;
+  if (dst->d != src->d || dst->kern != src->kern || dst->device != src->device)
+    throw Err(BOBE_ERR_ARG, "clone needs handles of the same kernel, dimension and device");
+  if (!src->have_data) throw Err(BOBE_ERR_STATE, "source holds no data");
+  src->use();
+  src->sync();
+  dst->sync();
+  dst->N = src->N;
+  dst->hyp = src->hyp;
+  if (dst->Np != src->Np) {
+    dst->Np = src->Np;
+    dst->nb = src->nb;
+    dst->alloc_for_n();
+  }
+  const size_t mat = (size_t)src->Np * src->Np * sizeof(double), vec = (size_t)src->Np * sizeof(double);
+  dst->X.ensure((size_t)src->N * src->d * sizeof(double));
+  HIPCHK(hipMemcpyAsync(dst->X.p, src->X.p, (size_t)src->N * src->d * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(hipMemcpyAsync(dst->y.p, src->y.p, vec, hipMemcpyDeviceToDevice, dst->stream));
+  if (src->factored) {
+    HIPCHK(hipMemcpyAsync(dst->XsT.p, src->XsT.p, (size_t)src->d * vec, hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(hipMemcpyAsync(dst->A.p, src->A.p, mat, hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(hipMemcpyAsync(dst->Linv.p, src->Linv.p, mat, hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(hipMemcpyAsync(dst->alpha.p, src->alpha.p, vec, hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(hipMemcpyAsync(dst->w.p, src->w.p, vec, hipMemcpyDeviceToDevice, dst->stream));
+  }
+  dst->sync();
+  dst->have_data = true;
+  dst->factored = src->factored;
+  dst->not_pd = src->not_pd;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_append(bobe_gp_t* g, const double* X_new, int64_t b, const double* y_all) {
+  API_BEGIN
+  if (!g || !X_new || !y_all) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (b < 1 || b > 64) throw Err(BOBE_ERR_ARG, "b must be in [1, 64] (larger batches: bobe_gp_set_data + bobe_gp_factor)");
+  if (!g->factored || g->not_pd) throw Err(BOBE_ERR_STATE, "append needs a positive-definite factorised state");
+  g->use();
+  g->sync();
+  const int d = g->d;
+  const int64_t N0 = g->N, N1 = N0 + b, Np0 = g->Np, Np1 = round_up(N1, TILE);
+  // ---- training data: X gains b rows, every y changes (the caller re-standardised them, gp.py:520-536)
+  {
+    DBuf nx;
+    nx.ensure((size_t)N1 * d * sizeof(double));
+    HIPCHK(hipMemcpyAsync(nx.p, g->X.p, (size_t)N0 * d * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(static_cast<double*>(nx.p) + N0 * d, X_new, (size_t)b * d * sizeof(double),
+                          is_device_ptr(X_new) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g->stream));
+    g->sync();
+    std::swap(g->X, nx);
+    nx.release();
+  }
+  // ---- a larger padded size: move L and Linv into the new [[., 0], [0, I]] frame
+  if (Np1 != Np0) {
+    DBuf oa, ol;
+    std::swap(oa, g->A);
+    std::swap(ol, g->Linv);
+    g->Np = Np1;
+    g->nb = (int)(Np1 / TILE);
+    g->alloc_for_n();                      // A, Linv (fresh), scratch, probs for the new block count
+    hipLaunchKernelGGL(k_load_padded_lower, dim3((unsigned)((Np1 + 255) / 256), (unsigned)Np1), dim3(256), 0, g->stream,
+                       (const double*)oa.p, (int64_t)0, g->A.d(), Np1, Np1);         // identity everywhere ...
+    hipLaunchKernelGGL(k_load_padded_lower, dim3((unsigned)((Np1 + 255) / 256), (unsigned)Np1), dim3(256), 0, g->stream,
+                       (const double*)ol.p, (int64_t)0, g->Linv.d(), Np1, Np1);
+    HIPCHK(hipMemcpy2DAsync(g->A.p, (size_t)Np1 * 8, oa.p, (size_t)Np0 * 8, (size_t)Np0 * 8, (size_t)Np0,
+                            hipMemcpyDeviceToDevice, g->stream));                     // ... then the old frame on top
+    HIPCHK(hipMemcpy2DAsync(g->Linv.p, (size_t)Np1 * 8, ol.p, (size_t)Np0 * 8, (size_t)Np0 * 8, (size_t)Np0,
+                            hipMemcpyDeviceToDevice, g->stream));
+    g->sync();
+    oa.release();
+    ol.release();
+  }
+  const int64_t Np = g->Np;
+  const int nb = g->nb;
+  g->N = N0;                               // (old point count while the cross-covariances are assembled)
+  HIPCHK(hipMemsetAsync(g->y.p, 0, (size_t)Np * sizeof(double), g->stream));
+  HIPCHK(hipMemcpyAsync(g->y.p, y_all, (size_t)N1 * sizeof(double),
+                        is_device_ptr(y_all) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g->stream));
+  // ---- V = Linv K(X_old, X_new), W = Linv^T V, S = K(X_new, X_new) + noise I - V^T V
+  const int64_t bp = TILE;
+  g->kXC.ensure((size_t)Np * std::max<int64_t>(bp, g->chunk) * sizeof(double));
+  g->VZ.ensure((size_t)Np * bp * sizeof(double));
+  g->WZ.ensure((size_t)Np * bp * sizeof(double));
+  g->kin_a.ensure((size_t)d * bp * sizeof(double));
+  g->qpart.ensure((size_t)nb * std::max<int64_t>(bp, g->chunk) * sizeof(double));
+  g->o_misc.ensure((size_t)(3 * 64 * 64 + 8) * sizeof(double));
+  g->scale(g->X.d(), N0, Np, g->hyp, g->XsT.d(), Np);                                    // old points only (rest 0)
+  g->scale(g->X.d() + N0 * d, b, bp, g->hyp, g->kin_a.d(), bp);
+  g->kernel_matrix_cross(g->XsT.d(), Np, N0, Np, g->kin_a.d(), bp, b, bp, g->hyp, g->kXC.d(), bp);
+  hipLaunchKernelGGL(k_trimul, dim3(1, (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, g->stream, (const double*)g->Linv.d(), Np,
+                     nb, (const double*)g->kXC.d(), bp, g->VZ.d(), bp, (double*)nullptr, (int64_t)0, (const double*)nullptr,
+                     (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+  hipLaunchKernelGGL(k_trimul_t, dim3(1, (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, g->stream, (const double*)g->Linv.d(), Np,
+                     nb, (const double*)g->VZ.d(), bp, g->WZ.d(), bp);
+  double* G = g->o_misc.d();                                                             // b*b Gram matrix V^T V
+  hipLaunchKernelGGL(k_gram_small, dim3((unsigned)b, (unsigned)b), dim3(256), 0, g->stream, (const double*)g->VZ.d(), bp, N0,
+                     (int)b, G);
+  LAUNCH_CHECK();
+  std::vector<double> hG((size_t)b * b), hK((size_t)b * b), hx((size_t)b * d);
+  HIPCHK(hipMemcpyAsync(hG.data(), G, hG.size() * 8, hipMemcpyDeviceToHost, g->stream));
+  HIPCHK(hipMemcpyAsync(hx.data(), g->X.d() + N0 * d, hx.size() * 8, hipMemcpyDeviceToHost, g->stream));
+  g->sync();
+  // K(X_new, X_new) + noise I on the host (b <= 64 points; the kernel of gp.py:124-168 with direct differences)
+  for (int64_t i = 0; i < b; ++i)
+    for (int64_t j = 0; j < b; ++j) {
+      double r2 = 0.0;
+      for (int q = 0; q < d; ++q) {
+        const double df = hx[i * d + q] / g->hyp.ls[q] - hx[j * d + q] / g->hyp.ls[q];
+        r2 += df * df;
+      }
+      double kv;
+      if (g->kern == 0) {
+        kv = g->hyp.kvar * std::exp(-0.5 * r2);
+      } else {
+        const double dd = std::sqrt(r2 < 1e-30 ? 1e-30 : r2);
+        kv = g->hyp.kvar * (1.0 + dd * (SQRT5 + (dd * 5.0) / 3.0)) * std::exp(-SQRT5 * dd);
+      }
+      hK[i * b + j] = kv + (i == j ? g->hyp.noise : 0.0) - hG[i * b + j];
+    }
+  // L22 = chol(S), L22inv by forward substitution; a non-positive pivot = the appended matrix is not positive definite
+  std::vector<double> s22((size_t)2 * b * b, 0.0);
+  double* L22 = s22.data();
+  double* Li = s22.data() + b * b;
+  bool pd = true;
+  for (int64_t j = 0; j < b && pd; ++j) {
+    double dj = hK[j * b + j];
+    for (int64_t k = 0; k < j; ++k) dj -= L22[j * b + k] * L22[j * b + k];
+    if (!(dj > 0.0)) { pd = false; break; }
+    L22[j * b + j] = std::sqrt(dj);
+    for (int64_t i = j + 1; i < b; ++i) {
+      double v = hK[i * b + j];
+      for (int64_t k = 0; k < j; ++k) v -= L22[i * b + k] * L22[j * b + k];
+      L22[i * b + j] = v / L22[j * b + j];
+    }
+  }
+  g->N = N1;
+  if (!pd) {                               // same outcome as the full refactorisation: NaN state, BOBE_NOT_PD
+    g->factored = false;
+    return bobe_gp_factor(g);
+  }
+  for (int64_t c = 0; c < b; ++c)
+    for (int64_t i = c; i < b; ++i) {
+      double v = (i == c) ? 1.0 : 0.0;
+      for (int64_t k = c; k < i; ++k) v -= L22[i * b + k] * Li[k * b + c];
+      Li[i * b + c] = v / L22[i * b + i];
+    }
+  double* d22 = g->o_misc.d() + 64 * 64;
+  HIPCHK(hipMemcpyAsync(d22, s22.data(), s22.size() * 8, hipMemcpyHostToDevice, g->stream));
+  hipLaunchKernelGGL(k_append_rows, dim3((unsigned)((N1 + 255) / 256)), dim3(256), 0, g->stream, g->A.d(), g->Linv.d(), Np,
+                     N0, (int)b, (const double*)g->VZ.d(), (const double*)g->WZ.d(), bp, (const double*)d22);
+  LAUNCH_CHECK();
+  g->scale(g->X.d(), N1, Np, g->hyp, g->XsT.d(), Np);                                    // all points again
+  g->solve_alpha(g->Linv.d(), g->w.d(), g->alpha.d(), g->part.d());                     // alpha = Linv^T Linv y
+  g->sync();                               // (s22 / hG are host temporaries of this call)
+  g->factored = true;
+  g->not_pd = false;
+  return BOBE_OK;
+  API_END
+}
+
 int bobe_debug_gemm(int device, int la, int lb, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                     const double* B, int64_t ldb, double* C, int64_t ldc) {
   API_BEGIN
@@ -1834,7 +2023,7 @@ int bobe_debug_time_potrf_lockstep(bobe_gp_t* g, int B, int reps, double* ms) {
     g->assemble_kxx(g->hyp, g->bw.XsT.d(), g->bw.A.d(), hdev, B, xs, mat);
     HIPCHK(hipMemsetAsync(g->bw.info.p, 0x7f, (size_t)B * sizeof(int), g->stream));
     HIPCHK(hipEventRecord(e0, g->stream));
-    g->potrf(g->bw.A.d(), g->bw.Linv.d(), static_cast<int*>(g->bw.info.p), B, mat, mat);
+    g->potrf(g->bw.A.d(), g->bw.Linv.d(), static_cast<int*>(g->bw.info.p), B, mat, mat, g->bw.diag.d());
     HIPCHK(hipEventRecord(e1, g->stream));
     HIPCHK(hipEventSynchronize(e1));
     float t = 0.f;

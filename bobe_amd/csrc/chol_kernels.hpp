@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
 //       the first 256 threads stay.
 //       Every panel workgroup stages block (k,k) in LDS and factors it itself (the factor is needed by all of them
 //       and takes as long on one CU as on sixty: recomputing it replaces a kernel boundary and a global round
-//       trip); pw = 0 also writes L_kk and the 16x16 inverses back.  Its four waves then solve rows
+//       trip); pw = 0 also writes the 16x16 inverses back and L_kk to a scratch block (see chol_panel_body).  Its
+//       four waves then solve rows
 //       (k+1)*128 + 64*pw + 16*wave .. +15 of block column k exactly like k_trsm_panel (same MFMA sequence, same
 //       bits), reading L_kk and the inverses from the workgroup's LDS; the rows are fetched into registers in
 //       accumulator layout BEFORE the factor loop, so their latency is hidden.
@@ -458,10 +459,14 @@ constexpr int STEP_TILE_SMEM_DOUBLES = gemm_smem_doubles_exact<KC, KC, 64, 64, 1
 constexpr int STEP_SMEM_BYTES = POTF2_SMEM_BYTES;                                           // 150,528 B
 static_assert(4 * STEP_TILE_SMEM_DOUBLES * 8 <= STEP_SMEM_BYTES, "four update tiles must fit beside each other");
 
+// Lkk_out: where pw = 0 leaves L_kk (a dense 128 x 128 scratch block, NOT the diagonal block itself: the other panel
+// workgroups of the launch read A_kk whenever they get a CU - on a busy GPU possibly after pw = 0 has finished - so
+// the block must stay intact until the launch is over; k_copy_diag moves the scratch blocks into place afterwards).
 template <bool STAMP>
 __device__ __forceinline__ void chol_panel_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                 int64_t ldl, int k, int pw, bool has_rows, int* __restrict__ info,
-                                                int nvalid, unsigned long long* __restrict__ stamps) {
+                                                int nvalid, double* __restrict__ Lkk_out,
+                                                unsigned long long* __restrict__ stamps) {
   extern __shared__ double S[];
   double* Dall = S + TILE * PLD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -490,7 +495,7 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ A, int64_t 
   BOBE_STAMP(1);
   potf2_factor_lds<STAMP, 4>(S, Dall, nsteps, (int)col0, info, stamps);
   BOBE_STAMP(26);
-  if (pw == 0) potf2_stage_out(S, Dall, Ab, lda, Ib, ldl);
+  if (pw == 0) potf2_stage_out(S, Dall, Lkk_out, TILE, Ib, ldl);
   BOBE_STAMP(27);
   if (!has_rows) return;
   // X^T_p = invD_p * (A^T_p - sum_{q<p} L_kk[p][q] X^T_q), the MFMA sequence of k_trsm_panel
@@ -533,10 +538,25 @@ template <bool STAMP = false>
 __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
                                                     double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
                                                     int npanel, int* __restrict__ info, int nvalid,
+                                                    double* __restrict__ diag, int64_t bsD,
                                                     unsigned long long* __restrict__ stamps = nullptr) {
   const int slot = blockIdx.y;
   chol_panel_body<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel > 1, info + slot, nvalid,
-                         stamps);
+                         diag + slot * bsD + (int64_t)k * TILE * TILE, stamps);
+}
+
+// A[blk][blk] <- scratch block blk for blk = first + blockIdx.x (slot = blockIdx.y): the L_kk the panel launches left aside
+__global__ __launch_bounds__(256) void k_copy_diag(double* __restrict__ A, int64_t lda, int64_t bsA,
+                                                   const double* __restrict__ diag, int64_t bsD, int first) {
+  const int blk = first + blockIdx.x;
+  const double* src = diag + blockIdx.y * bsD + (int64_t)blk * TILE * TILE;
+  double* dst = A + blockIdx.y * bsA + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) {
+    const int r = 4 * i + wave;
+    *reinterpret_cast<v2d*>(dst + (int64_t)r * lda + 2 * lane) = *reinterpret_cast<const v2d*>(src + r * TILE + 2 * lane);
+  }
 }
 
 template <bool STAMP = false>
@@ -544,13 +564,15 @@ __global__ __launch_bounds__(STEP_THREADS) void k_chol_step(double* __restrict__
                                                             double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
                                                             int nbatch, int npanel, int ntiles,
                                                             int* __restrict__ info, int nvalid,
+                                                            double* __restrict__ diag, int64_t bsD,
                                                             unsigned long long* __restrict__ stamps = nullptr) {
   extern __shared__ double smem[];
   const int wg = blockIdx.x;
   if (wg < nbatch * npanel) {
     if (threadIdx.x >= 256) return;     // (a barrier waits only for the waves still alive)
     const int slot = wg / npanel, pw = wg - slot * npanel;
-    chol_panel_body<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, pw, npanel > 1, info + slot, nvalid, stamps);
+    chol_panel_body<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, pw, npanel > 1, info + slot, nvalid,
+                           diag + slot * bsD + (int64_t)k * TILE * TILE, stamps);
     return;
   }
   const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;

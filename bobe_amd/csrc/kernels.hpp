@@ -446,6 +446,48 @@ __global__ void k_load_padded_lower(const double* __restrict__ src, int64_t n, d
   dst[i * ld + j] = v;
 }
 
+// ---- rank-b append (bobe_gp_append; the reference's fast_update_cholesky, gp.py:181-197, b rows at a time) ------
+// G[i*b + j] = sum_{k < n} V[k*ldv + i] * V[k*ldv + j]   (b <= 64; one workgroup per (i, j), fixed summation order)
+__global__ __launch_bounds__(256) void k_gram_small(const double* __restrict__ V, int64_t ldv, int64_t n, int b,
+                                                    double* __restrict__ G) {
+  __shared__ double red[4];
+  const int i = blockIdx.x, j = blockIdx.y;
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < n; k += 256) s += V[k * ldv + i] * V[k * ldv + j];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) G[i * b + j] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// rows n0 .. n0+b-1 of the padded factor and of its inverse:
+//   L[n0+i][c]    = V[c][i]                         (c < n0)      L[n0+i][n0+j]    = L22[i][j]  (0 above the diagonal)
+//   Linv[n0+i][c] = -sum_j L22inv[i][j] W[c][j]     (c < n0)      Linv[n0+i][n0+j] = L22inv[i][j]
+// with V = Linv_old K(X, X_new), W = Linv_old^T V; s22 holds L22 (b*b) followed by L22inv (b*b), row-major.
+__global__ void k_append_rows(double* __restrict__ L, double* __restrict__ Linv, int64_t ld, int64_t n0, int b,
+                              const double* __restrict__ V, const double* __restrict__ W, int64_t ldv,
+                              const double* __restrict__ s22) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n0 + b) return;
+  const double* L22 = s22;
+  const double* Li = s22 + b * b;
+  for (int i = 0; i < b; ++i) {
+    double lv, iv;
+    if (c < n0) {
+      lv = V[c * ldv + i];
+      double a = 0.0;
+      for (int j = 0; j <= i; ++j) a += Li[i * b + j] * W[c * ldv + j];
+      iv = -a;
+    } else {
+      const int j = (int)(c - n0);
+      lv = (j <= i) ? L22[i * b + j] : 0.0;
+      iv = (j <= i) ? Li[i * b + j] : 0.0;
+    }
+    L[(n0 + i) * ld + c] = lv;
+    Linv[(n0 + i) * ld + c] = iv;
+  }
+}
+
 // EI / LogEI pointwise scorers (BOBE/acquisition.py:21-75, 226-253, 318-330); mu, var standardised
 __device__ __forceinline__ double norm_pdf(double u) { return exp(-0.5 * u * u) * 0.39894228040143267794; }
 __device__ __forceinline__ double norm_cdf(double u) { return 0.5 * erfc(-u * 0.70710678118654752440); }

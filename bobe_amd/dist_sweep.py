@@ -39,22 +39,32 @@ def shard_bounds(n_candidates: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def reduce_argmin(scores, global_idx) -> Tuple[float, int]:
+    """The merge rule on the gathered per-shard (min score, global index) pairs: smallest score wins, ties go to the
+    lowest global index (``jnp.argmin`` returns the first occurrence, acquisition.py:397); a NaN score counts as
+    minimal (np.argmin / jnp.argmin propagate NaN)."""
+    scores = np.asarray(scores, dtype=np.float64).reshape(-1)
+    idx = np.asarray(global_idx, dtype=np.int64).reshape(-1)
+    key = np.where(np.isnan(scores), -np.inf, scores)
+    order = np.lexsort((idx, key))
+    return float(scores[order[0]]), int(idx[order[0]])
+
+
 def merge_argmin(local_min: float, local_global_idx: int, group=None, device=None) -> Tuple[float, int]:
-    """All-gather (score, global index) and return the global (min, argmin); NaN scores count as minimal
-    (np.argmin / jnp.argmin propagate NaN)."""
+    """ONE all-gather of (score, global index) per acquisition, then ``reduce_argmin`` on every rank.  The index
+    travels in the same float64 payload as the score (16 B per rank, one collective): exact up to 2^53 candidates."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(local_min), int(local_global_idx)
+    if not 0 <= int(local_global_idx) < 2 ** 53:
+        raise ValueError("candidate index does not fit the float64 payload of the all-gather")
     world = dist.get_world_size(group)
     mine = torch.tensor([float(local_min), float(local_global_idx)], dtype=torch.float64, device=device)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine, group=group)
     allv = torch.stack(parts).cpu().numpy()
-    scores, idx = allv[:, 0], allv[:, 1].astype(np.int64)
-    key = np.where(np.isnan(scores), -np.inf, scores)
-    order = np.lexsort((idx, key))
-    return float(scores[order[0]]), int(idx[order[0]])
+    return reduce_argmin(allv[:, 0], allv[:, 1].astype(np.int64))
 
 
 def merge_best_fit(local_mll: float, local_params: np.ndarray, group=None, device=None):

@@ -76,8 +76,10 @@ class GP:
     def __init__(self, train_x, train_y, noise=1e-8, kernel="rbf", optimizer="scipy", optimizer_options={},
                  kernel_variance_bounds=[1e-4, 1e8], lengthscale_bounds=[0.01, 5], lengthscales=None,
                  kernel_variance=None, kernel_variance_prior=None, lengthscale_prior=None, tausq=None,
-                 tausq_bounds=[1e-4, 1e4], param_names: Optional[List[str]] = None, device: int = 0):
-        """Same keywords as BOBE/gp.py:201-203 plus ``device`` (HIP device index)."""
+                 tausq_bounds=[1e-4, 1e4], param_names: Optional[List[str]] = None, device: int = 0,
+                 _factor: bool = True):
+        """Same keywords as BOBE/gp.py:201-203 plus ``device`` (HIP device index).  ``_factor=False`` (internal) leaves
+        the factorisation to the caller, which is about to install a known one (``from_state_dict``, ``copy``)."""
         self._lib = _lib.load()
         self._h = C.c_void_p(0)
         self.device = int(device)
@@ -108,8 +110,12 @@ class GP:
         self._setup_lengthscale_prior(lengthscale_prior)
         self._setup_optimization_parameters()
 
+        self.append_updates = True             # update(): rank-b append (O(b N^2)) instead of a full refactorisation
+        self._chol_cache = self._alpha_cache = None
+        self.not_pd = False
         self._push_data()
-        self.recompute_cholesky()                                               # gp.py:257-260
+        if _factor:
+            self.recompute_cholesky()                                           # gp.py:257-260
 
     def __del__(self):
         try:
@@ -405,8 +411,23 @@ class GP:
                 log.warning("Training targets have zero variance. Setting std to 1.0 to avoid division by zero.")
                 self.y_std = 1.0
             self.train_y = (y_orig - self.y_mean) / self.y_std
-            self._push_data()
-            self.recompute_cholesky()
+            self._refresh_after_update(len(pts))
+
+    def _refresh_after_update(self, n_new: int):
+        """K, L, alpha for the grown training set (gp.py:541).  The hyper-parameters have not changed, so the factor
+        of the old points is still valid: the new rows are appended on the GPU (``bobe_gp_append``, the b-row form of
+        the reference's own ``fast_update_cholesky``, gp.py:181-197) and alpha is re-solved for the re-standardised
+        targets — O(b N^2) instead of O(N^3).  Falls back to the full refactorisation when there is no usable
+        factor (NaN state) or the batch is large."""
+        if self.append_updates and not self.not_pd and 1 <= n_new <= 64 and self.train_x.shape[0] > n_new:
+            xn = _lib.as_f64(self.train_x[-n_new:])
+            ya = _lib.as_f64(self.train_y).reshape(-1)
+            st = _lib.check(self._lib.bobe_gp_append(self._h, _lib.ptr(xn), n_new, _lib.ptr(ya)), "bobe_gp_append")
+            self._chol_cache = self._alpha_cache = None
+            self.not_pd = (st == _lib.BOBE_NOT_PD)
+            return
+        self._push_data()
+        self.recompute_cholesky()
 
     # ------------------------------------------------------------------ fantasy variance / sweep
     def fantasy_var(self, new_x, mc_points, k_train_mc=None):
@@ -488,8 +509,9 @@ class GP:
         return rng.uniform(0, 1, size=self.train_x.shape[1])
 
     # ------------------------------------------------------------------ state (gp.py:587-750)
-    def state_dict(self):
-        """Same keys as BOBE/gp.py:597-634 (npz-interchangeable)."""
+    def state_dict(self, with_factor: bool = True):
+        """Same keys as BOBE/gp.py:597-634 (npz-interchangeable).  ``with_factor=False`` (internal, ``copy``) leaves
+        the N x N factor on the GPU."""
         return {
             "train_x": np.array(self.train_x),
             "train_y": np.array(self.train_y * self.y_std + self.y_mean),
@@ -508,15 +530,16 @@ class GP:
             "lengthscale_bounds": self.lengthscale_bounds,
             "kernel_variance_bounds": self.kernel_variance_bounds,
             "tausq_bounds": self.tausq_bounds,
-            "cholesky": np.array(self.cholesky),
-            "alphas": np.array(self.alphas),
+            "cholesky": np.array(self.cholesky) if with_factor else None,
+            "alphas": np.array(self.alphas) if with_factor else None,
             "ndim": self.ndim,
             "gp_class": "GP",
         }
 
     @classmethod
-    def from_state_dict(cls, state, device: int = 0):
-        """BOBE/gp.py:638-677 — L and alpha are restored on the GPU without refactorising."""
+    def from_state_dict(cls, state, device: int = 0, _clone_of=None):
+        """BOBE/gp.py:638-677 — L and alpha are restored on the GPU without refactorising (``_clone_of``: take them
+        from that GP's device state instead of ``state``)."""
         def plain(v):
             return v.item() if isinstance(v, np.ndarray) and v.shape == () else v
         gp = cls(train_x=state["train_x"], train_y=state["train_y"], noise=plain(state["noise"]),
@@ -528,13 +551,23 @@ class GP:
                  kernel_variance_prior=plain(state.get("kernel_variance_prior_spec")),
                  lengthscale_prior=plain(state.get("lengthscale_prior_spec")),
                  tausq=plain(state.get("tausq", 1.0)),
-                 tausq_bounds=list(np.asarray(state.get("tausq_bounds", [1e-4, 1e4])).tolist()), device=device)
+                 tausq_bounds=list(np.asarray(state.get("tausq_bounds", [1e-4, 1e4])).tolist()), device=device,
+                 _factor=False)
         L, a = state.get("cholesky"), state.get("alphas")
-        if L is not None and a is not None and np.all(np.isfinite(np.asarray(L, dtype=np.float64))):
+        if _clone_of is not None:
+            _lib.check(gp._lib.bobe_gp_clone_state(gp._h, _clone_of._h), "bobe_gp_clone_state")
+            gp.not_pd = bool(_clone_of.not_pd)
+            # the host copy of the standardisation too, bit for bit (a state_dict round trip re-derives it)
+            gp.train_y, gp.y_mean, gp.y_std = np.array(_clone_of.train_y), _clone_of.y_mean, _clone_of.y_std
+            gp._chol_cache, gp._alpha_cache = None, None
+        elif L is not None and a is not None and np.all(np.isfinite(np.asarray(L, dtype=np.float64))):
             L = _lib.as_f64(L)
             a = _lib.as_f64(a).reshape(-1)
+            gp._push_hyper()
             _lib.check(gp._lib.bobe_gp_set_chol(gp._h, _lib.ptr(L), _lib.ptr(a)), "bobe_gp_set_chol")
             gp._chol_cache, gp._alpha_cache = None, None
+        else:
+            gp.recompute_cholesky()
         return gp
 
     @classmethod
@@ -557,8 +590,12 @@ class GP:
         np.savez(filename, **self.state_dict())
 
     def copy(self):
-        """BOBE/gp.py:740-750."""
-        return self.__class__.from_state_dict(self.state_dict(), device=self.device)
+        """BOBE/gp.py:740-750 — an independent GP with the same data, hyper-parameters and factor.  The reference goes
+        through ``state_dict`` / ``from_state_dict``; here the device state is duplicated on the GPU
+        (``bobe_gp_clone_state``): no N x N host round trip, no factorisation."""
+        state = self.state_dict(with_factor=False)
+        new = self.__class__.from_state_dict(state, device=self.device, _clone_of=self)
+        return new
 
     @property
     def npoints(self):

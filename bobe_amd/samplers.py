@@ -80,6 +80,22 @@ def _draw_in_ellipsoid(mu, A, n, rng):
     return x[np.all((x >= 0.0) & (x <= 1.0), axis=1)]
 
 
+def logz_from_samples(gp, samples_x, logl, logvol, mean: float, logz_err: float) -> Dict:
+    """The logZ dictionary of a finished run (samplers.py:172-183): the GP's predictive variance at every sample —
+    ONE batched ``bobe_gp_predict`` call instead of the reference's ``lax.map`` over points — turns into
+    logl +- std for the upper / lower evidence integrals and into the variance estimate of logZ."""
+    logl = np.asarray(logl, dtype=np.float64)
+    var = np.asarray(gp.predict_var_batched(samples_x), dtype=np.float64)
+    std = np.sqrt(var)
+    upper = compute_integrals(logl=logl + std, logvol=logvol)
+    lower = compute_integrals(logl=logl - std, logvol=logvol)
+    var = np.clip(var, 1e-12, 1e12)
+    log_var_delta = compute_integrals(logl=2 * logl + np.log(var), logvol=logvol, squared=True)[-1]
+    var_logz = math.exp(float(np.clip(log_var_delta - 2 * mean, -100, 100)))
+    return {"mean": float(mean), "dlogz_sampler": float(logz_err), "upper": float(upper[-1]), "lower": float(lower[-1]),
+            "var": var_logz, "std": 2 * math.sqrt(var_logz)}
+
+
 def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", dlogz: float = 0.01,
                     maxcall: int = int(5e6), equal_weights: bool = False, rng=None, batch: int = 8192,
                     enlarge: float = 1.25, nlive: Optional[int] = None) -> Tuple[Dict, Dict, bool]:
@@ -176,16 +192,8 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
     logz_err = math.sqrt(max(h_info, 0.0) / nlive)
     success = bool(~np.all(logl == logl[0]))                                  # samplers.py:167
 
-    # GP-uncertainty bounds (samplers.py:172-183): one batched variance call for every sample
-    var = np.asarray(gp.predict_var_batched(samples_x), dtype=np.float64)
-    std = np.sqrt(var)
-    upper = compute_integrals(logl=logl + std, logvol=logvol)
-    lower = compute_integrals(logl=logl - std, logvol=logvol)
-    var = np.clip(var, 1e-12, 1e12)
-    log_var_delta = compute_integrals(logl=2 * logl + np.log(var), logvol=logvol, squared=True)[-1]
-    var_logz = math.exp(float(np.clip(log_var_delta - 2 * mean, -100, 100)))
-    logz_dict = {"mean": mean, "dlogz_sampler": logz_err, "upper": float(upper[-1]), "lower": float(lower[-1]),
-                 "var": var_logz, "std": 2 * math.sqrt(var_logz), "ncall": int(ncall), "niter": int(niter)}
+    logz_dict = logz_from_samples(gp, samples_x, logl, logvol, mean, logz_err)
+    logz_dict.update(ncall=int(ncall), niter=int(niter))
     best_pt = samples_x[int(np.argmax(logl))]
     weights = renormalise_log_weights(logwt)
     if equal_weights:

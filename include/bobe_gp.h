@@ -145,6 +145,19 @@ int bobe_gp_get_chol(bobe_gp_t* gp, double* L, double* alpha);
 /* GP.from_state_dict restore without refactorisation (gp.py:671-675). */
 int bobe_gp_set_chol(bobe_gp_t* gp, const double* L, const double* alpha);
 
+/* GP.copy (gp.py:740-750) without leaving the device: dst (created with the same kernel, d and device) receives
+ * src's training data, hyper-parameters and factorised state by device-to-device copies - no host round trip of the
+ * N x N factor and no refactorisation (the reference copies through state_dict / from_state_dict). */
+int bobe_gp_clone_state(bobe_gp_t* dst, bobe_gp_t* src);
+
+/* GP.update at unchanged hyper-parameters as a rank-b append, O(b N^2) instead of the O(N^3) recompute_cholesky of
+ * gp.py:541-550 (the reference has the rank-1 form as fast_update_cholesky, gp.py:181-197, but uses it only inside
+ * fantasy_var).  X_new: b x d new points (1 <= b <= 64); y_all: the N+b targets after re-standardisation
+ * (gp.py:520-536 changes all of them; L does not depend on y, alpha is re-solved).  Requires a positive-definite
+ * factorised state; if the appended matrix is not positive definite the call ends like bobe_gp_factor (NaN state,
+ * BOBE_NOT_PD). */
+int bobe_gp_append(bobe_gp_t* gp, const double* X_new, int64_t b, const double* y_all);
+
 /* number of training points / padded leading dimension currently held */
 int64_t bobe_gp_npoints(bobe_gp_t* gp);
 

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libbobe_oracle_c.so")
+# BOBE_ORACLE_C_LIB selects another build of the same source (the sanitizer build of `make -C oracle asan`)
+_PATH = os.environ.get("BOBE_ORACLE_C_LIB") or os.path.join(_HERE, "libbobe_oracle_c.so")
 _lib = None
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 

@@ -9,7 +9,8 @@ import pytest
 
 from oracle import bobe_oracle as O
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("loop_"))     # loop_*: BO-step fixtures (tests/test_gpu_loop_parity.py)
 
 
 def load(path):

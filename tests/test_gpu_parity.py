@@ -300,7 +300,8 @@ def test_acquisition_classes_next_point_and_batch():
     assert np.shape(x) == (2,) and val >= 0                    # tests/test_acquisition.py:156-158
 
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("loop_"))     # loop_*: BO-step fixtures (tests/test_gpu_loop_parity.py)
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])

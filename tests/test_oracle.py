@@ -233,6 +233,29 @@ def test_c_restatement_agrees_with_numpy_restatement(kernel):
         assert np.allclose(f_c, f_np, rtol=1e-6, atol=1e-12 * og.y_std ** 2)
 
 
+def test_c_restatement_under_address_sanitizer():
+    """the host-side C of the checker under -fsanitize=address,undefined (`make -C oracle asan`).
+    The sanitizer runtime has to be the first library of the process, so the C oracle's tests run in a child
+    interpreter with libasan preloaded; any report aborts the child."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    odir = os.path.join(os.path.dirname(here), "oracle")
+    subprocess.run(["make", "-C", odir, "asan"], check=True, capture_output=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    if not os.path.isabs(asan):
+        pytest.skip("no libasan in this toolchain")
+    env = dict(os.environ, LD_PRELOAD=asan, BOBE_ORACLE_C_LIB=os.path.join(odir, "libbobe_oracle_c_asan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
+                        "c_restatement_agrees or c_restatement_not_positive"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
+    assert "passed" in p.stdout
+
+
 def test_c_restatement_not_positive_definite_is_nan():
     from oracle import c_binding as OC
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.7, 0.3]])
