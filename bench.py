@@ -62,6 +62,9 @@ def parse(argv=None):
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk of the sweep (0 = library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a single GPU")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "rccl"],
+                    help="who issues the all-gathers: torch.distributed (default) or the library's own RCCL communicator "
+                         "(bobe_mgpu_*, include/bobe_gp.h)")
     ap.add_argument("--shard-candidates", type=int, default=SHARD_TOTAL_CANDIDATES,
                     help="total candidates of --config shard (tests use a smaller set)")
     return ap.parse_args(argv)
@@ -88,8 +91,19 @@ def cpu_baseline(X, y, cand, Z, thetas, noise, gpu_check, sample_c=4096, samples
     LAPACK/BLAS, all threads): one warm-up, then the MEDIAN of ``samples`` value+gradient evaluations, one refactor,
     one sweep of a ``sample_c``-candidate sample; extrapolated linearly to the full cycle."""
     from oracle import cpu_port as P
+    import torch
     d = X.shape[1]
     ls0, kv0 = np.exp(thetas[0, :d]), float(np.exp(thetas[0, d]))
+    # thread count: the fastest of a few candidates on one evaluation each (all logical CPUs is NOT the fastest on a
+    # box whose CPU share is smaller than its core count: 6.1 s with 128 threads against 1.4 s with 16 at N = 4096)
+    ncpu = os.cpu_count() or 1
+    tried = {}
+    for nt in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu), torch.get_num_threads()}):
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        P.cycle_value_and_grad(X, y, ls0, kv0, noise)
+        tried[nt] = time.perf_counter() - t0
+    torch.set_num_threads(min(tried, key=tried.get))
     mll0, g0 = P.cycle_value_and_grad(X, y, ls0, kv0, noise)              # warm-up (also the parity reference)
     t_vg = []
     for _ in range(samples):
@@ -119,7 +133,8 @@ def cpu_baseline(X, y, cand, Z, thetas, noise, gpu_check, sample_c=4096, samples
             "sample": f"median of {samples} value+grad after 1 warm-up ({vg:.3f}s; min {min(t_vg):.3f}, max {max(t_vg):.3f}) "
                       f"x {len(thetas)}, 1 refactor ({t_fac:.3f}s), {sc} of {cand.shape[0]} candidates ({t_sw:.3f}s) "
                       f"extrapolated linearly; same rank-1 sweep algorithm as the GPU",
-            "host": host, "seconds_per_cycle": cyc, "parity_vs_gpu": par}
+            "host": host, "seconds_per_cycle": cyc, "thread_calibration_s": {str(k): round(v, 3) for k, v in tried.items()},
+            "parity_vs_gpu": par}
 
 
 def main():
@@ -154,6 +169,19 @@ def main():
     dev = torch.device("cuda", local)
     coll_dev = dev if args.backend == "nccl" else None   # where the all-gather payload lives
     from bobe_amd.dist_sweep import merge_argmin, merge_best_fit, shard_bounds
+    if args.exchange == "rccl":                        # the C ABI's exchange step instead of torch's collectives
+        from bobe_amd import mgpu
+        mgpu.init_from_torch(local)
+
+        def merge_argmin(score, gidx, device=None):                    # noqa: F811
+            mine = np.array([score, 0.0])
+            mine[1:].view(np.int64)[0] = gidx
+            # (one (score, index) pair through the same all-gather + merge bobe_mgpu_wip_sweep uses)
+            best, th = mgpu.best_fit(-score if np.isfinite(score) else -np.inf, mine)
+            return float(th[0]), int(th[1:].view(np.int64)[0])
+
+        def merge_best_fit(mll_, theta_, device=None):                 # noqa: F811
+            return mgpu.best_fit(mll_, theta_)
 
     strong = args.config == "shard"
     if strong:
@@ -382,7 +410,7 @@ def main():
                                + (f", split over the ranks (this rank: restarts {my_restarts})" if strong and world > 1 else ""))
                        if R_total > 1 else f"{len(thetas)} sequential value+gradient evaluations",
                        "parallelism": f"candidate-sharded x{world}" + (", restart-sharded fit" if strong else ""),
-                       "backend": args.backend if world > 1 else None},
+                       "backend": args.backend if world > 1 else None, "exchange": args.exchange},
             "cholesky_gflops": flops_potrf / (potrf_ms * 1e-3) / 1e9,
             "cholesky_ms": potrf_ms,
             "cholesky_concurrent": chol["lockstep_4"],
@@ -398,6 +426,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(X, y, cand, Z, thetas, noise, gpu_check)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
+    if args.exchange == "rccl":
+        mgpu.finalize()
     if world > 1:
         dist.barrier()              # rank 0's secondary measurements are done: leave together
         dist.destroy_process_group()

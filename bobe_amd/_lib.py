@@ -60,6 +60,15 @@ SIGNATURES = [
     ("bobe_gp_set_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_clone_state", C.c_int, [C.c_void_p, C.c_void_p]),
     ("bobe_gp_append", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("bobe_mgpu_unique_id", C.c_int, [C.c_char_p]),
+    ("bobe_mgpu_init", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    ("bobe_mgpu_world", C.c_int, []),
+    ("bobe_mgpu_rank", C.c_int, []),
+    ("bobe_mgpu_finalize", None, []),
+    ("bobe_mgpu_wip_sweep", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_double,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      c_int64_p, c_double_p, c_int64_p, c_double_p]),
+    ("bobe_mgpu_best_fit", C.c_int, [C.c_double, C.c_void_p, C.c_int, c_double_p, C.c_void_p]),
     ("bobe_gp_npoints", C.c_int64, [C.c_void_p]),
     ("bobe_debug_gemm", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),

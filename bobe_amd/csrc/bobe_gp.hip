@@ -18,6 +18,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include "kernels.hpp"
 
 using namespace bobe;
@@ -1875,6 +1878,197 @@ int bobe_gp_profile_read(bobe_gp_t* g, double* total_ms, int64_t* launches) {
   *total_ms = tot;
   *launches = (int64_t)g->prof_used;
   g->prof_used = 0;
+  return BOBE_OK;
+  API_END
+}
+
+// -------------------------------------------------------------------------------------------------
+// Multi-GPU exchange step, one process per GPU: a RCCL communicator owned by the library.  librccl is
+// opened on first use (dlopen), so libbobe_gp.so itself loads on hosts without it.
+// -------------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0, device = 0;
+  hipStream_t stream = nullptr;
+  DBuf send, recv;
+  double* h_recv = nullptr;      // pinned
+  size_t h_recv_doubles = 0;
+  void load() {
+    if (lib) return;
+    lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) throw Err(BOBE_ERR_HIP, std::string("cannot open librccl.so: ") + dlerror());
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString)
+      throw Err(BOBE_ERR_HIP, "librccl.so lacks an expected entry point");
+  }
+  void check(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) throw Err(BOBE_ERR_HIP, std::string(what) + ": " + GetErrorString(r));
+  }
+  // every rank contributes n doubles; returns world*n doubles (rank-major) in pinned host memory
+  const double* all_gather(const double* mine, size_t n) {
+    if (!comm) throw Err(BOBE_ERR_STATE, "call bobe_mgpu_init first");
+    HIPCHK(hipSetDevice(device));
+    send.ensure(n * sizeof(double));
+    recv.ensure((size_t)world * n * sizeof(double));
+    if (h_recv_doubles < (size_t)world * n) {
+      if (h_recv) (void)hipHostFree(h_recv);
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_recv), (size_t)world * n * sizeof(double), hipHostMallocDefault));
+      h_recv_doubles = (size_t)world * n;
+    }
+    HIPCHK(hipMemcpyAsync(send.p, mine, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    check(AllGather(send.p, recv.p, n, ncclDouble, comm, stream), "ncclAllGather");
+    HIPCHK(hipMemcpyAsync(h_recv, recv.p, (size_t)world * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return h_recv;
+  }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+// merge rule of the exchange (jnp.argmin semantics, acquisition.py:397): smallest score, ties to the lowest global
+// index, a NaN score counts as minimal
+void merge_pairs(const double* all, int world, int stride, int off, double* best, int64_t* best_idx) {
+  bool have = false;
+  double bs = 0.0;
+  int64_t bi = 0;
+  for (int r = 0; r < world; ++r) {
+    const double s = all[(size_t)r * stride + off];
+    int64_t i;
+    std::memcpy(&i, &all[(size_t)r * stride + off + 1], sizeof(i));      // the index travels as raw int64 bits
+    if (i < 0) continue;                                                   // a rank without candidates
+    const double key = std::isnan(s) ? -INFINITY : s, bkey = std::isnan(bs) ? -INFINITY : bs;
+    if (!have || key < bkey || (key == bkey && i < bi)) {
+      have = true;
+      bs = s;
+      bi = i;
+    }
+  }
+  *best = have ? bs : std::nan("");
+  *best_idx = have ? bi : -1;
+}
+}  // namespace
+extern "C" {
+
+int bobe_mgpu_unique_id(char* id128) {
+  API_BEGIN
+  if (!id128) throw Err(BOBE_ERR_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  g_rccl.load();
+  ncclUniqueId id;
+  g_rccl.check(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+  static_assert(sizeof(id) == BOBE_MGPU_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id128, &id, sizeof(id));
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_mgpu_init(const char* id128, int world, int rank, int device) {
+  API_BEGIN
+  if (!id128 || world < 1 || rank < 0 || rank >= world) throw Err(BOBE_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (g_rccl.comm) throw Err(BOBE_ERR_STATE, "already initialised: call bobe_mgpu_finalize first");
+  g_rccl.load();
+  HIPCHK(hipSetDevice(device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  g_rccl.check(g_rccl.CommInitRank(&g_rccl.comm, world, id, rank), "ncclCommInitRank");
+  g_rccl.world = world;
+  g_rccl.rank = rank;
+  g_rccl.device = device;
+  HIPCHK(hipStreamCreateWithFlags(&g_rccl.stream, hipStreamNonBlocking));
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_mgpu_world(void) { return g_rccl.comm ? g_rccl.world : 0; }
+int bobe_mgpu_rank(void) { return g_rccl.comm ? g_rccl.rank : -1; }
+
+void bobe_mgpu_finalize(void) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (!g_rccl.comm) return;
+  (void)hipSetDevice(g_rccl.device);
+  (void)hipStreamSynchronize(g_rccl.stream);
+  (void)g_rccl.CommDestroy(g_rccl.comm);
+  g_rccl.comm = nullptr;
+  (void)hipStreamDestroy(g_rccl.stream);
+  g_rccl.stream = nullptr;
+  g_rccl.send.release();
+  g_rccl.recv.release();
+  if (g_rccl.h_recv) (void)hipHostFree(g_rccl.h_recv);
+  g_rccl.h_recv = nullptr;
+  g_rccl.h_recv_doubles = 0;
+  g_rccl.world = 1;
+  g_rccl.rank = 0;
+}
+
+int bobe_mgpu_wip_sweep(bobe_gp_t* g, const double* cand, int64_t C, int64_t global_offset, const double* Z, int64_t M,
+                        double y_std, double* wipv, double* wipstd, double* mean, double* var, int64_t* argmin_v,
+                        double* min_v, int64_t* argmin_s, double* min_s) {
+  API_BEGIN
+  if (!g || !Z) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (C < 0 || global_offset < 0) throw Err(BOBE_ERR_ARG, "bad shard");
+  if (!g_rccl.comm) throw Err(BOBE_ERR_STATE, "call bobe_mgpu_init first");
+  g->use();
+  int64_t lv = -1, ls = -1;
+  double mv = std::nan(""), msd = std::nan("");
+  if (C > 0) {
+    if (!cand) throw Err(BOBE_ERR_ARG, "NULL argument");
+    g->sweep(cand, C, Z, M, y_std, wipv, wipstd, mean, var, 1, &lv, &mv, &ls, &msd, nullptr);
+    lv += global_offset;
+    ls += global_offset;
+  }
+  double mine[4];
+  mine[0] = mv;
+  std::memcpy(&mine[1], &lv, sizeof(lv));
+  mine[2] = msd;
+  std::memcpy(&mine[3], &ls, sizeof(ls));
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  const double* all = g_rccl.all_gather(mine, 4);            // ONE collective per acquisition: 32 B per rank
+  double bv, bs;
+  int64_t iv, is;
+  merge_pairs(all, g_rccl.world, 4, 0, &bv, &iv);
+  merge_pairs(all, g_rccl.world, 4, 2, &bs, &is);
+  if (argmin_v) *argmin_v = iv;
+  if (min_v) *min_v = bv;
+  if (argmin_s) *argmin_s = is;
+  if (min_s) *min_s = bs;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_mgpu_best_fit(double mll, const double* theta, int n, double* best_mll, double* best_theta) {
+  API_BEGIN
+  if (!theta || !best_mll || !best_theta || n < 1 || n > 126) throw Err(BOBE_ERR_ARG, "bad argument");
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  std::vector<double> mine((size_t)n + 1);
+  mine[0] = mll;
+  std::memcpy(mine.data() + 1, theta, (size_t)n * sizeof(double));
+  const double* all = g_rccl.all_gather(mine.data(), (size_t)n + 1);
+  int br = -1;
+  double bm = -INFINITY;
+  for (int r = 0; r < g_rccl.world; ++r) {                    // max by mll, a non-finite mll never wins (pool.py:322-326)
+    const double m = all[(size_t)r * (n + 1)];
+    if (std::isfinite(m) && (br < 0 || m > bm)) {
+      br = r;
+      bm = m;
+    }
+  }
+  if (br < 0) br = 0;
+  *best_mll = all[(size_t)br * (n + 1)];
+  std::memcpy(best_theta, all + (size_t)br * (n + 1) + 1, (size_t)n * sizeof(double));
   return BOBE_OK;
   API_END
 }

@@ -158,6 +158,27 @@ int bobe_gp_clone_state(bobe_gp_t* dst, bobe_gp_t* src);
  * BOBE_NOT_PD). */
 int bobe_gp_append(bobe_gp_t* gp, const double* X_new, int64_t b, const double* y_all);
 
+/* ---- multi-GPU exchange step (the reference's counterpart is the MPI pool's pickled send/recv,
+ * BOBE/pool.py:298-326, and it has no candidate parallelism at all: acquisition.py:394 maps sequentially) ----------
+ * One process per GPU.  The library owns a RCCL communicator (librccl.so is opened on first use):
+ *   rank 0:      bobe_mgpu_unique_id(id)  -> ship the BOBE_MGPU_ID_BYTES bytes to the other ranks (any channel)
+ *   every rank:  bobe_mgpu_init(id, world, rank, device)
+ * bobe_mgpu_wip_sweep = bobe_gp_wip_sweep on this rank's contiguous shard [global_offset, global_offset + C) of the
+ * candidates (C may be 0), then ONE ncclAllGather of (min wipv, index, min wipstd, index) - 32 bytes per rank - and the
+ * merge every rank repeats: smallest score, ties to the lowest GLOBAL index (jnp.argmin's first occurrence,
+ * acquisition.py:397), NaN counts as minimal.  argmin_* / min_* are the global results; the score vectors stay local.
+ * bobe_mgpu_best_fit = all-gather of (mll, theta) and max by mll (pool.py:322-326) for the restart-sharded fit. */
+#define BOBE_MGPU_ID_BYTES 128
+int bobe_mgpu_unique_id(char* id128);
+int bobe_mgpu_init(const char* id128, int world, int rank, int device);
+int bobe_mgpu_world(void);
+int bobe_mgpu_rank(void);
+void bobe_mgpu_finalize(void);
+int bobe_mgpu_wip_sweep(bobe_gp_t* gp, const double* cand_shard, int64_t C, int64_t global_offset, const double* Z,
+                        int64_t M, double y_std, double* wipv, double* wipstd, double* mean, double* var,
+                        int64_t* argmin_v, double* min_v, int64_t* argmin_s, double* min_s);
+int bobe_mgpu_best_fit(double mll, const double* theta, int n, double* best_mll, double* best_theta);
+
 /* number of training points / padded leading dimension currently held */
 int64_t bobe_gp_npoints(bobe_gp_t* gp);
 

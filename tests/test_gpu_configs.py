@@ -129,3 +129,31 @@ def test_config5_rosenbrock_10d_full_loop_to_logz_convergence():
     assert res["best_val"] > -3.0                      # the maximum of the likelihood is 0 at x = 1
     s = res["samples"]
     assert s["x"].shape[1] == D and np.all(s["x"] >= -2.0 - 1e-9) and np.all(s["x"] <= 2.0 + 1e-9)
+
+
+def test_library_owned_rccl_exchange_single_rank():
+    """bobe_mgpu_*: the C ABI's own RCCL all-gather + merge.  One GPU on the box means one rank (RCCL refuses two
+    ranks on one device), which still runs ncclCommInitRank / ncclAllGather for real: the merged result must be the
+    plain sweep's, global offsets applied, and an empty shard must not win."""
+    from bobe_amd import GP, mgpu
+    rng = np.random.default_rng(8)
+    X = rng.uniform(size=(500, 4))
+    y = np.sin(X.sum(1))
+    gp = GP(X, y, noise=1e-6, lengthscales=np.full(4, 0.5))
+    cand, Z = rng.uniform(size=(3000, 4)), rng.uniform(size=(128, 4))
+    plain = gp.wip_sweep(cand, Z)
+    assert mgpu.world() == 0
+    w, r = mgpu.init_from_torch(device=0)
+    try:
+        assert (w, r) == (1, 0) and mgpu.world() == 1
+        got = mgpu.wip_sweep(gp, cand, 1000, Z)
+        assert np.array_equal(got["wipstd"], plain["wipstd"]) and np.array_equal(got["wipv"], plain["wipv"])
+        assert got["argmin_s"] == 1000 + plain["argmin_s"] and got["min_s"] == plain["min_s"]
+        assert got["argmin_v"] == 1000 + plain["argmin_v"] and got["min_v"] == plain["min_v"]
+        bm, bt = mgpu.best_fit(-12.5, np.array([0.1, 0.2, 0.3]))
+        assert bm == -12.5 and np.array_equal(bt, [0.1, 0.2, 0.3])
+        with pytest.raises(Exception):
+            mgpu.init(b"\0" * 128, 1, 0, 0)               # already initialised
+    finally:
+        mgpu.finalize()
+    assert mgpu.world() == 0

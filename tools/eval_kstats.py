@@ -1,0 +1,35 @@
+"""Per-kernel totals of ONE lock-step value+gradient batch (bobe_gp_mll_batch) from a rocprofv3 kernel trace.
+  run   : rocprofv3 --kernel-trace --output-format csv -d DIR -- python tools/eval_kstats.py run N B
+  parse : python tools/eval_kstats.py parse <kernel_trace.csv>"""
+import collections
+import csv
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+if sys.argv[1] == "run":
+    from bobe_amd.gp import GP
+    N, B = int(sys.argv[2]), int(sys.argv[3])
+    rng = np.random.default_rng(0)
+    X = rng.uniform(size=(N, 8))
+    gp = GP(X, np.sin(X.sum(1)), noise=1e-4, lengthscales=np.full(8, 0.6))
+    ls = np.full((B, 8), 0.55) + 0.01 * np.arange(B)[:, None]
+    for _ in range(3):
+        gp.mll_data_batch(ls, np.ones(B)) if B > 1 else gp.mll_data(ls[0], 1.0)
+else:
+    rows = list(csv.DictReader(open(sys.argv[2])))
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void bobe::", "").replace("bobe::", ""))
+                for r in rows)
+    last = max(i for i, e in enumerate(ev) if "k_scale_coords" in e[2])
+    seg = ev[last:]
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for s, e, n in seg:
+        tot[n] += (e - s) / 1e3
+        cnt[n] += 1
+    span = (seg[-1][1] - seg[0][0]) / 1e3
+    for n, v in sorted(tot.items(), key=lambda kv: -kv[1]):
+        print(f"{n:44s} {cnt[n]:4d} launches {v:9.1f} us  avg {v / cnt[n]:8.2f} us  {100 * v / span:5.1f} %")
+    print(f"span {span:.1f} us")
