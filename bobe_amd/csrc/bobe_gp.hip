@@ -533,8 +533,10 @@ void bobe_gp::trtri(const double* a, double* linv, double* tmp, int B, int64_t b
     const Depth& D = depths[dd];
     const TriProb* pr = static_cast<const TriProb*>(probs.p) + D.first;
     prof_begin(BOBE_PROF_TRTRI);
-    // (64x64 tiles while a level has too few 128x128 tiles to fill the chip; a tile's K order is the same either way)
-    if (B * D.nblocks < tu.trtri64_below) {
+    // (64x64 tiles while a level of ONE matrix has too few 128x128 tiles to fill the chip; a tile's K order is the
+    // same either way.  Batches keep the per-matrix choice: four in lock step at N = 4096 take 7.0 ms per evaluation
+    // round with 64x64 tiles at every level against 7.4 with 128x128 tiles at the top level)
+    if (D.nblocks < tu.trtri64_below) {
       hipLaunchKernelGGL(k_trtri_T<64>, dim3(2 * D.nblocks, B), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
                          (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT);
       hipLaunchKernelGGL(k_trtri_R<64>, dim3(2 * D.nblocks, B), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,

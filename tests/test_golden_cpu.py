@@ -1,6 +1,8 @@
-"""CPU regression: the oracle reproduces the committed golden vectors (tests/golden/make_golden.py), and — once
-somebody with the reference's environment has run tests/golden/make_reference_golden.py and committed its ref_*.npz —
-the reference's own outputs (those files are compared with tolerances that allow for XLA-vs-LAPACK rounding)."""
+"""ORACLE REGRESSION, not reference parity: the committed .npz vectors were written by the oracle itself
+(tests/golden/make_golden.py), so this file only guards the oracle against drifting.  What pins the oracle to the
+reference is tests/test_reference_held_cpu.py (the reference's own logged fit) and the independent implementations of
+tests/test_oracle.py.  Should somebody with the reference's JAX environment run tests/golden/make_reference_golden.py and
+commit its ref_*.npz, those files are picked up here too (tolerances allow for XLA-vs-LAPACK rounding)."""
 import glob
 import os
 

@@ -20,8 +20,12 @@ def test_two_rank_bo_run_retraces_single_process(tmp_path):
     single = W.run_case()
     out = tmp_path / "dist.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:          # a free port: two suites may share a box
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "workers", "dist_bo_worker.py"), str(out)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]

@@ -106,7 +106,7 @@ int run(const char* name, double* A, int64_t n, int first, int smem) {
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((k_upd<G, T, BK, PERSIST, INTERLEAVE>), dim3(PERSIST ? 256 : nq), dim3(256 * G), smem, 0, A, n, first, nt, tiles);
+    hipLaunchKernelGGL((k_upd<G, T, BK, PERSIST, INTERLEAVE>), dim3(PERSIST ? (G == 1 ? 1024 : 256) : nq), dim3(256 * G), smem, 0, A, n, first, nt, tiles);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -142,7 +142,10 @@ int main() {
     printf("1x64 BK16 waves_per_eu(4,4)  first= 8 tiles=%6d: %8.2f us  %6.2f TFLOP/s\n", tiles, best * 1e3, 2.0 * tiles * 64.0 * 64 * 128 / (best * 1e-3) / 1e12);
   }
   for (int first : {8}) {
-    if (run<2, 64, 16, false>("2x64 BK16 512thr 2WG/CU", A, n, first, 2 * 36864)) return 1;   // 56 blocks (207 MB of lower tiles: HBM) / 31 blocks (63 MB: Infinity Cache)
+    if (run<2, 64, 16, false>("2x64 BK16 512thr 2WG/CU", A, n, first, 2 * 36864)) return 1;
+    if (run<1, 64, 16, true>("1x64 BK16 persistent x1024", A, n, first, 36864)) return 1;
+    if (run<1, 64, 32, false>("1x64 BK32 (2 WG/CU)", A, n, first, gemm_smem_doubles_exact<KC, KC, 64, 64, 32>() * 8)) return 1;
+    if (run<1, 128, 32, false>("1x128 BK32 (1 WG/CU)", A, n, first, gemm_smem_doubles_exact<KC, KC, 128, 128, 32>() * 8)) return 1;   // 56 blocks (207 MB of lower tiles: HBM) / 31 blocks (63 MB: Infinity Cache)
     if (run<1, 64, 16, false>("1x64 BK16 (4 WG/CU)", A, n, first, gemm_smem_doubles_exact<KC, KC, 64, 64, 16>() * 8)) return 1;
     if (run<4, 64, 16, false>("4x64 BK16 1024thr", A, n, first, BIG)) return 1;
     if (run<4, 64, 16, true>("4x64 BK16 1024thr persist", A, n, first, BIG)) return 1;
