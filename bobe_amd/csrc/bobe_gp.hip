@@ -459,7 +459,9 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
   const Tuning& tu = tuning();
   if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches (B = 1)
   const int64_t bsD = (int64_t)nb * TILE * TILE;
-  if (B > 1 || tu.chol_legacy || !tu.chol_lookahead) {
+  // (on an evaluation slot the other slots' kernels share the chip: the lookahead step's 1024-thread, 150 KB
+  // workgroups would make the update half wait for EMPTY CUs too - the separate launches keep it on 36 KB tiles)
+  if (B > 1 || in_slot || tu.chol_legacy || !tu.chol_lookahead) {
     potrf_legacy(a, linv, info_dev, B, bsA, bsL, dg);
     return;
   }

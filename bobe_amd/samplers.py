@@ -96,13 +96,47 @@ def logz_from_samples(gp, samples_x, logl, logvol, mean: float, logz_err: float)
             "var": var_logz, "std": 2 * math.sqrt(var_logz)}
 
 
+def _rwalk_pool(loglike, live, live_logl, worst, lstar, rng, n_walkers, walks, scale):
+    """Replacement candidates by constrained random walks, the proposal dynesty's 'rwalk' uses (the reference's choice,
+    samplers.py:64, 152) — run as ONE batch: ``n_walkers`` walkers start from random live points and take ``walks``
+    Metropolis steps inside {L > L*, unit cube}, every step one batched surrogate call.  Steps are drawn from the live
+    points' covariance ellipsoid scaled by ``scale``.  Returns (points, logl, calls, acceptance rate); walkers that
+    never moved are dropped (they would duplicate a live point)."""
+    nlive, d = live.shape
+    ok = np.ones(nlive, dtype=bool)
+    ok[worst] = False
+    cov = np.cov(live[ok], rowvar=False).reshape(d, d) + 1e-14 * np.eye(d)
+    A = np.linalg.cholesky(cov)
+    start = rng.choice(np.flatnonzero(ok), size=n_walkers)
+    x, lx = live[start].copy(), live_logl[start].copy()
+    moved = np.zeros(n_walkers, dtype=bool)
+    n_acc, calls = 0, 0
+    for _ in range(walks):
+        prop = x + scale * (rng.standard_normal((n_walkers, d)) @ A.T)
+        inside = np.all((prop >= 0.0) & (prop <= 1.0), axis=1)
+        lp = np.full(n_walkers, -np.inf)
+        if inside.any():
+            lp[inside] = loglike(prop[inside])
+            calls += int(inside.sum())
+        acc = inside & (lp > lstar)
+        x[acc], lx[acc] = prop[acc], lp[acc]
+        moved |= acc
+        n_acc += int(acc.sum())
+    perm = rng.permutation(np.flatnonzero(moved))
+    return x[perm], lx[perm], calls, n_acc / float(n_walkers * walks)
+
+
 def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", dlogz: float = 0.01,
                     maxcall: int = int(5e6), equal_weights: bool = False, rng=None, batch: int = 8192,
-                    enlarge: float = 1.25, nlive: Optional[int] = None) -> Tuple[Dict, Dict, bool]:
+                    enlarge: float = 1.25, nlive: Optional[int] = None, sample_method: str = "auto",
+                    walks: Optional[int] = None) -> Tuple[Dict, Dict, bool]:
     """Static nested sampling of exp(GP mean) over the unit cube -> (samples_dict, logz_dict, success).
 
     Settings follow ``nested_sampling_Dy`` (samplers.py:119-126): mode 'acq' uses nlive = max(100, min(500, 20 d))
-    and dlogz = 0.1 with equal-weight samples; otherwise nlive = max(500, 40 d)."""
+    and dlogz = 0.1 with equal-weight samples; otherwise nlive = max(500, 40 d).
+    ``sample_method``: 'ellipsoid' = uniform draws in the enlarged bounding ellipsoid of the live points (exact, cheap
+    in a few dimensions), 'rwalk' = batched constrained random walks (``_rwalk_pool``; what the reference asks dynesty
+    for), 'auto' = ellipsoid up to 4 dimensions, rwalk above."""
     rng = rng if rng is not None else get_numpy_rng()
     ndim = ndim if ndim is not None else gp.ndim
     if mode == "acq":
@@ -121,6 +155,9 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
         nan = float("nan")
         return ({"x": live, "weights": np.ones(nlive), "logl": live_logl, "best": live[0], "method": "nested"},
                 {"mean": nan, "dlogz_sampler": nan, "upper": nan, "lower": nan, "var": nan, "std": nan}, False)
+    use_rwalk = sample_method == "rwalk" or (sample_method == "auto" and ndim > 4)
+    walks = walks if walks is not None else max(25, 4 * ndim)           # dynesty's default is 25
+    rw_scale = 2.38 / math.sqrt(ndim)
     ncall = nlive
     dead_x, dead_logl = [], []
     logz = -np.inf
@@ -157,6 +194,21 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
                 pool_pos += 1
             if found:
                 break
+            if use_rwalk:
+                pool_x, pool_l, calls, rate = _rwalk_pool(loglike, live, live_logl, worst, lstar, rng,
+                                                          n_walkers=max(256, min(batch // 8, 2 * nlive)), walks=walks,
+                                                          scale=rw_scale)
+                pool_pos = 0
+                ncall += calls
+                # keep the acceptance rate of a step near one half (dynesty adapts its scale the same way)
+                rw_scale = float(np.clip(rw_scale * math.exp((rate - 0.5) / max(ndim, 1) * 4.0), 1e-4, 4.0))
+                tries += 1
+                if tries > 200 or ncall >= maxcall:
+                    if tries > 200:
+                        log.warning("nested sampling: no acceptable replacement found; stopping early")
+                    found = True
+                    ncall = maxcall
+                continue
             if since_update >= update_every or tries > 0 or len(pool_l) == 0:
                 mask = np.ones(nlive, dtype=bool)
                 mask[worst] = False
@@ -215,9 +267,11 @@ def nested_sampling_Dy(gp, mode: str = "acq", ndim: int = 1, dlogz: float = 0.1,
                        maxcall: Optional[int] = int(5e6), print_progress: Optional[bool] = True,
                        equal_weights: bool = False, sample_method: str = "rwalk", rng=None):
     """The reference's entry point name and keywords (samplers.py:55-65) on ``nested_sampling`` above; ``dynamic``,
-    ``print_progress`` and ``sample_method`` are dynesty options without a counterpart here."""
+    ``print_progress`` are dynesty options without a counterpart here; ``sample_method='rwalk'`` (the reference's
+    default) maps to 'auto': exact ellipsoid draws in up to 4 dimensions, batched random walks above."""
     return nested_sampling(gp, ndim=ndim if ndim and ndim > 1 else gp.ndim, mode=mode, dlogz=dlogz,
-                           maxcall=maxcall if maxcall is not None else int(5e6), equal_weights=equal_weights, rng=rng)
+                           maxcall=maxcall if maxcall is not None else int(5e6), equal_weights=equal_weights, rng=rng,
+                           sample_method="auto" if sample_method == "rwalk" else sample_method)
 
 
 def get_hmc_settings(ndim, warmup_steps=None, num_samples=None, thinning=None):
