@@ -138,17 +138,15 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, chol_strips, chol_ll, mll_slots, own_queues, graph_max_n, lockstep_min_n; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, mll_slots, own_queues, graph_max_n, lockstep_min_n; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 1, 0, 1150, 4, 1, 2048, 1024};
+    Tuning v{512, 600, 1200, 0, 1, 4, 1, 2048, 1024};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_CHOL_LEGACY")) v.chol_legacy = std::atoi(e);   // always potf2 / trsm / syrk launches
     if (const char* e = std::getenv("BOBE_CHOL_LOOKAHEAD")) v.chol_lookahead = std::atoi(e);   // 0: no fused step for B = 1
-    if (const char* e = std::getenv("BOBE_CHOL_STRIPS")) v.chol_strips = std::atoi(e);         // 1: 64-column strips with column-update launches (measured slower)
-    if (const char* e = std::getenv("BOBE_CHOL_LL")) v.chol_ll = std::atoi(e);                 // left-looking strips while B*rem^2 > this (0: never)
     if (const char* e = std::getenv("BOBE_LOCKSTEP_MIN_N")) v.lockstep_min_n = std::atoi(e);
     if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
     if (const char* e = std::getenv("BOBE_OWN_QUEUES")) v.own_queues = std::atoi(e);
@@ -300,8 +298,6 @@ struct bobe_gp {
   void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0);
   void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0, double* dg = nullptr);
   void potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg);
-  void potrf_strips(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg);
-  void potrf_strips_ll(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg);
   void trtri(const double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
   int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
             const Hyper* hdev = nullptr, double* gp_out = nullptr, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
@@ -465,14 +461,6 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
   const int64_t bsD = (int64_t)nb * TILE * TILE;
   // (on an evaluation slot the other slots' kernels share the chip: the lookahead step's 1024-thread, 150 KB
   // workgroups would make the update half wait for EMPTY CUs too - the separate launches keep it on 36 KB tiles)
-  if (tu.chol_strips && !tu.chol_legacy && !in_slot) {
-    potrf_strips(a, linv, info_dev, B, bsA, bsL, dg);
-    return;
-  }
-  if (tu.chol_ll > 0 && !tu.chol_legacy && !in_slot && B * (nb - 1) * (nb - 1) > tu.chol_ll) {
-    potrf_strips_ll(a, linv, info_dev, B, bsA, bsL, dg);
-    return;
-  }
   if (B > 1 || in_slot || tu.chol_legacy || !tu.chol_lookahead) {
     potrf_legacy(a, linv, info_dev, B, bsA, bsL, dg);
     return;
@@ -495,129 +483,6 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
     prof_end(BOBE_PROF_POTF2);
   }
   hipLaunchKernelGGL(k_copy_diag, dim3(nb, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD, 0);
-  LAUNCH_CHECK();
-}
-
-// 64-column strips with one-step lookahead (chol_kernels.hpp "64-column strips"): per 128-block column k
-//   1. k_chol_strip   panel of strip a (columns k*128 .. +63)   ||  first half of the update by block k-1 (K = 128)
-//   2. k_strip_update strip b receives strip a's panel (K = 64)
-//   3. k_chol_strip   panel of strip b                          ||  second half of that update
-//   4. k_syrk_trail   (colmode 1) block column k+1 receives block k's panels (K = 128)
-// All four are 256-thread launches with <= 36 KB of LDS, so the update runs at k_syrk_trail's rate while the panel
-// chain runs beside it.
-void bobe_gp::potrf_strips(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
-  const int64_t bsD = (int64_t)nb * TILE * TILE;
-  for (int k = 0; k < nb; ++k) {
-    const int rem = nb - 1 - k;
-    const int nvalid = (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE);
-    const int nva = std::min(64, nvalid), nvb = std::max(0, nvalid - 64);
-    const int n64 = 2 * rem;
-    const int ntiles = k > 0 ? n64 * (n64 + 1) / 2 : 0;        // update by block k-1 on the tiles right of column k
-    const int half = ntiles / 2;
-    const int64_t kbeg = (int64_t)(k - 1) * TILE, kend = (int64_t)k * TILE;
-    const int64_t col0 = (int64_t)k * TILE;
-    prof_begin(BOBE_PROF_POTF2);
-    {
-      const int npanel = 2 * rem + 1;                          // rows below strip a's diagonal block, 64 per workgroup
-      hipLaunchKernelGGL(k_chol_strip, dim3(B * npanel + B * half), dim3(256), STRIP_SMEM_BYTES, stream, a, Np, bsA, linv, Np,
-                         bsL, col0, B, npanel, true, info_dev, nva, dg, bsD, 2 * k, k + 1, 0, half, kbeg, kend);
-    }
-    prof_end(BOBE_PROF_POTF2);
-    prof_begin(BOBE_PROF_TRSM);
-    hipLaunchKernelGGL(k_strip_update, dim3((unsigned)(2 * ((Np - col0 - 64) / 32)), (unsigned)B), dim3(256),
-                       STRIPUPD_SMEM_BYTES, stream, a, Np, bsA, col0);
-    prof_end(BOBE_PROF_TRSM);
-    prof_begin(BOBE_PROF_POTF2);
-    {
-      const int npanel = rem > 0 ? 2 * rem : 1;
-      hipLaunchKernelGGL(k_chol_strip, dim3(B * npanel + B * (ntiles - half)), dim3(256), STRIP_SMEM_BYTES, stream, a, Np, bsA,
-                         linv, Np, bsL, col0 + 64, B, npanel, rem > 0, info_dev, nvb, dg, bsD, 2 * k + 1, k + 1, half, ntiles,
-                         kbeg, kend);
-    }
-    prof_end(BOBE_PROF_POTF2);
-    if (rem > 0) {
-      prof_begin(BOBE_PROF_SYRK);
-      syrk(a, k, k + 1, k + 1, 1, B, bsA);
-      prof_end(BOBE_PROF_SYRK);
-    }
-  }
-  hipLaunchKernelGGL(k_copy_diag64, dim3(2 * nb, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD, 0);
-  LAUNCH_CHECK();
-}
-
-// Left-looking 64-column strips with the bulk update beside them - TWO launches per 128-block column and nothing else
-// on the chain - for the steps whose update outlasts the panel chain (B * rem^2 > chol_ll; a batch of four at
-// N = 4096: the first 14 of 32 steps); the remaining steps take the separate launches.  Per block column k:
-//   1. k_chol_strip  panel of strip a, left-looking over block k-1   ||  first half of the update by block k-1 of the
-//                                                                        tiles right of block column k
-//   2. k_chol_strip  panel of strip b, left-looking over block k-1 and strip a   ||  second half of that update
-// Block column k therefore needs no separate column-update launches; what block k-1 owes to the columns right of k is
-// the bulk half of the two launches.
-void bobe_gp::potrf_strips_ll(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
-  const Tuning& tu = tuning();
-  const int64_t bsD = (int64_t)nb * TILE * TILE;
-  int k = 0;
-  for (; k < nb; ++k) {
-    const int rem = nb - 1 - k;
-    if (B * rem * rem <= tu.chol_ll) break;                    // from here on the chain is longer than the update
-    const int n64 = 2 * rem;
-    const int ntiles = k > 0 ? n64 * (n64 + 1) / 2 : 0;
-    const int half = ntiles / 2;
-    const int64_t kbeg = (int64_t)(k - 1) * TILE, kend = (int64_t)k * TILE, col0 = (int64_t)k * TILE;
-    prof_begin(BOBE_PROF_POTF2);
-    {
-      const int npanel = 2 * rem + 1;
-      hipLaunchKernelGGL(k_chol_strip, dim3(B * npanel + B * half), dim3(256), STRIP_SMEM_BYTES, stream, a, Np, bsA, linv, Np,
-                         bsL, col0, B, npanel, true, info_dev, 64, dg, bsD, 2 * k, k + 1, 0, half, kbeg, kend,
-                         k > 0 ? kbeg : (int64_t)0, k > 0 ? kend : (int64_t)0);
-      const int npb = 2 * rem;                                 // (rem > 0 here)
-      hipLaunchKernelGGL(k_chol_strip, dim3(B * npb + B * (ntiles - half)), dim3(256), STRIP_SMEM_BYTES, stream, a, Np, bsA,
-                         linv, Np, bsL, col0 + 64, B, npb, true, info_dev, 64, dg, bsD, 2 * k + 1, k + 1, half, ntiles, kbeg,
-                         kend, k > 0 ? kbeg : col0, col0 + 64);
-    }
-    prof_end(BOBE_PROF_POTF2);
-  }
-  const int kswitch = k;
-  if (kswitch > 0) {
-    hipLaunchKernelGGL(k_copy_diag64, dim3(2 * kswitch, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD, 0);
-    // block kswitch-1 has not been applied to anything right of it yet
-    prof_begin(BOBE_PROF_SYRK);
-    syrk(a, kswitch - 1, kswitch, kswitch, 0, B, bsA);
-    prof_end(BOBE_PROF_SYRK);
-  }
-  // the chain-bound rest: panel + update as separate launches
-  int first_aside = nb;
-  for (k = kswitch; k < nb; ++k) {
-    const int rem = nb - k - 1;
-    const int nvalid = (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE);
-    const int npanel = rem > 0 ? 2 * rem : 1;
-    if (B * npanel <= std::max(num_cus, 1)) {
-      first_aside = std::min(first_aside, k);
-      prof_begin(BOBE_PROF_POTF2);
-      hipLaunchKernelGGL(k_chol_panel<false>, dim3(npanel, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
-                         k, npanel, info_dev, nvalid, dg, bsD, (unsigned long long*)nullptr);
-      prof_end(BOBE_PROF_POTF2);
-    } else {
-      prof_begin(BOBE_PROF_POTF2);
-      hipLaunchKernelGGL((k_potf2<true, false>), dim3(B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k, info_dev,
-                         (unsigned long long*)nullptr, nvalid, bsA, bsL);
-      prof_end(BOBE_PROF_POTF2);
-      if (rem > 0) {
-        prof_begin(BOBE_PROF_TRSM);
-        hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rem, B), dim3(256), TRSM_SMEM_BYTES, stream, a, Np,
-                           (const double*)linv, Np, k, (unsigned long long*)nullptr, bsA, bsL);
-        prof_end(BOBE_PROF_TRSM);
-      }
-    }
-    if (rem > 0) {
-      prof_begin(BOBE_PROF_SYRK);
-      syrk(a, k, k + 1, k + 1, 0, B, bsA);
-      prof_end(BOBE_PROF_SYRK);
-    }
-  }
-  if (first_aside < nb)
-    hipLaunchKernelGGL(k_copy_diag, dim3(nb - first_aside, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD,
-                       first_aside);
   LAUNCH_CHECK();
 }
 

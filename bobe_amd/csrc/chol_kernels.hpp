@@ -91,8 +91,7 @@ __device__ __forceinline__ void tri_decode_small(int t, int& i, int& j) {
   j = t - ii * (ii + 1) / 2;
 }
 
-// S[ti][tj] -= L[ti][p] L[tj][p]^T for two 16x16 tiles at once (independent MFMA chains); PLD = leading dimension of S
-template <int PLD = bobe::PLD>
+// S[ti][tj] -= L[ti][p] L[tj][p]^T for two 16x16 tiles at once (independent MFMA chains)
 __device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0, int ti1, int tj1, bool two, int lane) {
   v4d acc0, acc1;
 #pragma unroll
@@ -591,263 +590,6 @@ __global__ __launch_bounds__(STEP_THREADS) void k_chol_step(double* __restrict__
   gemm_tile<KC, KC, 64, 64, 16, true>(acc, As, lda, base + (int64_t)a * 64, As, lda, base + (int64_t)b * 64,
                                       (int64_t)(k - 1) * TILE, (int64_t)k * TILE, smem + grp * STEP_TILE_SMEM_DOUBLES, tid);
   if (live) store_tile<64, 64>(acc, As, lda, base + (int64_t)a * 64, base + (int64_t)b * 64, 1.0, 0.0, tid);
-}
-
-// ---- 64-column strips: the panel in 33 KB of LDS, so that it shares a launch SHAPE with the 64x64 update tiles ------
-// A 128-block column is factored as two strips of 64 columns.  A strip's diagonal block is 64 x 64 = 33 KB of LDS
-// (leading dimension 66); the inverses of its four 16x16 diagonal sub-blocks live in otherwise unused UPPER tiles of
-// the same LDS image.  A strip panel workgroup (256 threads, 64 rows of the panel) is therefore no bigger than a
-// k_syrk_trail<64,16> workgroup (36 KB), and k_chol_strip runs panel workgroups and update tiles side by side at four
-// workgroups per CU - the one-launch lookahead of k_chol_step without its 1024-thread update half.
-// Every matrix element still sees the operation sequence of the 128-column form (same 16-column steps, same MFMA
-// order): a strip's rows inside the block are solved like panel rows, which is the same dot-product order as the
-// in-LDS update + row solve of k_potf2.
-constexpr int SLD = 66;                                   // LDS leading dimension of a 64x64 block (doubles)
-constexpr int STRIP_SMEM_DOUBLES = 64 * SLD;              // 4224 doubles = 33,792 B
-constexpr int STRIP_SMEM_BYTES = gemm_smem_doubles_exact<KC, KC, 64, 64, 16>() * 8;      // 36,864 B: the update tile's
-static_assert(STRIP_SMEM_DOUBLES * 8 <= STRIP_SMEM_BYTES, "strip panel must fit the update tile's LDS");
-
-// inverse of diagonal sub-block p: tile (p, p+1) for p = 0, 1, 2 and tile (0, 3) for p = 3 (leading dimension SLD)
-__device__ __forceinline__ double* strip_dinv(double* S, int p) {
-  const int tr = (p == 3) ? 0 : p, tc = (p == 3) ? 3 : p + 1;
-  return S + (16 * tr) * SLD + 16 * tc;
-}
-
-// factor loop of k_potf2 on a 64x64 block (four 16-column steps); same phases, same arithmetic per tile
-__device__ __forceinline__ void strip_factor_lds(double* S, int nsteps, int colbase, int* __restrict__ info) {
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = t >> 6;
-  for (int p = 0; p < nsteps; ++p) {
-    const int o = 16 * p;
-    double* Dv = strip_dinv(S, p);
-    if (wave == 0) {
-      if (lane < 32) {
-        const int li = lane & 15;
-        const bool ident = lane >= 16;
-        double r[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) r[c] = ident ? ((c == li) ? 1.0 : 0.0) : S[(o + li) * SLD + o + c];
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const double ajj = readlane_f64(r[j], j);
-          if (!(ajj > 0.0)) bad = true;
-          const double inv = rsqrt_nr(ajj);
-          r[j] *= inv;
-#pragma unroll
-          for (int c = j + 1; c < 16; ++c) {
-            const double lcj = readlane_f64(r[j], c);
-            r[c] = __builtin_fma(-r[j], lcj, r[c]);
-          }
-        }
-        if (lane < 16) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) S[(o + li) * SLD + o + c] = (c <= li) ? r[c] : 0.0;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) Dv[c * SLD + li] = r[c];
-        }
-        if (bad && lane == 0) atomicMin(info, colbase + o + 1);
-      }
-    } else if (p > 0) {
-      // deferred updates of step p-1: tiles (ti, tj), p <= tj <= ti <= 3, except (p, p)
-      const int op = o - 16;
-      const int nt = 4 - p;
-      const int ntiles = nt * (nt + 1) / 2 - 1;
-      for (int q = wave - 1; q < ntiles; q += 6) {
-        int a0, b0, a1, b1;
-        tri_decode_small(q + 1, a0, b0);
-        const bool two = (q + 3) < ntiles;
-        tri_decode_small(two ? q + 4 : q + 1, a1, b1);
-        potf2_update2<SLD>(S, op, p + a0, p + b0, p + a1, p + b1, two, lane);
-      }
-    }
-    __syncthreads();
-    for (int tt = p + 1 + wave; tt < 4; tt += 4) {
-      v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double av = Dv[(lane & 15) * SLD + (lane >> 4) + 4 * r];
-        const double bv = S[(16 * tt + (lane & 15)) * SLD + o + (lane >> 4) + 4 * r];
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S[(16 * tt + (lane & 15)) * SLD + o + (lane >> 4) + 4 * r] = y[r];
-    }
-    __syncthreads();
-    if (p + 1 < nsteps && wave == 0) potf2_update2<SLD>(S, o, p + 1, p + 1, p + 1, p + 1, false, lane);
-  }
-  __syncthreads();
-}
-
-// One 64-row workgroup of a strip panel: stage the strip's 64x64 diagonal block, factor it (every workgroup does: no
-// hand-off), pw = 0 leaves L (dense 64x64 scratch block, see chol_panel_body for why not in place) and the four 16x16
-// inverses (diagonal positions of Linv), then solve rows rowbase + 64*pw + 16*wave .. +15 of the strip.
-// LEFT-LOOKING form (ke > kb): the strip has not yet received the panels of columns [kb, ke) - the previous block
-// column and, for a second strip, the first strip.  The workgroup applies them itself, to its own 64 rows and
-// (redundantly, like the factorisation) to the diagonal block, with the update tile's own GEMM core and LDS, before
-// it factors: the narrow column-update launches between the steps disappear from the chain.  An element still
-// receives its K range in ascending order, as one more load-accumulate pass.
-__device__ __forceinline__ void strip_panel_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv, int64_t ldl,
-                                                 int64_t col0, int pw, bool has_rows, int* __restrict__ info, int nvalid,
-                                                 double* __restrict__ Lout, double* S, int64_t kb = 0, int64_t ke = 0) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int g = lane >> 4, li = lane & 15;
-  const int nsteps = (nvalid + 15) >> 4;
-  double* Ab = A + col0 * lda + col0;
-  const int64_t row0 = col0 + 64 + (int64_t)pw * 64 + wave * 16;
-  double* Aw = A + row0 * lda + col0;
-  v4d X[4];
-  if (ke > kb) {
-    if (has_rows) {
-      const int64_t rw = col0 + 64 + (int64_t)pw * 64;
-      v4d acc[2][2];
-      load_tile<64, 64>(acc, A, lda, rw, col0);
-      gemm_tile<KC, KC, 64, 64, 16, true>(acc, A, lda, rw, A, lda, col0, kb, ke, S);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) S[acc_row<64>(i, r) * SLD + acc_col<64>(j)] = acc[i][j][r];
-      __syncthreads();
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X[p][r] = S[(wave * 16 + li) * SLD + 16 * p + g + 4 * r];
-      __syncthreads();
-    }
-    v4d acc[2][2];
-    load_tile<64, 64>(acc, A, lda, col0, col0);
-    gemm_tile<KC, KC, 64, 64, 16, true>(acc, A, lda, col0, A, lda, col0, kb, ke, S);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[acc_row<64>(i, r) * SLD + acc_col<64>(j)] = acc[i][j][r];
-  } else {
-    const int row = t >> 2, c0 = (t & 3) * 16;
-    v2d v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const v2d*>(Ab + (int64_t)row * lda + c0 + 2 * i);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<v2d*>(S + row * SLD + c0 + 2 * i) = v[i];
-    if (has_rows) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X[p][r] = Aw[(int64_t)li * lda + 16 * p + g + 4 * r];
-    }
-  }
-  __syncthreads();
-  if (nsteps < 4) {      // identity inverses for the padding steps of a ragged last block
-    for (int e = t; e < (4 - nsteps) * 256; e += 256) {
-      const int pp = nsteps + (e >> 8), rr = (e >> 4) & 15, cc = e & 15;
-      strip_dinv(S, pp)[rr * SLD + cc] = (rr == cc) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-  }
-  strip_factor_lds(S, nsteps, (int)col0, info);
-  if (pw == 0) {
-    const int row = t >> 2, c0 = (t & 3) * 16;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) Lout[row * 64 + c0 + c] = (c0 + c <= row) ? S[row * SLD + c0 + c] : 0.0;
-    const int bb = t >> 6, rr = (t >> 2) & 15, cc0 = (t & 3) * 4;
-    const double* src = strip_dinv(S, bb) + rr * SLD + cc0;
-    double* dst = Linv + (col0 + 16 * bb + rr) * ldl + col0 + 16 * bb + cc0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c] = src[c];
-  }
-  if (!has_rows) return;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    v4d x = X[p];
-#pragma unroll
-    for (int q = 0; q < p; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double av = -S[(16 * p + li) * SLD + 16 * q + g + 4 * r];
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[q][r], x, 0, 0, 0);
-      }
-    const double* Dp = strip_dinv(S, p);
-    v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double av = Dp[li * SLD + g + 4 * r];
-      y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, x[r], y, 0, 0, 0);
-    }
-    X[p] = y;
-  }
-  __syncthreads();   // every wave is done with L and the inverses: reuse the block as transposer
-  double* Sw = S + (wave * 16) * SLD;
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Sw[li * SLD + 16 * p + g + 4 * r] = X[p][r];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int rr = 2 * i + (lane >> 5), cc = 2 * (lane & 31);
-    *reinterpret_cast<v2d*>(Aw + (int64_t)rr * lda + cc) = *reinterpret_cast<const v2d*>(Sw + rr * SLD + cc);
-  }
-}
-
-// One launch = strip panel  ||  a slice of the trailing update, all 256-thread workgroups with 36 KB of LDS.
-//   workgroups [0, nbatch*npanel): panel of the strip starting at column col0 (slot = wg / npanel, pw = wg % npanel),
-//       left-looking over columns [llb, lle) when that range is not empty
-//   the others: lower 64x64 tiles [t0, t1) (row-major triangular enumeration) of the trailing matrix that starts at
-//       128-block `first`, updated with columns [kbeg, kend) (k_syrk_trail's tile arithmetic); slot-major.
-__global__ __launch_bounds__(256, 4) void k_chol_strip(double* __restrict__ A, int64_t lda, int64_t bsA,
-                                                    double* __restrict__ Linv, int64_t ldl, int64_t bsL, int64_t col0,
-                                                    int nbatch, int npanel, bool has_rows, int* __restrict__ info,
-                                                    int nvalid, double* __restrict__ diag, int64_t bsD, int strip_index,
-                                                    int first, int t0, int t1, int64_t kbeg, int64_t kend,
-                                                    int64_t llb = 0, int64_t lle = 0) {
-  extern __shared__ double smem[];
-  const int wg = blockIdx.x;
-  if (wg < nbatch * npanel) {
-    const int slot = wg / npanel, pw = wg - slot * npanel;
-    strip_panel_body(A + slot * bsA, lda, Linv + slot * bsL, ldl, col0, pw, has_rows, info + slot, nvalid,
-                     diag + slot * bsD + (int64_t)strip_index * 4096, smem, llb, lle);
-    return;
-  }
-  const int q = wg - nbatch * npanel;
-  const int per = t1 - t0;
-  const int slot = q / per;
-  double* As = A + slot * bsA;
-  int a, b;
-  tri_decode(t0 + (q - slot * per), a, b);
-  const int64_t base = (int64_t)first * TILE;
-  v4d acc[2][2];
-  load_tile<64, 64>(acc, As, lda, base + (int64_t)a * 64, base + (int64_t)b * 64);
-  gemm_tile<KC, KC, 64, 64, 16, true>(acc, As, lda, base + (int64_t)a * 64, As, lda, base + (int64_t)b * 64, kbeg, kend, smem);
-  store_tile<64, 64>(acc, As, lda, base + (int64_t)a * 64, base + (int64_t)b * 64, 1.0, 0.0);
-}
-
-// second strip of a block column receives the first strip's panel: rows >= col0 + 64, columns [col0 + 64, col0 + 128),
-// K = [col0, col0 + 64).  32x32 tiles, the whole K in one LDS stage; grid = (row tiles * 2, nbatch).
-constexpr int STRIPUPD_SMEM_BYTES = gemm_smem_doubles_exact<KC, KC, 32, 32, 64>() * 8 / 2;     // 33,792 B (one buffer)
-__global__ __launch_bounds__(256) void k_strip_update(double* __restrict__ A, int64_t lda, int64_t bsA, int64_t col0) {
-  extern __shared__ double smem[];
-  A += blockIdx.y * bsA;
-  const int64_t m0 = col0 + 64 + (int64_t)(blockIdx.x >> 1) * 32, n0 = col0 + 64 + (int64_t)(blockIdx.x & 1) * 32;
-  v4d acc[1][1];
-  load_tile<32, 32>(acc, A, lda, m0, n0);
-  gemm_tile<KC, KC, 32, 32, 64, true>(acc, A, lda, m0, A, lda, n0, col0, col0 + 64, smem);
-  store_tile<32, 32>(acc, A, lda, m0, n0, 1.0, 0.0);
-}
-
-// A[64-block j][64-block j] <- scratch block j for j = first + blockIdx.x (slot = blockIdx.y)
-__global__ __launch_bounds__(256) void k_copy_diag64(double* __restrict__ A, int64_t lda, int64_t bsA,
-                                                     const double* __restrict__ diag, int64_t bsD, int first) {
-  const int j = first + blockIdx.x;
-  const double* src = diag + blockIdx.y * bsD + (int64_t)j * 4096;
-  double* dst = A + blockIdx.y * bsA + ((int64_t)j * 64) * lda + (int64_t)j * 64;
-  const int row = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    *reinterpret_cast<v2d*>(dst + (int64_t)row * lda + c0 + 2 * i) = *reinterpret_cast<const v2d*>(src + row * 64 + c0 + 2 * i);
 }
 
 // ---- trailing update: A[i][j] -= sum_{k0 <= k < k1} L[i][k] L[j][k]^T over lower T x T tiles ---------------
