@@ -408,7 +408,7 @@ void bobe_gp::kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int
 
 void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev, int B, int64_t bsX,
                            int64_t bsA) {
-  const dim3 grid((unsigned)(nb * (nb + 1) / 2), (unsigned)B);
+  const dim3 grid((unsigned)(2 * nb * (nb + 1)), (unsigned)B);   // four workgroups per lower 128x128 tile
   prof_begin(BOBE_PROF_KXX);
   KM_DISPATCH(true, grid, xst, Np, N, xst, Np, N, h, a, Np, hdev, bsX, bsA);
   prof_end(BOBE_PROF_KXX);

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
     AT += blockIdx.y * bsX;
     BT += blockIdx.y * bsX;
     out += blockIdx.y * bsO;
-    tri_decode(blockIdx.x, ti, tj);
+    // four workgroups per lower tile (32 rows each): n(n+1)/2 tiles alone are barely two per CU at N = 4096
+    tri_decode(blockIdx.x >> 2, ti, tj);
   } else {
     ti = blockIdx.y;
     tj = blockIdx.x;
@@ -110,8 +111,9 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
   for (int j = 0; j < DCAP; ++j) xb[j] = (FULL || j < h.d) ? BT[j * ldb + gb] : 0.0;
   const int a0 = __builtin_amdgcn_readfirstlane(t >> 7);   // wave-uniform (a wave spans 64 consecutive columns)
   const double* arow = AT + (int64_t)ti * TILE;
+  const int abeg = SQUARE ? (int)(blockIdx.x & 3) * (TILE / 4) : 0, aend = SQUARE ? abeg + TILE / 4 : TILE;
 #pragma unroll 4
-  for (int a = a0; a < TILE; a += 2) {
+  for (int a = abeg + a0; a < aend; a += 2) {
     const int64_t ga = (int64_t)ti * TILE + a;
     double r2 = 0.0;
     double xa[DCAP];   // unconditional (clamped) loads: all in flight at once, no branch per dimension
