@@ -138,15 +138,16 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, mll_slots, own_queues, graph_max_n, lockstep_min_n; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, lookahead_max_rem, mll_slots, own_queues, graph_max_n, lockstep_min_n; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 1, 4, 1, 2048, 1024};
+    Tuning v{512, 600, 1200, 0, 1, 39, 4, 1, 2048, 1024};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_CHOL_LEGACY")) v.chol_legacy = std::atoi(e);   // always potf2 / trsm / syrk launches
     if (const char* e = std::getenv("BOBE_CHOL_LOOKAHEAD")) v.chol_lookahead = std::atoi(e);   // 0: no fused step for B = 1
+    if (const char* e = std::getenv("BOBE_LOOKAHEAD_MAX_REM")) v.lookahead_max_rem = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LOCKSTEP_MIN_N")) v.lockstep_min_n = std::atoi(e);
     if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
     if (const char* e = std::getenv("BOBE_OWN_QUEUES")) v.own_queues = std::atoi(e);
@@ -297,7 +298,6 @@ struct bobe_gp {
                     int64_t bsX = 0, int64_t bsA = 0);
   void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0);
   void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0, double* dg = nullptr);
-  void potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg);
   void trtri(const double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
   int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
             const Hyper* hdev = nullptr, double* gp_out = nullptr, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
@@ -457,44 +457,38 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
 // Every matrix element sees the same operation sequence in all three forms (same bits).
 void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
   const Tuning& tu = tuning();
-  if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches (B = 1)
+  if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches
   const int64_t bsD = (int64_t)nb * TILE * TILE;
-  // (on an evaluation slot the other slots' kernels share the chip: the lookahead step's 1024-thread, 150 KB
-  // workgroups would make the update half wait for EMPTY CUs too - the separate launches keep it on 36 KB tiles)
-  if (B > 1 || in_slot || tu.chol_legacy || !tu.chol_lookahead) {
-    potrf_legacy(a, linv, info_dev, B, bsA, bsL, dg);
-    return;
-  }
-  for (int k = 0; k < nb; ++k) {
-    const int rem = nb - 1 - k;
-    if (k > 0) {
-      prof_begin(BOBE_PROF_SYRK);
-      syrk(a, k - 1, k, k, 1, B, bsA);
-      prof_end(BOBE_PROF_SYRK);
-    }
-    const int npanel = rem > 0 ? 2 * rem : 1;                 // 64 rows of the panel per workgroup
-    const int n64 = 2 * rem;
-    const int ntiles = k > 0 ? n64 * (n64 + 1) / 2 : 0;       // per slot
-    const int grid = B * npanel + (B * ntiles + 3) / 4;
-    prof_begin(BOBE_PROF_POTF2);
-    hipLaunchKernelGGL(k_chol_step<false>, dim3(grid), dim3(STEP_THREADS), STEP_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
-                       k, B, npanel, ntiles, info_dev, (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE), dg, bsD,
-                       (unsigned long long*)nullptr);
-    prof_end(BOBE_PROF_POTF2);
-  }
-  hipLaunchKernelGGL(k_copy_diag, dim3(nb, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD, 0);
-  LAUNCH_CHECK();
-}
-
-// panel and update as separate launches (see above)
-void bobe_gp::potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
-  const Tuning& tu = tuning();
-  const int64_t bsD = (int64_t)nb * TILE * TILE;
+  // The one-launch lookahead step is for a LONE factorisation (on an evaluation slot the other slots' kernels share
+  // the chip, and its 1024-thread / 150 KB workgroups would make the update half wait for EMPTY CUs too), and only
+  // for the steps whose update is shorter than the panel chain: its update half runs at 33-36 TFLOP/s against 48 for
+  // the separate launch, which wins from rem ~ 40 blocks up (N = 12288 alone: 35 TFLOP/s with the separate
+  // launches in the early steps, 32 with the lookahead everywhere).
+  const bool can_look = B == 1 && !in_slot && !tu.chol_legacy && tu.chol_lookahead;
+  bool pending = false;                                       // panel k-1 not yet applied right of block column k-1
   int first_aside = nb;                                       // first step whose L_kk was left in the scratch blocks
   for (int k = 0; k < nb; ++k) {
-    const int rem = nb - k - 1;
+    const int rem = nb - 1 - k;
     const int nvalid = (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE);
-    const int npanel = rem > 0 ? 2 * rem : 1;
+    const int npanel = rem > 0 ? 2 * rem : 1;                 // 64 rows of the panel per workgroup
+    if (can_look && rem <= tu.lookahead_max_rem) {
+      if (pending) {
+        prof_begin(BOBE_PROF_SYRK);
+        syrk(a, k - 1, k, k, 1, B, bsA);                      // block column k receives panel k-1
+        prof_end(BOBE_PROF_SYRK);
+      }
+      const int n64 = 2 * rem;
+      const int ntiles = pending ? n64 * (n64 + 1) / 2 : 0;   // rest of the update by panel k-1, beside panel k
+      first_aside = std::min(first_aside, k);
+      prof_begin(BOBE_PROF_POTF2);
+      hipLaunchKernelGGL(k_chol_step<false>, dim3(B * npanel + (B * ntiles + 3) / 4), dim3(STEP_THREADS), STEP_SMEM_BYTES,
+                         stream, a, Np, bsA, linv, Np, bsL, k, B, npanel, ntiles, info_dev, nvalid, dg, bsD,
+                         (unsigned long long*)nullptr);
+      prof_end(BOBE_PROF_POTF2);
+      pending = true;
+      continue;
+    }
+    // panel and update as separate launches
     if (!tu.chol_legacy && B * npanel <= std::max(num_cus, 1)) {
       first_aside = std::min(first_aside, k);
       prof_begin(BOBE_PROF_POTF2);
@@ -519,7 +513,9 @@ void bobe_gp::potrf_legacy(double* a, double* linv, int* info_dev, int B, int64_
       prof_end(BOBE_PROF_SYRK);
     }
   }
-  if (first_aside < nb)    // (B * npanel only shrinks with k: every step from first_aside on took the one-launch panel)
+  // (the scratch blocks of a k_chol_panel / k_chol_step step; k_potf2 steps wrote in place, and come first:
+  // B * npanel and rem only shrink with k)
+  if (first_aside < nb)
     hipLaunchKernelGGL(k_copy_diag, dim3(nb - first_aside, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD,
                        first_aside);
   LAUNCH_CHECK();
