@@ -138,16 +138,17 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, lookahead_max_rem, mll_slots, own_queues, graph_max_n, lockstep_min_n; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, lookahead_max_rem, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 1, 39, 4, 1, 2048, 1024};
+    Tuning v{512, 600, 1200, 0, 1, 39, 300, 4, 1, 2048, 1024};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_CHOL_LEGACY")) v.chol_legacy = std::atoi(e);   // always potf2 / trsm / syrk launches
     if (const char* e = std::getenv("BOBE_CHOL_LOOKAHEAD")) v.chol_lookahead = std::atoi(e);   // 0: no fused step for B = 1
     if (const char* e = std::getenv("BOBE_LOOKAHEAD_MAX_REM")) v.lookahead_max_rem = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_PAIR_MIN")) v.pair_min = std::atoi(e);   // K = 256 update pairs while B*rem^2 > this (0: never)
     if (const char* e = std::getenv("BOBE_LOCKSTEP_MIN_N")) v.lockstep_min_n = std::atoi(e);
     if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
     if (const char* e = std::getenv("BOBE_OWN_QUEUES")) v.own_queues = std::atoi(e);
@@ -489,24 +490,47 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
       continue;
     }
     // panel and update as separate launches
-    if (!tu.chol_legacy && B * npanel <= std::max(num_cus, 1)) {
-      first_aside = std::min(first_aside, k);
-      prof_begin(BOBE_PROF_POTF2);
-      hipLaunchKernelGGL(k_chol_panel<false>, dim3(npanel, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
-                         k, npanel, info_dev, nvalid, dg, bsD, (unsigned long long*)nullptr);
-      prof_end(BOBE_PROF_POTF2);
-    } else {
-      prof_begin(BOBE_PROF_POTF2);
-      hipLaunchKernelGGL((k_potf2<true, false>), dim3(B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, k, info_dev,
-                         (unsigned long long*)nullptr, nvalid, bsA, bsL);
-      prof_end(BOBE_PROF_POTF2);
-      if (rem > 0) {
-        prof_begin(BOBE_PROF_TRSM);
-        hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rem, B), dim3(256), TRSM_SMEM_BYTES, stream, a, Np,
-                           (const double*)linv, Np, k, (unsigned long long*)nullptr, bsA, bsL);
-        prof_end(BOBE_PROF_TRSM);
+    auto panel = [&](int kk) {
+      const int rr = nb - 1 - kk;
+      const int np_ = rr > 0 ? 2 * rr : 1;
+      const int nv = (int)std::min<int64_t>(TILE, N - (int64_t)kk * TILE);
+      if (!tu.chol_legacy && B * np_ <= std::max(num_cus, 1)) {
+        first_aside = std::min(first_aside, kk);
+        prof_begin(BOBE_PROF_POTF2);
+        hipLaunchKernelGGL(k_chol_panel<false>, dim3(np_, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
+                           kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr);
+        prof_end(BOBE_PROF_POTF2);
+      } else {
+        prof_begin(BOBE_PROF_POTF2);
+        hipLaunchKernelGGL((k_potf2<true, false>), dim3(B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, kk,
+                           info_dev, (unsigned long long*)nullptr, nv, bsA, bsL);
+        prof_end(BOBE_PROF_POTF2);
+        if (rr > 0) {
+          prof_begin(BOBE_PROF_TRSM);
+          hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rr, B), dim3(256), TRSM_SMEM_BYTES, stream, a, Np,
+                             (const double*)linv, Np, kk, (unsigned long long*)nullptr, bsA, bsL);
+          prof_end(BOBE_PROF_TRSM);
+        }
       }
+    };
+    // Update-bound steps go in PAIRS: panel k, block column k+1 <- panel k (narrow), panel k+1, then ONE trailing pass
+    // with both panels (K = 256): half the passes over the trailing matrix and a tile kernel that runs 15 % faster at
+    // K = 256 than at 128, for one narrow launch more on the chain.  Same bits (every element still receives panel k
+    // before panel k+1).
+    if (!tu.chol_legacy && tu.pair_min > 0 && rem >= 2 && (int64_t)B * rem * rem > tu.pair_min &&
+        !(can_look && rem - 1 <= tu.lookahead_max_rem)) {
+      panel(k);
+      prof_begin(BOBE_PROF_SYRK);
+      syrk(a, k, k + 1, k + 1, 1, B, bsA);
+      prof_end(BOBE_PROF_SYRK);
+      panel(k + 1);
+      prof_begin(BOBE_PROF_SYRK);
+      syrk(a, k, k + 2, k + 2, 0, B, bsA);
+      prof_end(BOBE_PROF_SYRK);
+      ++k;
+      continue;
     }
+    panel(k);
     if (rem > 0) {
       prof_begin(BOBE_PROF_SYRK);
       syrk(a, k, k + 1, k + 1, 0, B, bsA);
