@@ -449,13 +449,14 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
 //             the diagonal block itself) while all B * 2 * (nb-1-k) workgroups fit on the chip at once, else the
 //             k_potf2 + k_trsm_panel pair (one factorisation per slot).
 //   update    A22 -= L21 L21^T on the lower tiles (k_syrk_trail).
-// A batch shares the latency-bound panel chain (32 x ~40 us at N = 4096, the same for 1 or 8 matrices) and gives the
-// update 4-8x the tiles: 35 % of the fp64 MFMA peak with four in flight, 42 % with eight, against 15 % alone and 22 %
+//             Update-bound steps go in pairs: one K = 256 pass for two panels (see the loop).
+// A batch shares the latency-bound panel chain (32 x ~38 us at N = 4096, the same for 1 or 8 matrices) and gives the
+// update 4-8x the tiles: 38 % of the fp64 MFMA peak with four in flight, 47 % with eight, against 17 % alone and 22 %
 // for four on private streams (whose 150 KB-LDS panel kernels wait for a CU the others' update tiles keep occupied).
-// A LONE factorisation (B = 1) is chain-bound at every step and takes the one-step lookahead form instead:
+// A LONE factorisation (B = 1) takes the one-step lookahead form in its chain-bound steps:
 //   1. k_syrk_trail (colmode 1): block column k receives panel k-1 - the only part of the update panel k waits for;
 //   2. k_chol_step: panel k side by side with the rest of the update by panel k-1, in one launch.
-// Every matrix element sees the same operation sequence in all three forms (same bits).
+// Every matrix element sees the same operation sequence in all forms (same bits).
 void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
   const Tuning& tu = tuning();
   if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches
