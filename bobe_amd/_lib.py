@@ -54,6 +54,8 @@ SIGNATURES = [
     ("bobe_gp_acq_ei", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     ("bobe_gp_predict_grad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    ("bobe_gp_hmc_leapfrog", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                       C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_kernel", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
                                  C.c_double, C.c_int, C.c_void_p]),
     ("bobe_gp_get_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1564,6 +1564,54 @@ int bobe_gp_predict_grad(bobe_gp_t* g, const double* Xq, int64_t C, double* mean
   API_END
 }
 
+int bobe_gp_hmc_leapfrog(bobe_gp_t* g, int64_t P, double* U, double* Pm, const double* inv_mass, double eps, int L,
+                         double y_std, double y_mean, double temp, double* logp, double* grad, double* mean, double* X) {
+  API_BEGIN
+  if (!g || !U || !Pm || !inv_mass || !logp || !grad || !mean || !X) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  if (P <= 0 || L < 1 || !(temp > 0.0)) throw Err(BOBE_ERR_ARG, "bad argument");
+  g->use();
+  const int d = g->d;
+  const size_t pd = (size_t)P * d;
+  // staging: [U | Pm | grad | X] (P*d each), [logp | mean] (P each), inv_mass (d)
+  g->in_stage.ensure((4 * pd + 2 * (size_t)P + d) * sizeof(double));
+  double* dU = g->in_stage.d();
+  double* dP = dU + pd;
+  double* dG = dP + pd;
+  double* dX = dG + pd;
+  double* dL = dX + pd;
+  double* dM = dL + P;
+  double* dI = dM + P;
+  const bool dev = is_device_ptr(U);
+  const hipMemcpyKind in = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const hipMemcpyKind out = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  HIPCHK(hipMemcpyAsync(dU, U, pd * sizeof(double), in, g->stream));
+  HIPCHK(hipMemcpyAsync(dP, Pm, pd * sizeof(double), in, g->stream));
+  HIPCHK(hipMemcpyAsync(dI, inv_mass, (size_t)d * sizeof(double), is_device_ptr(inv_mass) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                        g->stream));
+  const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+#define HL(KE, DC)                                                                                                   \
+  hipLaunchKernelGGL((k_hmc_leapfrog<KE, DC>), dim3((unsigned)P), dim3(256), 0, g->stream, (const double*)g->XsT.d(),   \
+                     g->Np, g->N, (const double*)g->alpha.d(), g->hyp, dU, dP, (const double*)dI, eps, L, y_std, y_mean, \
+                     temp, dL, dG, dM, dX)
+  if (g->hyp.kern == 0) {
+    if (dcap == 8) HL(0, 8); else if (dcap == 16) HL(0, 16); else HL(0, 32);
+  } else {
+    if (dcap == 8) HL(1, 8); else if (dcap == 16) HL(1, 16); else HL(1, 32);
+  }
+#undef HL
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(U, dU, pd * sizeof(double), out, g->stream));
+  HIPCHK(hipMemcpyAsync(Pm, dP, pd * sizeof(double), out, g->stream));
+  HIPCHK(hipMemcpyAsync(grad, dG, pd * sizeof(double), out, g->stream));
+  HIPCHK(hipMemcpyAsync(X, dX, pd * sizeof(double), out, g->stream));
+  HIPCHK(hipMemcpyAsync(logp, dL, (size_t)P * sizeof(double), out, g->stream));
+  HIPCHK(hipMemcpyAsync(mean, dM, (size_t)P * sizeof(double), out, g->stream));
+  g->sync();
+  return BOBE_OK;
+  API_END
+}
+
 int bobe_gp_kernel(bobe_gp_t* g, const double* A, int64_t nA, const double* B, int64_t nB, const double* ls,
                    double kvar, double noise, int include_noise, double* out) {
   API_BEGIN

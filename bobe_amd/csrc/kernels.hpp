@@ -591,6 +591,98 @@ __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__
   }
 }
 
+// ---- Hamiltonian Monte Carlo on the surrogate: L leapfrog steps of every chain in ONE launch ---------------------
+// Consumer of the posterior mean (the reference's NUTS differentiates predict_mean_batched through JAX, one call per
+// step and chain, samplers.py:268-288).  One workgroup = one chain.  Target on u = logit(x), x in the unit cube:
+//   logp(u) = (mean(x) * ystd + ymean) / temp + sum_j [log x_j + log(1 - x_j)]          (Jacobian of the logit map)
+//   g(u)    = dmean/dx * ystd / temp * x (1 - x) + (1 - 2x)
+// with mean(x) = sum_n alpha_n k(x_n, x), dmean/dx_j = sum_n alpha_n G(r2) (s_nj - s_j) / ls_j (k_predict_grad's
+// mean-only arithmetic).  In:  U, Pm = p0 + eps/2 * g(U)  (P x d).  Per step: u += eps * inv_mass * p; evaluate;
+// p += (eps | eps/2 on the last step) * g.  Out: U, Pm (final), logp, grad, mean (physical units), X.
+// Fixed reduction order (4 waves x lanes, then a fixed tree): a chain's trajectory does not depend on the batch.
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_hmc_leapfrog(const double* __restrict__ XsT, int64_t ldx, int64_t n,
+                                                      const double* __restrict__ alpha, Hyper h,
+                                                      double* __restrict__ U, double* __restrict__ Pm,
+                                                      const double* __restrict__ inv_mass, double eps, int L,
+                                                      double ystd, double ymean, double temp,
+                                                      double* __restrict__ logp, double* __restrict__ grad,
+                                                      double* __restrict__ mean_out, double* __restrict__ Xout) {
+  __shared__ double u[DCAP], pm[DCAP], x[DCAP], xs[DCAP], g[DCAP], red[4][DCAP + 1], lp_s, mean_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t c = blockIdx.x;
+  const int d = h.d;
+  if (t < d) {
+    u[t] = U[c * d + t];
+    pm[t] = Pm[c * d + t];
+  }
+  __syncthreads();
+  for (int s = 0; s < L; ++s) {
+    if (t < d) {
+      const double un = u[t] + eps * inv_mass[t] * pm[t];
+      u[t] = un;
+      double xv = 1.0 / (1.0 + exp(-un));
+      xv = xv < 1e-12 ? 1e-12 : (xv > 1.0 - 1e-12 ? 1.0 - 1e-12 : xv);
+      x[t] = xv;
+      xs[t] = xv / h.ls[t];
+    }
+    __syncthreads();
+    double ms = 0.0, gm[DCAP];
+#pragma unroll
+    for (int j = 0; j < DCAP; ++j) gm[j] = 0.0;
+    for (int64_t i = t; i < n; i += 256) {
+      double df[DCAP];
+      double r2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) {
+        df[j] = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
+        r2 += df[j] * df[j];
+      }
+      const double kv = kern_eval<KERN>(r2, h.kvar);
+      const double a = alpha[i];
+      const double ag = a * kern_grad_factor<KERN>(r2, h.kvar, kv);
+      ms += a * kv;
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
+    }
+    ms = wave_sum(ms);
+    if (lane == 0) red[wave][DCAP] = ms;
+#pragma unroll
+    for (int j = 0; j < DCAP; ++j) {
+      if (j < d) {
+        const double v = wave_sum(gm[j]);
+        if (lane == 0) red[wave][j] = v;
+      }
+    }
+    __syncthreads();
+    if (t < d) {
+      const double dm = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) / h.ls[t];
+      const double xv = x[t];
+      const double gv = dm * ystd / temp * (xv * (1.0 - xv)) + (1.0 - 2.0 * xv);
+      g[t] = gv;
+      pm[t] += ((s < L - 1) ? eps : 0.5 * eps) * gv;
+    }
+    if (t == 0) {
+      const double m = (((red[0][DCAP] + red[1][DCAP]) + red[2][DCAP]) + red[3][DCAP]) * ystd + ymean;
+      double jac = 0.0;
+      for (int j = 0; j < d; ++j) jac += log(x[j]) + log1p(-x[j]);
+      mean_s = m;
+      lp_s = m / temp + jac;
+    }
+    __syncthreads();
+  }
+  if (t < d) {
+    U[c * d + t] = u[t];
+    Pm[c * d + t] = pm[t];
+    grad[c * d + t] = g[t];
+    Xout[c * d + t] = x[t];
+  }
+  if (t == 0) {
+    logp[c] = lp_s;
+    mean_out[c] = mean_s;
+  }
+}
+
 // ---- WIPV / WIPStd and their gradients w.r.t. the candidate coordinates ---------------------------------------
 // (what the reference gets from jax.grad of WIPV.fun / WIPStd.fun in the local refinement, acquisition.py:403-412)
 // One workgroup per candidate c.  With s = kself - k_c^T K^-1 k_c, u = K^-1 k_c, W = K^-1 K(X,Z):

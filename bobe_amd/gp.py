@@ -503,6 +503,21 @@ class GP:
                                                   _lib.ptr(dmean), _lib.ptr(dvar)), "bobe_gp_predict_grad")
         return mean, var, dmean, dvar
 
+    def hmc_leapfrog(self, U, Pm, inv_mass, eps: float, L: int, temp: float = 1.0):
+        """``L`` leapfrog steps of P Hamiltonian-Monte-Carlo chains on the surrogate's mean in ONE GPU launch
+        (``bobe_gp_hmc_leapfrog``): U, Pm are (P, d) positions in logit space and momenta (Pm = p0 + eps/2 * grad).
+        Returns (U', Pm', logp, grad, mean (physical units), X')."""
+        U = _lib.as_f64(np.atleast_2d(U)).copy()
+        Pm = _lib.as_f64(np.atleast_2d(Pm)).copy()
+        im = _lib.as_f64(inv_mass).reshape(-1)
+        P = U.shape[0]
+        logp, mean = np.empty(P), np.empty(P)
+        grad, X = np.empty_like(U), np.empty_like(U)
+        _lib.check(self._lib.bobe_gp_hmc_leapfrog(self._h, P, _lib.ptr(U), _lib.ptr(Pm), _lib.ptr(im), float(eps), int(L),
+                                                  float(self.y_std), float(self.y_mean), float(temp), _lib.ptr(logp),
+                                                  _lib.ptr(grad), _lib.ptr(mean), _lib.ptr(X)), "bobe_gp_hmc_leapfrog")
+        return U, Pm, logp, grad, mean, X
+
     def get_random_point(self, rng=None, nstd=None):
         """BOBE/gp.py:578-585."""
         rng = rng if rng is not None else get_numpy_rng()

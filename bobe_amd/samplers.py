@@ -288,8 +288,8 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     ``'best'``, ``'method'``).
 
     Deviation: NumPyro's NUTS (one JAX call per leapfrog step and chain) is replaced by Hamiltonian Monte Carlo run
-    as ONE batch of ``16 * num_chains`` chains: every leapfrog step is a single ``bobe_gp_predict_grad`` call for all
-    chains.  Same stationary distribution; the per-chain length shrinks by the same factor so the number of returned
+    as ONE batch of ``16 * num_chains`` chains: a whole trajectory (4-12 leapfrog steps) of all chains is a single
+    ``bobe_gp_hmc_leapfrog`` launch (gated GPs: one ``bobe_gp_predict_grad`` call per leapfrog step).  Same stationary distribution; the per-chain length shrinks by the same factor so the number of returned
     samples is the reference's.  The cube constraint is handled like NumPyro does it, by sampling u = logit(x) with
     the Jacobian term; step size by dual averaging to 0.8 acceptance and a diagonal mass matrix from the warm-up
     spread of the chains.  Chains start at the best training point and at ``gp.get_random_point`` draws
@@ -305,6 +305,9 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     keep_per_chain = -(-n_keep_total // P)
     base_gp_grad = getattr(gp, "predict_grad")
     gated = hasattr(gp, "use_clf")
+    # a plain GP runs its trajectories on the device (bobe_gp_hmc_leapfrog); the classifier's gate is host code
+    # (scikit-learn), so a gated GP keeps one surrogate call per leapfrog step
+    fused = (not gated) and hasattr(gp, "hmc_leapfrog") and kwargs.get("fused_trajectories", True)
 
     def logp_and_grad(U):
         X = np.clip(expit(U), 1e-12, 1.0 - 1e-12)
@@ -337,11 +340,14 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     for it in range(total):
         L = int(rng.integers(4, 13))
         p0 = rng.normal(size=U.shape) / np.sqrt(inv_mass)
-        Un, pn, gn = U.copy(), p0 + 0.5 * eps * g, g
-        for s in range(L):
-            Un = Un + eps * inv_mass * pn
-            lpn, gn, meann, Xn = logp_and_grad(Un)
-            pn = pn + (eps if s < L - 1 else 0.5 * eps) * gn
+        if fused:                                              # the whole trajectory of every chain in ONE launch
+            Un, pn, lpn, gn, meann, Xn = gp.hmc_leapfrog(U, p0 + 0.5 * eps * g, inv_mass, eps, L, temp)
+        else:
+            Un, pn, gn = U.copy(), p0 + 0.5 * eps * g, g
+            for s in range(L):
+                Un = Un + eps * inv_mass * pn
+                lpn, gn, meann, Xn = logp_and_grad(Un)
+                pn = pn + (eps if s < L - 1 else 0.5 * eps) * gn
         h0 = lp - 0.5 * np.sum(p0 * p0 * inv_mass, axis=1)
         h1 = lpn - 0.5 * np.sum(pn * pn * inv_mass, axis=1)
         with np.errstate(over="ignore", invalid="ignore"):

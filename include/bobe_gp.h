@@ -145,6 +145,15 @@ int bobe_gp_get_chol(bobe_gp_t* gp, double* L, double* alpha);
 /* GP.from_state_dict restore without refactorisation (gp.py:671-675). */
 int bobe_gp_set_chol(bobe_gp_t* gp, const double* L, const double* alpha);
 
+/* Hamiltonian Monte Carlo on the surrogate (the consumer behind sample_GP_NUTS, samplers.py:216-360, whose NUTS calls
+ * the jitted predict_mean once per leapfrog step and chain, samplers.py:268-288): L leapfrog steps of P chains in ONE
+ * launch.  Target on u = logit(x): logp = (mean(x) y_std + y_mean) / temp + sum_j [log x_j + log(1 - x_j)].
+ * In/out: U (P x d positions), Pm (P x d momenta: in = p0 + eps/2 grad(U), out = final momenta); inv_mass (d).
+ * Out: logp (P), grad (P x d, d logp / du at the end point), mean (P, physical units), X (P x d, the end points in
+ * the unit cube).  Host or device pointers (all of one kind). */
+int bobe_gp_hmc_leapfrog(bobe_gp_t* gp, int64_t P, double* U, double* Pm, const double* inv_mass, double eps, int L,
+                         double y_std, double y_mean, double temp, double* logp, double* grad, double* mean, double* X);
+
 /* GP.copy (gp.py:740-750) without leaving the device: dst (created with the same kernel, d and device) receives
  * src's training data, hyper-parameters and factorised state by device-to-device copies - no host round trip of the
  * N x N factor and no refactorisation (the reference copies through state_dict / from_state_dict). */

@@ -78,3 +78,55 @@ def test_hmc_on_the_surrogate_recovers_a_gaussian_posterior():
     assert mc["x"].shape == (256, d)
     pts = get_mc_points(mc, mc_points_size=64, rng=np.random.default_rng(4))
     assert pts.shape == (64, d)
+
+
+def test_fused_hmc_trajectory_equals_the_step_by_step_leapfrog():
+    """bobe_gp_hmc_leapfrog (L leapfrog steps of every chain in one launch) against the same trajectory stepped on the
+    host with one bobe_gp_predict_grad call per step, and against the oracle's posterior mean at the end point."""
+    from scipy.special import expit
+    from bobe_amd import GP
+    from oracle import bobe_oracle as O
+    for kernel, d in (("rbf", 3), ("matern", 5), ("rbf", 10)):
+        rng = np.random.default_rng(d)
+        X = rng.uniform(size=(150, d))
+        y = -20.0 * np.sum((X - 0.45) ** 2, axis=1) + 3.0
+        ls = np.linspace(0.3, 0.8, d)
+        gp = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.7)
+        og = O.OracleGP(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.7)
+        P, L, eps, temp = 7, 9, 0.07, 1.3
+        U = rng.normal(size=(P, d))
+        inv_mass = rng.uniform(0.5, 2.0, size=d)
+
+        def lpg(Uq):
+            Xq = np.clip(expit(Uq), 1e-12, 1 - 1e-12)
+            m, _, dm, _ = gp.predict_grad(Xq, mean_only=True)
+            mean = m * gp.y_std + gp.y_mean
+            return (mean / temp + np.sum(np.log(Xq) + np.log1p(-Xq), axis=1),
+                    dm * gp.y_std / temp * (Xq * (1 - Xq)) + (1 - 2 * Xq), mean, Xq)
+        _, g0, _, _ = lpg(U)
+        p0 = rng.normal(size=(P, d))
+        Un, pn = U.copy(), p0 + 0.5 * eps * g0
+        for s in range(L):
+            Un = Un + eps * inv_mass * pn
+            lpn, gn, meann, Xn = lpg(Un)
+            pn = pn + (eps if s < L - 1 else 0.5 * eps) * gn
+        Uf, pf, lpf, gf, meanf, Xf = gp.hmc_leapfrog(U, p0 + 0.5 * eps * g0, inv_mass, eps, L, temp)
+        assert np.allclose(Uf, Un, rtol=1e-10, atol=1e-10) and np.allclose(pf, pn, rtol=1e-9, atol=1e-9)
+        assert np.allclose(lpf, lpn, rtol=1e-10, atol=1e-9) and np.allclose(gf, gn, rtol=1e-8, atol=1e-8)
+        assert np.allclose(Xf, Xn, rtol=1e-12) and np.allclose(meanf, meann, rtol=1e-10, atol=1e-9)
+        assert np.allclose(meanf, og.predict_mean_batched(Xf), rtol=1e-8, atol=1e-7)
+
+
+def test_hmc_sampler_same_statistics_fused_and_stepwise():
+    from bobe_amd import GP
+    from bobe_amd.samplers import sample_GP_NUTS
+    rng = np.random.default_rng(0)
+    X = rng.uniform(size=(120, 2))
+    y = -0.5 * np.sum(((X - np.array([0.4, 0.6])) / 0.12) ** 2, axis=1)
+    gp = GP(X, y, noise=1e-6, lengthscales=[0.5, 0.5], kernel_variance=50.0)
+    a = sample_GP_NUTS(gp, np_rng=np.random.default_rng(1), warmup_steps=256, num_samples=1024, thinning=2)
+    b = sample_GP_NUTS(gp, np_rng=np.random.default_rng(1), warmup_steps=256, num_samples=1024, thinning=2,
+                       fused_trajectories=False)
+    for s in (a, b):
+        assert np.allclose(s["x"].mean(0), [0.4, 0.6], atol=0.03) and np.allclose(s["x"].std(0), 0.12, atol=0.03)
+    assert a["x"].shape == b["x"].shape

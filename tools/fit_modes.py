@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bobe_amd import GP  # noqa: E402
 from bobe_amd.optim import optimize_scipy  # noqa: E402
 
-for N in (64, 256, 512, 1024, 2048):
+for N in [int(a) for a in sys.argv[1:]] or (64, 256, 512, 1024, 2048):
     rng = np.random.default_rng(0)
     d = 4
     X = rng.uniform(size=(N, d))

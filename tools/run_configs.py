@@ -25,6 +25,10 @@ def rosen10(x):
     return -float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1.0 - x[:-1]) ** 2)) / 20.0
 
 
+if os.environ.get("HMC_STEPWISE"):                      # A/B: one surrogate call per leapfrog step instead of one per trajectory
+    from bobe_amd.gp import GP
+    del GP.hmc_leapfrog
+SEED = int(os.environ.get("SEED", 7))
 which = sys.argv[1:] or ["banana", "himmelblau", "rosen10"]
 if "banana" in which:
     h = HELD["notebook_banana"]
@@ -47,7 +51,7 @@ if "himmelblau" in which:
 if "rosen10" in which:
     t0 = time.time()
     D = 10
-    b = BOBE(rosen10, [f"x{i}" for i in range(D)], np.array([[-2.0, 2.0]] * D).T, n_sobol_init=64, seed=7)
+    b = BOBE(rosen10, [f"x{i}" for i in range(D)], np.array([[-2.0, 2.0]] * D).T, n_sobol_init=64, seed=SEED)
     r = b.run(acq="wipstd", min_evals=150, max_evals=int(os.environ.get("MAX_EVALS", 600)), logz_threshold=0.5, fit_n_points=10,
               ns_n_points=10, batch_size=5, mc_points_size=256, num_hmc_warmup=256, num_hmc_samples=512, do_final_ns=True,
               verbose=True)
