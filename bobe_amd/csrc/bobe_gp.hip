@@ -138,10 +138,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, lookahead_max_rem, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, lookahead_max_rem, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 1, 39, 300, 4, 1, 2048, 1024};
+    Tuning v{512, 600, 1200, 0, 1, 39, 300, 4, 1, 2048, 1024, 1};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -153,9 +153,19 @@ const Tuning& tuning() {
     if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
     if (const char* e = std::getenv("BOBE_OWN_QUEUES")) v.own_queues = std::atoi(e);
     if (const char* e = std::getenv("BOBE_GRAPH_MAX_N")) v.graph_max_n = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_XCD_SHARES")) v.xcd_shares = std::atoi(e);   // 0: row-major tile order on every XCD
     return v;
   }();
   return t;
+}
+
+// Grid of an equal-work tile launch whose workgroups take their tile from xcd_share() (gemm_f64.hpp): `per` logical
+// tiles per XCD, grid = 8 * per.  Small launches keep the plain order (per = 0).
+struct TileGrid { int grid, per; };
+TileGrid tile_grid(int ntiles) {
+  if (!tuning().xcd_shares || ntiles < 256) return {ntiles, 0};
+  const int per = (ntiles + 7) / 8;
+  return {8 * per, per};
 }
 
 }  // namespace
@@ -439,8 +449,9 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
                        colmode, n32, bsA);
     return;
   }
-  hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(t64, B), dim3(256), SYRK64_SMEM, stream, a, Np, k0, k1, first,
-                     colmode, n64, bsA);
+  const TileGrid tg = colmode ? TileGrid{t64, 0} : tile_grid(t64);
+  hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(tg.grid, B), dim3(256), SYRK64_SMEM, stream, a, Np, k0, k1, first,
+                     colmode, n64, bsA, tg.per);
 }
 
 // Blocked right-looking Cholesky (NB = 128) of B matrices in lock step on one stream; every launch carries the slot
@@ -560,10 +571,11 @@ void bobe_gp::trtri(const double* a, double* linv, double* tmp, int B, int64_t b
     // same either way.  Batches keep the per-matrix choice: four in lock step at N = 4096 take 7.0 ms per evaluation
     // round with 64x64 tiles at every level against 7.4 with 128x128 tiles at the top level)
     if (D.nblocks < tu.trtri64_below) {
-      hipLaunchKernelGGL(k_trtri_T<64>, dim3(2 * D.nblocks, B), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
-                         (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT);
-      hipLaunchKernelGGL(k_trtri_R<64>, dim3(2 * D.nblocks, B), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
-                         (const double*)tmp, Np, pr, D.count, bsL, bsT);
+      const TileGrid tg = tile_grid(2 * D.nblocks);         // (tile pairs of complementary K: equal work)
+      hipLaunchKernelGGL(k_trtri_T<64>, dim3(tg.grid, B), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
+                         (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT, tg.per);
+      hipLaunchKernelGGL(k_trtri_R<64>, dim3(tg.grid, B), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
+                         (const double*)tmp, Np, pr, D.count, bsL, bsT, tg.per);
     } else {
       hipLaunchKernelGGL(k_trtri_T<128>, dim3(D.nblocks, B), dim3(256), GEMM_SMEM_BYTES, stream, a, Np,
                          (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT);

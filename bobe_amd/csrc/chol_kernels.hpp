@@ -598,12 +598,18 @@ __global__ __launch_bounds__(STEP_THREADS) void k_chol_step(double* __restrict__
 // tile columns b < 128/T, rows b <= a < n, grid = S n - S(S-1)/2 with S = 128/T.
 template <int T, int BK>
 __global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k0, int k1, int first,
-                                                    int colmode, int n, int64_t bsA = 0) {
+                                                    int colmode, int n, int64_t bsA = 0, int per = 0) {
   extern __shared__ double smem[];
   A += blockIdx.y * bsA;
   int a, b;
   if (colmode == 0) {
-    tri_decode(blockIdx.x, a, b);
+    if (per > 0) {                                        // one contiguous share of 8 x 8 tile groups per XCD
+      const int t = xcd_share(blockIdx.x, per);
+      if (t >= n * (n + 1) / 2) return;
+      tri_grouped(t, n, a, b);
+    } else {
+      tri_decode(blockIdx.x, a, b);
+    }
   } else {
     constexpr int S = TILE / T;
     int idx = blockIdx.x;
@@ -658,18 +664,23 @@ __global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L
                                                     const double* __restrict__ Linv, int64_t ldi,
                                                     double* __restrict__ Tmp, int64_t ldt,
                                                     const TriProb* __restrict__ probs, int nprob, int64_t bsA = 0,
-                                                    int64_t bsL = 0, int64_t bsT = 0) {
+                                                    int64_t bsL = 0, int64_t bsT = 0, int per = 0) {
   extern __shared__ double smem[];
   L += blockIdx.y * bsA;
   Linv += blockIdx.y * bsL;
   Tmp += blockIdx.y * bsT;
   TriProb p;
   int e[2];
-  if (!tri_find<T>(probs, nprob, blockIdx.x, p, e[0], e[1])) return;
-  const int rows = (p.hi - p.mid) * (TILE / T);
+  if (!tri_find<T>(probs, nprob, xcd_share(blockIdx.x, per), p, e[0], e[1])) return;
+  const int rows = (p.hi - p.mid) * (TILE / T), w = (p.mid - p.lo) * (TILE / T);
   for (int u = 0; u < 2; ++u) {
     if (e[u] < 0) continue;
-    const int tj = e[u] / rows, ti = e[u] % rows;          // column-major: small tj (long K) first
+    int ti, tj;
+    if (per > 0) {
+      rect_grouped(e[u], w, rows, tj, ti);                 // bands of 8 tile columns: small tj (long K) first
+    } else {
+      tj = e[u] / rows, ti = e[u] % rows;                  // column-major: small tj (long K) first
+    }
     const int64_t m0 = (int64_t)p.mid * TILE + (int64_t)ti * T, n0 = (int64_t)p.lo * TILE + (int64_t)tj * T;
     v4d acc[T / 32][T / 32];
     acc_zero(acc);
@@ -682,17 +693,23 @@ template <int T>
 __global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, int64_t ldi,
                                                     const double* __restrict__ Tmp, int64_t ldt,
                                                     const TriProb* __restrict__ probs, int nprob, int64_t bsL = 0,
-                                                    int64_t bsT = 0) {
+                                                    int64_t bsT = 0, int per = 0) {
   extern __shared__ double smem[];
   Linv += blockIdx.y * bsL;
   Tmp += blockIdx.y * bsT;
   TriProb p;
   int e[2];
-  if (!tri_find<T>(probs, nprob, blockIdx.x, p, e[0], e[1])) return;
+  if (!tri_find<T>(probs, nprob, xcd_share(blockIdx.x, per), p, e[0], e[1])) return;
   const int rows = (p.hi - p.mid) * (TILE / T), w = (p.mid - p.lo) * (TILE / T);
   for (int u = 0; u < 2; ++u) {
     if (e[u] < 0) continue;
-    const int ti = rows - 1 - e[u] / w, tj = e[u] % w;     // bottom rows (long K) first
+    int ti, tj;
+    if (per > 0) {
+      rect_grouped(e[u], rows, w, ti, tj);                 // bands of 8 tile rows: bottom rows (long K) first
+      ti = rows - 1 - ti;
+    } else {
+      ti = rows - 1 - e[u] / w, tj = e[u] % w;             // bottom rows (long K) first
+    }
     const int64_t m0 = (int64_t)p.mid * TILE + (int64_t)ti * T, n0 = (int64_t)p.lo * TILE + (int64_t)tj * T;
     v4d acc[T / 32][T / 32];
     acc_zero(acc);
