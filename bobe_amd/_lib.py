@@ -56,6 +56,9 @@ SIGNATURES = [
                                        C.c_void_p]),
     ("bobe_gp_hmc_leapfrog", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                        C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("bobe_gp_hmc_run", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int,
+                                  C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p]),
     ("bobe_gp_kernel", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
                                  C.c_double, C.c_int, C.c_void_p]),
     ("bobe_gp_get_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1624,6 +1624,54 @@ int bobe_gp_hmc_leapfrog(bobe_gp_t* g, int64_t P, double* U, double* Pm, const d
   API_END
 }
 
+int bobe_gp_hmc_run(bobe_gp_t* g, int64_t P, double* state, double* adapt, const double* inv_mass, uint64_t seed,
+                    int64_t it0, int niter, int do_adapt, double y_std, double y_mean, double temp, int hist_from,
+                    double* hist, int thin, double* keep, double* dbg) {
+  API_BEGIN
+  if (!g || !state || !adapt || !inv_mass) throw Err(BOBE_ERR_ARG, "NULL argument");
+  if (!g->factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  if (P <= 0 || niter < 1 || it0 < 0 || !(temp > 0.0) || thin < 1 || hist_from < 0 || hist_from > niter)
+    throw Err(BOBE_ERR_ARG, "bad argument");
+  g->use();
+  const int d = g->d;
+  const size_t sw = 3 * (size_t)d + 2, ns = (size_t)P * sw, na = (size_t)P * 5;
+  const size_t nh = hist ? (size_t)(niter - hist_from) * P * d : 0;
+  const size_t nk = keep ? (size_t)(niter / thin) * P * (d + 1) : 0;
+  const size_t nd = dbg ? (size_t)P * (d + 3) : 0;
+  // staging: state | adapt | inv_mass | hist | keep | dbg
+  g->in_stage.ensure((ns + na + d + nh + nk + nd) * sizeof(double));
+  double* dS = g->in_stage.d();
+  double* dA = dS + ns;
+  double* dI = dA + na;
+  double* dH = dI + d;
+  double* dK = dH + nh;
+  double* dD = dK + nk;
+  HIPCHK(hipMemcpyAsync(dS, state, ns * sizeof(double), hipMemcpyHostToDevice, g->stream));
+  HIPCHK(hipMemcpyAsync(dA, adapt, na * sizeof(double), hipMemcpyHostToDevice, g->stream));
+  HIPCHK(hipMemcpyAsync(dI, inv_mass, (size_t)d * sizeof(double), hipMemcpyHostToDevice, g->stream));
+  const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+#define HR(KE, DC)                                                                                                  \
+  hipLaunchKernelGGL((k_hmc_run<KE, DC>), dim3((unsigned)P), dim3(256), 0, g->stream, (const double*)g->XsT.d(), g->Np, \
+                     g->N, (const double*)g->alpha.d(), g->hyp, P, dS, dA, (const double*)dI,                       \
+                     (unsigned long long)seed, it0, niter, do_adapt, y_std, y_mean, temp, hist_from,                \
+                     hist ? dH : nullptr, thin, keep ? dK : nullptr, dbg ? dD : nullptr)
+  if (g->hyp.kern == 0) {
+    if (dcap == 8) HR(0, 8); else if (dcap == 16) HR(0, 16); else HR(0, 32);
+  } else {
+    if (dcap == 8) HR(1, 8); else if (dcap == 16) HR(1, 16); else HR(1, 32);
+  }
+#undef HR
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(state, dS, ns * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  HIPCHK(hipMemcpyAsync(adapt, dA, na * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  if (hist) HIPCHK(hipMemcpyAsync(hist, dH, nh * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  if (keep) HIPCHK(hipMemcpyAsync(keep, dK, nk * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  if (dbg) HIPCHK(hipMemcpyAsync(dbg, dD, nd * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  g->sync();
+  return BOBE_OK;
+  API_END
+}
+
 int bobe_gp_kernel(bobe_gp_t* g, const double* A, int64_t nA, const double* B, int64_t nB, const double* ls,
                    double kvar, double noise, int include_noise, double* out) {
   API_BEGIN

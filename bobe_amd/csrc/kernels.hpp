@@ -683,6 +683,186 @@ __global__ __launch_bounds__(256) void k_hmc_leapfrog(const double* __restrict__
   }
 }
 
+// ---- whole HMC chains on the device ---------------------------------------------------------------------------
+// `niter` trajectories of every chain in ONE launch (one workgroup = one chain): momentum draw, 4-12 leapfrog steps (the
+// arithmetic of k_hmc_leapfrog), Metropolis test, and - while warming up - the chain's own dual-averaging step-size
+// update (Hoffman & Gelman 2014, what NumPyro's warm-up does per chain).  The host only cuts the run at the
+// mass-matrix windows.  Random numbers are a counter hash (splitmix64 finaliser) of (seed, chain, iteration, index):
+// a chain's path depends on nothing but its own seed, whatever the batch or the launch boundaries.
+//   S     [P][3d+2]  chain state in/out: u (d), g = dlogp/du (d), x (d), logp, mean (physical units)
+//   adapt [P][5]     eps, mu, hbar, log_eps_bar, m (dual averaging; only eps is read when do_adapt == 0)
+//   hist  [niter - hist_from][P][d]   u after iterations >= hist_from of this launch        (may be null)
+//   keep  [niter / thin][P][d+1]      x and mean after every thin-th iteration of this launch (may be null)
+//   dbg   [P][d+3]   last iteration's p0 (d), L, uniform, acceptance probability             (may be null)
+__device__ __forceinline__ unsigned long long hmc_mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ double hmc_u01(unsigned long long bits) {          // in (0, 1)
+  return ((double)(bits >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT, int64_t ldx, int64_t n,
+                                                 const double* __restrict__ alpha, Hyper h, int64_t P,
+                                                 double* __restrict__ S, double* __restrict__ adapt,
+                                                 const double* __restrict__ inv_mass, unsigned long long seed,
+                                                 int64_t it0, int niter, int do_adapt, double ystd, double ymean,
+                                                 double temp, int hist_from, double* __restrict__ hist, int thin,
+                                                 double* __restrict__ keep, double* __restrict__ dbg) {
+  __shared__ double u[DCAP], pm[DCAP], x[DCAP], xs[DCAP], g[DCAP], red[4][DCAP + 1], lp_s, mean_s;
+  __shared__ double u0[DCAP], g0[DCAP], x0[DCAP], p0[DCAP], im[DCAP], lp0, mean0, eps_s;
+  __shared__ int L_s, acc_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t c = blockIdx.x;
+  const int d = h.d, sw = 3 * d + 2;
+  double* Sc = S + c * sw;
+  double* ad = adapt + c * 5;
+  if (t < d) {
+    u0[t] = Sc[t];
+    g0[t] = Sc[d + t];
+    x0[t] = Sc[2 * d + t];
+    im[t] = inv_mass[t];
+  }
+  if (t == 0) {
+    lp0 = Sc[3 * d];
+    mean0 = Sc[3 * d + 1];
+    eps_s = ad[0];
+  }
+  const unsigned long long ckey = hmc_mix64(seed ^ hmc_mix64((unsigned long long)c));
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    const unsigned long long ikey = ckey + ((unsigned long long)(it0 + it) << 12);
+    const double eps = eps_s;
+    if (t < d) {                                               // momentum ~ N(0, M), M = diag(1 / inv_mass)
+      const double a = hmc_u01(hmc_mix64(ikey + 2 * t)), b = hmc_u01(hmc_mix64(ikey + 2 * t + 1));
+      const double z = sqrt(-2.0 * log(a)) * cos(6.283185307179586 * b);
+      const double pv = z / sqrt(im[t]);
+      p0[t] = pv;
+      pm[t] = pv + 0.5 * eps * g0[t];
+      u[t] = u0[t];
+    }
+    if (t == 0) L_s = 4 + (int)(hmc_mix64(ikey + 4000) % 9ull);
+    __syncthreads();
+    const int L = L_s;
+    for (int s = 0; s < L; ++s) {
+      if (t < d) {
+        const double un = u[t] + eps * im[t] * pm[t];
+        u[t] = un;
+        double xv = 1.0 / (1.0 + exp(-un));
+        xv = xv < 1e-12 ? 1e-12 : (xv > 1.0 - 1e-12 ? 1.0 - 1e-12 : xv);
+        x[t] = xv;
+        xs[t] = xv / h.ls[t];
+      }
+      __syncthreads();
+      double ms = 0.0, gm[DCAP];
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) gm[j] = 0.0;
+      for (int64_t i = t; i < n; i += 256) {
+        double df[DCAP];
+        double r2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < DCAP; ++j) {
+          df[j] = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
+          r2 += df[j] * df[j];
+        }
+        const double kv = kern_eval<KERN>(r2, h.kvar);
+        const double a = alpha[i];
+        const double ag = a * kern_grad_factor<KERN>(r2, h.kvar, kv);
+        ms += a * kv;
+#pragma unroll
+        for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
+      }
+      ms = wave_sum(ms);
+      if (lane == 0) red[wave][DCAP] = ms;
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) {
+        if (j < d) {
+          const double v = wave_sum(gm[j]);
+          if (lane == 0) red[wave][j] = v;
+        }
+      }
+      __syncthreads();
+      if (t < d) {
+        const double dm = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) / h.ls[t];
+        const double xv = x[t];
+        const double gv = dm * ystd / temp * (xv * (1.0 - xv)) + (1.0 - 2.0 * xv);
+        g[t] = gv;
+        pm[t] += ((s < L - 1) ? eps : 0.5 * eps) * gv;
+      }
+      if (t == 0) {
+        const double m = (((red[0][DCAP] + red[1][DCAP]) + red[2][DCAP]) + red[3][DCAP]) * ystd + ymean;
+        double jac = 0.0;
+        for (int j = 0; j < d; ++j) jac += log(x[j]) + log1p(-x[j]);
+        mean_s = m;
+        lp_s = m / temp + jac;
+      }
+      __syncthreads();
+    }
+    if (t == 0) {                                              // Metropolis test and the chain's step-size update
+      double k0 = 0.0, k1 = 0.0;
+      for (int j = 0; j < d; ++j) {
+        k0 += p0[j] * p0[j] * im[j];
+        k1 += pm[j] * pm[j] * im[j];
+      }
+      const double h0 = lp0 - 0.5 * k0, h1 = lp_s - 0.5 * k1;
+      double ap = 0.0;
+      if (isfinite(h1)) ap = h1 >= h0 ? 1.0 : exp(h1 - h0);
+      const double r = hmc_u01(hmc_mix64(ikey + 4001));
+      const int acc = r < ap;
+      acc_s = acc;
+      if (acc) {
+        lp0 = lp_s;
+        mean0 = mean_s;
+      }
+      if (do_adapt) {
+        constexpr double t0 = 10.0, gamma = 0.05, kappa = 0.75, target = 0.8;
+        const double m = ad[4] + 1.0;
+        const double hbar = (1.0 - 1.0 / (m + t0)) * ad[2] + (target - ap) / (m + t0);
+        const double le = ad[1] - sqrt(m) / gamma * hbar;
+        const double eta = pow(m, -kappa);
+        ad[2] = hbar;
+        ad[3] = eta * le + (1.0 - eta) * ad[3];
+        ad[4] = m;
+        double e = exp(le);
+        e = e < 1e-4 ? 1e-4 : (e > 2.0 ? 2.0 : e);
+        ad[0] = e;
+        eps_s = e;
+      }
+      if (dbg && it == niter - 1) {
+        double* dc = dbg + c * (d + 3);
+        for (int j = 0; j < d; ++j) dc[j] = p0[j];
+        dc[d] = (double)L;
+        dc[d + 1] = r;
+        dc[d + 2] = ap;
+      }
+    }
+    __syncthreads();
+    if (t < d) {
+      if (acc_s) {
+        u0[t] = u[t];
+        g0[t] = g[t];
+        x0[t] = x[t];
+      }
+      if (hist && it >= hist_from) hist[((int64_t)(it - hist_from) * P + c) * d + t] = u0[t];
+      if (keep && (it + 1) % thin == 0) keep[((int64_t)((it + 1) / thin - 1) * P + c) * (d + 1) + t] = x0[t];
+    }
+    if (t == 0 && keep && (it + 1) % thin == 0) keep[((int64_t)((it + 1) / thin - 1) * P + c) * (d + 1) + d] = mean0;
+    __syncthreads();
+  }
+  if (t < d) {
+    Sc[t] = u0[t];
+    Sc[d + t] = g0[t];
+    Sc[2 * d + t] = x0[t];
+  }
+  if (t == 0) {
+    Sc[3 * d] = lp0;
+    Sc[3 * d + 1] = mean0;
+  }
+}
+
 // ---- WIPV / WIPStd and their gradients w.r.t. the candidate coordinates ---------------------------------------
 // (what the reference gets from jax.grad of WIPV.fun / WIPStd.fun in the local refinement, acquisition.py:403-412)
 // One workgroup per candidate c.  With s = kself - k_c^T K^-1 k_c, u = K^-1 k_c, W = K^-1 K(X,Z):

@@ -518,6 +518,26 @@ class GP:
                                                   _lib.ptr(grad), _lib.ptr(mean), _lib.ptr(X)), "bobe_gp_hmc_leapfrog")
         return U, Pm, logp, grad, mean, X
 
+    def hmc_run(self, state, adapt, inv_mass, seed: int, it0: int, niter: int, do_adapt: bool, temp: float = 1.0,
+                hist_from: Optional[int] = None, thin: int = 0, debug: bool = False):
+        """``niter`` whole HMC trajectories of every chain in ONE GPU launch (``bobe_gp_hmc_run``): ``state`` (P, 3d+2) =
+        [u, dlogp/du, x, logp, mean] and ``adapt`` (P, 5) = [eps, mu, hbar, log_eps_bar, m] are updated in place.
+        Returns (hist, keep, dbg): u after the iterations >= ``hist_from`` (niter - hist_from, P, d), [x, mean] after
+        every ``thin``-th iteration (niter // thin, P, d+1), and the last iteration's draws (P, d+3) - each None
+        unless asked for."""
+        P, d = state.shape[0], self.ndim
+        assert state.shape == (P, 3 * d + 2) and adapt.shape == (P, 5) and state.flags.c_contiguous and adapt.flags.c_contiguous
+        im = _lib.as_f64(inv_mass).reshape(-1)
+        hist = np.empty((niter - hist_from, P, d)) if hist_from is not None else None
+        keep = np.empty((niter // thin, P, d + 1)) if thin else None
+        dbg = np.empty((P, d + 3)) if debug else None
+        _lib.check(self._lib.bobe_gp_hmc_run(self._h, P, _lib.ptr(state), _lib.ptr(adapt), _lib.ptr(im), int(seed), int(it0),
+                                             int(niter), int(bool(do_adapt)), float(self.y_std), float(self.y_mean), float(temp),
+                                             int(hist_from or 0), _lib.ptr(hist) if hist is not None else None,
+                                             int(thin) if thin else 1, _lib.ptr(keep) if keep is not None else None,
+                                             _lib.ptr(dbg) if dbg is not None else None), "bobe_gp_hmc_run")
+        return hist, keep, dbg
+
     def get_random_point(self, rng=None, nstd=None):
         """BOBE/gp.py:578-585."""
         rng = rng if rng is not None else get_numpy_rng()

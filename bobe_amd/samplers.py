@@ -288,8 +288,10 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     ``'best'``, ``'method'``).
 
     Deviation: NumPyro's NUTS (one JAX call per leapfrog step and chain) is replaced by Hamiltonian Monte Carlo run
-    as ONE batch of ``16 * num_chains`` chains: a whole trajectory (4-12 leapfrog steps) of all chains is a single
-    ``bobe_gp_hmc_leapfrog`` launch (gated GPs: one ``bobe_gp_predict_grad`` call per leapfrog step).  Same stationary distribution; the per-chain length shrinks by the same factor so the number of returned
+    as ONE batch of ``16 * num_chains`` chains that live on the device: a warm-up window or the whole sampling phase
+    (momentum draws, 4-12 leapfrog steps per trajectory, Metropolis tests, per-chain step-size adaptation) is a single
+    ``bobe_gp_hmc_run`` launch; ``device_chains=False`` steps trajectory by trajectory from the host
+    (``bobe_gp_hmc_leapfrog``), and a classifier-gated GP calls ``bobe_gp_predict_grad`` once per leapfrog step.  Same stationary distribution; the per-chain length shrinks by the same factor so the number of returned
     samples is the reference's.  The cube constraint is handled like NumPyro does it, by sampling u = logit(x) with
     the Jacobian term; step size by dual averaging to 0.8 acceptance and a diagonal mass matrix from the warm-up
     spread of the chains.  Chains start at the best training point and at ``gp.get_random_point`` draws
@@ -308,6 +310,7 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     # a plain GP runs its trajectories on the device (bobe_gp_hmc_leapfrog); the classifier's gate is host code
     # (scikit-learn), so a gated GP keeps one surrogate call per leapfrog step
     fused = (not gated) and hasattr(gp, "hmc_leapfrog") and kwargs.get("fused_trajectories", True)
+    on_device = fused and hasattr(gp, "hmc_run") and kwargs.get("device_chains", True)
 
     def logp_and_grad(U):
         X = np.clip(expit(U), 1e-12, 1.0 - 1e-12)
@@ -331,12 +334,39 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     U = np.log(inits) - np.log1p(-inits)
     lp, g, mean, X = logp_and_grad(U)
     inv_mass = np.ones(d)
+    total = warmup_steps + keep_per_chain * thinning
+    if on_device:
+        # Whole chains on the device (bobe_gp_hmc_run): the host only cuts the warm-up at the mass-matrix windows and
+        # pools the chains' spread there; every chain adapts its OWN step size (NumPyro does the same per chain).
+        state = np.ascontiguousarray(np.concatenate([U, g, X, lp[:, None], mean[:, None]], axis=1))
+        adapt = np.tile(np.array([0.1, math.log(1.0), 0.0, 0.0, 0.0]), (P, 1))
+        seed = int(rng.integers(0, 2 ** 62))
+        cuts = sorted({int(warmup_steps * f) for f in (0.25, 0.5, 0.75)} | {warmup_steps})
+        it = 0
+        for cut in cuts:
+            n_it = cut - it
+            if n_it <= 0:
+                continue
+            last = cut == warmup_steps
+            hist, _, _ = gp.hmc_run(state, adapt, inv_mass, seed, it, n_it, True, temp,
+                                    hist_from=None if last else n_it // 2)
+            it = cut
+            if not last:                                       # mass matrix from the spread of the batch
+                inv_mass = np.var(hist.reshape(-1, d), axis=0) + 1e-3
+                adapt[:, 1] = np.log(10.0 * adapt[:, 0])
+                adapt[:, 2] = 0.0
+                adapt[:, 3] = 0.0
+        if warmup_steps > 0:                                   # the averaged step size of the warm-up
+            adapt[:, 0] = np.where(adapt[:, 3] != 0.0, np.clip(np.exp(adapt[:, 3]), 1e-4, 2.0), adapt[:, 0])
+        _, keep, _ = gp.hmc_run(state, adapt, inv_mass, seed, it, keep_per_chain * thinning, False, temp, thin=thinning)
+        samples_x = keep[:, :, :d].reshape(-1, d)[:n_keep_total]
+        logps = keep[:, :, d].reshape(-1)[:n_keep_total]
+        return {"x": samples_x, "logp": logps, "best": samples_x[int(np.argmax(logps))], "method": "MCMC"}
     # dual averaging (Hoffman & Gelman 2014, as NumPyro's warm-up does) on one step size shared by the batch
     eps, mu, hbar, log_eps_bar, t0, gamma, kappa, target = 0.1, math.log(1.0), 0.0, 0.0, 10.0, 0.05, 0.75, 0.8
     windows = {int(warmup_steps * f) for f in (0.25, 0.5, 0.75)}
     recent = []
     xs, lps = [], []
-    total = warmup_steps + keep_per_chain * thinning
     for it in range(total):
         L = int(rng.integers(4, 13))
         p0 = rng.normal(size=U.shape) / np.sqrt(inv_mass)

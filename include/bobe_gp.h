@@ -154,6 +154,19 @@ int bobe_gp_set_chol(bobe_gp_t* gp, const double* L, const double* alpha);
 int bobe_gp_hmc_leapfrog(bobe_gp_t* gp, int64_t P, double* U, double* Pm, const double* inv_mass, double eps, int L,
                          double y_std, double y_mean, double temp, double* logp, double* grad, double* mean, double* X);
 
+/* Whole HMC chains on the device: `niter` trajectories (momentum draw, 4-12 leapfrog steps, Metropolis test and - with
+ * do_adapt - the chain's own dual-averaging step-size update) of P chains in ONE launch.  Replaces the per-step JAX
+ * calls of NumPyro's NUTS in sample_GP_NUTS (BOBE/samplers.py:216-360) for a plain GP.  All pointers are HOST memory.
+ *   state [P][3d+2]  in/out: u = logit(x) (d), dlogp/du (d), x (d), logp, mean (physical units)
+ *   adapt [P][5]     in/out: eps, mu, hbar, log_eps_bar, m
+ *   hist  [niter - hist_from][P][d]  u after the iterations >= hist_from of this call (NULL: not recorded)
+ *   keep  [niter / thin][P][d+1]     x and mean after every thin-th iteration of this call (NULL: not recorded)
+ *   dbg   [P][d+3]   the last iteration's momentum draw, L, uniform and acceptance probability (NULL; tests replay it)
+ * Random numbers are a counter hash of (seed, chain, it0 + iteration, index).  */
+int bobe_gp_hmc_run(bobe_gp_t* g, int64_t P, double* state, double* adapt, const double* inv_mass, uint64_t seed,
+                    int64_t it0, int niter, int do_adapt, double y_std, double y_mean, double temp, int hist_from,
+                    double* hist, int thin, double* keep, double* dbg);
+
 /* GP.copy (gp.py:740-750) without leaving the device: dst (created with the same kernel, d and device) receives
  * src's training data, hyper-parameters and factorised state by device-to-device copies - no host round trip of the
  * N x N factor and no refactorisation (the reference copies through state_dict / from_state_dict). */

@@ -127,6 +127,82 @@ def test_hmc_sampler_same_statistics_fused_and_stepwise():
     a = sample_GP_NUTS(gp, np_rng=np.random.default_rng(1), warmup_steps=256, num_samples=1024, thinning=2)
     b = sample_GP_NUTS(gp, np_rng=np.random.default_rng(1), warmup_steps=256, num_samples=1024, thinning=2,
                        fused_trajectories=False)
-    for s in (a, b):
+    c = sample_GP_NUTS(gp, np_rng=np.random.default_rng(1), warmup_steps=256, num_samples=1024, thinning=2,
+                       device_chains=False)
+    for s in (a, b, c):                  # chains on the device / one call per leapfrog step / one call per trajectory
         assert np.allclose(s["x"].mean(0), [0.4, 0.6], atol=0.03) and np.allclose(s["x"].std(0), 0.12, atol=0.03)
-    assert a["x"].shape == b["x"].shape
+        assert np.all(np.isfinite(s["logp"])) and s["best"].shape == (2,)
+    assert a["x"].shape == b["x"].shape == c["x"].shape
+    a2 = sample_GP_NUTS(gp, np_rng=np.random.default_rng(1), warmup_steps=256, num_samples=1024, thinning=2)
+    assert np.array_equal(a["x"], a2["x"])                       # same seed, same chains
+
+
+def _hmc_state(gp, U, temp):
+    from scipy.special import expit
+    X = np.clip(expit(U), 1e-12, 1 - 1e-12)
+    m, _, dm, _ = gp.predict_grad(X, mean_only=True)
+    mean = m * gp.y_std + gp.y_mean
+    lp = mean / temp + np.sum(np.log(X) + np.log1p(-X), axis=1)
+    g = dm * gp.y_std / temp * (X * (1 - X)) + (1 - 2 * X)
+    return np.ascontiguousarray(np.concatenate([U, g, X, lp[:, None], mean[:, None]], axis=1))
+
+
+def test_device_chain_iteration_replayed_on_the_host():
+    """One iteration of bobe_gp_hmc_run with its draws (momentum, L, uniform) read back: the same trajectory through
+    bobe_gp_hmc_leapfrog and the Metropolis rule on the host must give the same acceptance probability and the same
+    next state.  Then: launch boundaries and batch size do not change a chain (counter-based random numbers)."""
+    from bobe_amd import GP
+    for kernel, d in (("rbf", 2), ("matern", 6), ("rbf", 12)):
+        rng = np.random.default_rng(10 + d)
+        X = rng.uniform(size=(200, d))
+        y = -15.0 * np.sum((X - 0.5) ** 2, axis=1)
+        gp = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=np.linspace(0.4, 0.9, d), kernel_variance=2.0)
+        P, temp, eps = 24, 1.0, 0.05
+        inv_mass = rng.uniform(0.5, 2.0, size=d)
+        U0 = rng.normal(scale=0.5, size=(P, d))
+        st = _hmc_state(gp, U0, temp)
+        st0 = st.copy()
+        adapt = np.tile(np.array([eps, 0.0, 0.0, 0.0, 0.0]), (P, 1))
+        _, _, dbg = gp.hmc_run(st, adapt, inv_mass, seed=1234, it0=7, niter=1, do_adapt=False, temp=temp, debug=True)
+        p0, L, r, ap = dbg[:, :d], dbg[:, d].astype(int), dbg[:, d + 1], dbg[:, d + 2]
+        assert np.all((L >= 4) & (L <= 12)) and np.all((r > 0) & (r < 1))
+        g0, lp0 = st0[:, d:2 * d], st0[:, 3 * d]
+        for c in range(P):
+            Un, pn, lpn, gn, meann, Xn = gp.hmc_leapfrog(U0[c:c + 1], p0[c:c + 1] + 0.5 * eps * g0[c:c + 1], inv_mass, eps,
+                                                         int(L[c]), temp)
+            h0 = lp0[c] - 0.5 * np.sum(p0[c] ** 2 * inv_mass)
+            h1 = lpn[0] - 0.5 * np.sum(pn[0] ** 2 * inv_mass)
+            ap_host = min(1.0, np.exp(h1 - h0)) if np.isfinite(h1) else 0.0
+            assert ap[c] == pytest.approx(ap_host, rel=1e-9, abs=1e-12)
+            want = np.concatenate([Un[0], gn[0], Xn[0], lpn, meann]) if r[c] < ap[c] else st0[c]
+            assert np.allclose(st[c], want, rtol=1e-10, atol=1e-10)
+        assert np.array_equal(adapt[:, 0], np.full(P, eps))                     # no adaptation asked for
+        # 5 iterations in one launch == 3 + 2 in two launches == the first 8 chains alone
+        a, b, c8 = st0.copy(), st0.copy(), st0[:8].copy()
+        ad = lambda n: np.tile(np.array([eps, 0.0, 0.0, 0.0, 0.0]), (n, 1))
+        aa, ab, ac = ad(P), ad(P), ad(8)
+        gp.hmc_run(a, aa, inv_mass, 99, 0, 5, True, temp)
+        gp.hmc_run(b, ab, inv_mass, 99, 0, 3, True, temp)
+        gp.hmc_run(b, ab, inv_mass, 99, 3, 2, True, temp)
+        gp.hmc_run(c8, ac, inv_mass, 99, 0, 5, True, temp)
+        assert np.array_equal(a, b) and np.array_equal(aa, ab) and np.array_equal(a[:8], c8) and np.array_equal(aa[:8], ac)
+        assert np.all(aa[:, 4] == 5) and not np.array_equal(aa[:, 0], np.full(P, eps))   # every chain adapted its step
+
+
+def test_device_chain_random_numbers():
+    """Momentum draws ~ N(0, 1 / inv_mass), trajectory lengths uniform on 4..12, Metropolis uniforms uniform."""
+    from bobe_amd import GP
+    rng = np.random.default_rng(3)
+    d, P = 4, 4096
+    X = rng.uniform(size=(50, d))
+    gp = GP(X, -np.sum((X - 0.5) ** 2, axis=1), noise=1e-6, lengthscales=np.full(d, 0.7))
+    inv_mass = np.array([0.5, 1.0, 2.0, 4.0])
+    st = _hmc_state(gp, rng.normal(scale=0.3, size=(P, d)), 1.0)
+    adapt = np.tile(np.array([0.05, 0.0, 0.0, 0.0, 0.0]), (P, 1))
+    _, _, dbg = gp.hmc_run(st, adapt, inv_mass, seed=5, it0=0, niter=1, do_adapt=False, debug=True)
+    p0, L, r = dbg[:, :d], dbg[:, d], dbg[:, d + 1]
+    assert np.allclose(p0.mean(0), 0.0, atol=0.08) and np.allclose(p0.var(0) * inv_mass, 1.0, atol=0.08)
+    assert abs(np.corrcoef(p0[:, 0], p0[:, 1])[0, 1]) < 0.05 and abs(np.corrcoef(p0[:-1, 0], p0[1:, 0])[0, 1]) < 0.05
+    counts = np.bincount(L.astype(int), minlength=13)[4:]
+    assert counts.sum() == P and np.all(np.abs(counts - P / 9) < 5 * np.sqrt(P / 9))
+    assert abs(r.mean() - 0.5) < 0.02 and abs(r.var() - 1 / 12) < 0.01
