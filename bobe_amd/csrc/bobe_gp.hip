@@ -180,11 +180,17 @@ struct bobe_gp {
   int nb = 0;
   Hyper hyp;
   bool have_data = false, factored = false, not_pd = false;
+  // prepare_z() keeps its results (ZsT, W_Z, base_z) while the same host Z arrives again and nothing they depend on
+  // changed: an L-BFGS refinement of one acquisition point calls bobe_gp_wip_grad dozens of times with one Z
+  std::vector<double> z_seen;
+  int64_t z_seen_m = -1;
+  void forget_z() { z_seen_m = -1; }
   int64_t chunk = 8192;
 
   DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs, flags, diag;
   int num_cus = 0;
   // sweep / predict workspace
+  DBuf wg_ws;     // workspace of bobe_gp_wip_grad's few-candidates path
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
   std::vector<Depth> depths;
@@ -861,6 +867,10 @@ int bobe_gp::mll_lockstep_collect(int B, double* mll, double* grad, int* status)
 
 // Z-side quantities of the sweep: ZsT, kXZ, V_Z = Linv kXZ, base_z = kself - |V_Z[:,z]|^2, W_Z = Linv^T V_Z
 void bobe_gp::prepare_z(const double* Z, int64_t M, int64_t Mp) {
+  const bool host_z = !is_device_ptr(Z);
+  if (host_z && z_seen_m == M && std::memcmp(z_seen.data(), Z, (size_t)M * d * sizeof(double)) == 0) return;
+  forget_z();
+  if (host_z) z_seen.assign(Z, Z + (size_t)M * d);
   const double* zin = fetch(Z, (size_t)M * d, z_stage);
   ZsT.ensure((size_t)d * Mp * sizeof(double));
   kXZ.ensure((size_t)Np * Mp * sizeof(double));
@@ -878,6 +888,7 @@ void bobe_gp::prepare_z(const double* Z, int64_t M, int64_t Mp) {
   hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
                      (const double*)Linv.d(), Np, nb, (const double*)VZ.d(), Mp, WZ.d(), Mp);
   LAUNCH_CHECK();
+  if (host_z) z_seen_m = M;
 }
 
 void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, double y_std, double* wipv,
@@ -1178,6 +1189,7 @@ int bobe_gp_set_data(bobe_gp_t* g, const double* X, const double* ys, int64_t N)
   g->sync();
   g->have_data = true;
   g->factored = false;
+  g->forget_z();
   return BOBE_OK;
   API_END
 }
@@ -1189,6 +1201,7 @@ int bobe_gp_set_hyper(bobe_gp_t* g, const double* ls, double kvar, double noise)
   g->hyp.kvar = kvar;
   g->hyp.noise = noise;
   g->factored = false;
+  g->forget_z();
   return BOBE_OK;
   API_END
 }
@@ -1201,6 +1214,7 @@ int bobe_gp_factor(bobe_gp_t* g) {
   g->factor_into(g->hyp, g->XsT.d(), g->A.d(), g->Linv.d(), g->w.d(), g->alpha.d());
   const int inf = g->read_info();
   g->factored = true;
+  g->forget_z();
   g->not_pd = (inf != 0x7f7f7f7f);
   if (g->not_pd) {
     const double nan = std::nan("");
@@ -1430,6 +1444,76 @@ int bobe_gp_wip_grad(bobe_gp_t* g, const double* cand, int64_t C, const double* 
   double* d_dv = g->out_dev(dwipv, (size_t)C * d, g->o_mean);
   double* d_ds = g->out_dev(dwipstd, (size_t)C * d, g->o_var);
   const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+  static const bool few_path = [] { const char* e = std::getenv("BOBE_WIPG_FEW"); return !e || std::atoi(e) != 0; }();
+  if (few_path && C <= 16 && g->N <= 4096) {
+    // A handful of candidates (the L-BFGS refinement sends one): matrix-vector stages spread over the chip instead of
+    // 128-column tile passes and one workgroup per candidate (kernels.hpp, "the same for a HANDFUL of candidates").
+    const int64_t N = g->N;
+    const int nzw = (int)(Mp / 64), nnw = (int)((N + 63) / 64);
+    const size_t n_vec = (size_t)C * Np, n_a = (size_t)C * Mp;
+    g->wg_ws.ensure((3 * n_vec + 2 * n_a + (size_t)C * nzw * WG_ZS + (size_t)C * nnw * WG_NS) * sizeof(double));
+    g->part.ensure((size_t)C * nb * Np * sizeof(double));
+    double* kc = g->wg_ws.d();
+    double* vv = kc + n_vec;
+    double* uu = vv + n_vec;
+    double* a1 = uu + n_vec;
+    double* b1 = a1 + n_a;
+    double* pz = b1 + n_a;
+    double* pn = pz + (size_t)C * nzw * WG_ZS;
+    const Hyper& h = g->hyp;
+    const double* li = g->Linv.d();
+#define FEW(KE, DC)                                                                                                      \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((k_wg_col<KE, DC>), dim3((unsigned)(Np / 256 + 1), (unsigned)C), dim3(256), 0, g->stream,           \
+                       (const double*)g->XsT.d(), Np, N, Np, cin, h, kc);                                                 \
+    hipLaunchKernelGGL(k_gemv_lower, dim3((unsigned)(Np / 4), (unsigned)C), dim3(256), 0, g->stream, li, Np, Np,          \
+                       (const double*)kc, vv, (int64_t)0, Np, Np);                                                        \
+    hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(Np / 64), (unsigned)nb, (unsigned)C), dim3(256), 0, g->stream, li,  \
+                       Np, 1, (const double*)vv, g->part.d(), Np, (int64_t)0, Np, (int64_t)nb * Np);                      \
+    hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((Np + 255) / 256), (unsigned)C), dim3(256), 0, g->stream,          \
+                       (const double*)g->part.d(), Np, nb, 1, Np, uu, (int64_t)nb * Np, Np);                              \
+    hipLaunchKernelGGL((k_wg_cross<KE, DC>), dim3((unsigned)nzw, (unsigned)C), dim3(256), (size_t)N * sizeof(double),     \
+                       g->stream, (const double*)g->ZsT.d(), Mp, M, (const double*)g->WZ.d(), Mp, N, Np,                  \
+                       (const double*)kc, (const double*)vv, cin, h, kself, (const double*)g->basez.d(), y_std * y_std,   \
+                       a1, b1, Mp, pz);                                                                                  \
+    hipLaunchKernelGGL((k_wg_rows<KE, DC>), dim3((unsigned)nnw, (unsigned)C), dim3(256), 0, g->stream,                    \
+                       (const double*)g->XsT.d(), Np, N, Np, cin, h, (const double*)g->WZ.d(), Mp, Mp,                    \
+                       (const double*)a1, (const double*)b1, Mp, (const double*)uu, pn);                                  \
+  } while (0)
+    if (h.kern == 0) {
+      if (dcap == 8) FEW(0, 8); else if (dcap == 16) FEW(0, 16); else FEW(0, 32);
+    } else {
+      if (dcap == 8) FEW(1, 8); else if (dcap == 16) FEW(1, 16); else FEW(1, 32);
+    }
+#undef FEW
+    const size_t n_out = (size_t)C * (2 + 2 * d);
+    const bool packed = n_out <= 96 && !(wipv && is_device_ptr(wipv)) && !(wipstd && is_device_ptr(wipstd)) &&
+                        !(dwipv && is_device_ptr(dwipv)) && !(dwipstd && is_device_ptr(dwipstd));
+    if (packed) {                                  // one copy through the pinned result block instead of four
+      g->o_wipv.ensure(n_out * sizeof(double));
+      double* ob = g->o_wipv.d();
+      hipLaunchKernelGGL(k_wg_final, dim3((unsigned)C), dim3(64), 0, g->stream, (const double*)pz, nzw, (const double*)pn,
+                         nnw, h, M, ob, ob + C, ob + 2 * C, ob + 2 * C + C * d);
+      LAUNCH_CHECK();
+      HIPCHK(hipMemcpyAsync(g->h_res, ob, n_out * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+      g->sync();
+      const double* hr = g->h_res;
+      if (wipv) std::memcpy(wipv, hr, (size_t)C * sizeof(double));
+      if (wipstd) std::memcpy(wipstd, hr + C, (size_t)C * sizeof(double));
+      if (dwipv) std::memcpy(dwipv, hr + 2 * C, (size_t)C * d * sizeof(double));
+      if (dwipstd) std::memcpy(dwipstd, hr + 2 * C + C * d, (size_t)C * d * sizeof(double));
+      return BOBE_OK;
+    }
+    hipLaunchKernelGGL(k_wg_final, dim3((unsigned)C), dim3(64), 0, g->stream, (const double*)pz, nzw, (const double*)pn,
+                       nnw, h, M, d_v, d_s, d_dv, d_ds);
+    LAUNCH_CHECK();
+    g->out_finish(wipv, C, g->o_wipv);
+    g->out_finish(wipstd, C, g->o_wipstd);
+    g->out_finish(dwipv, (size_t)C * d, g->o_mean);
+    g->out_finish(dwipstd, (size_t)C * d, g->o_var);
+    g->sync();
+    return BOBE_OK;
+  }
   for (int64_t c0 = 0; c0 < C; c0 += CH) {
     const int64_t nc = std::min<int64_t>(CH, C - c0), ncp = round_up(nc, TILE);
     g->scale(cin + c0 * d, nc, ncp, g->hyp, g->CsT.d(), CH);
@@ -1526,6 +1610,7 @@ int bobe_gp_predict_grad(bobe_gp_t* g, const double* Xq, int64_t C, double* mean
   }
   g->CsT.ensure((size_t)d * std::max<int64_t>(CH, g->chunk) * sizeof(double));
   g->kXC.ensure((size_t)Np * std::max<int64_t>(CH, g->chunk) * sizeof(double));
+  g->forget_z();                                      // (VZ / WZ double as this call's scratch)
   g->VZ.ensure((size_t)Np * CH * sizeof(double));     // V = Linv k
   g->WZ.ensure((size_t)Np * CH * sizeof(double));     // U = Linv^T V = K^-1 k
   g->qpart.ensure((size_t)nb * std::max<int64_t>(CH, g->chunk) * sizeof(double));
@@ -1760,6 +1845,7 @@ int bobe_gp_set_chol(bobe_gp_t* g, const double* L, const double* alpha) {
   g->trtri(g->A.d(), g->Linv.d(), g->Tmp.d());
   g->sync();
   g->factored = true;
+  g->forget_z();
   g->not_pd = false;
   return BOBE_OK;
   API_END
@@ -1796,6 +1882,7 @@ int bobe_gp_clone_state(bobe_gp_t* dst, bobe_gp_t* src) {
   dst->sync();
   dst->have_data = true;
   dst->factored = src->factored;
+  dst->forget_z();
   dst->not_pd = src->not_pd;
   return BOBE_OK;
   API_END
@@ -1850,6 +1937,7 @@ int bobe_gp_append(bobe_gp_t* g, const double* X_new, int64_t b, const double* y
   // ---- V = Linv K(X_old, X_new), W = Linv^T V, S = K(X_new, X_new) + noise I - V^T V
   const int64_t bp = TILE;
   g->kXC.ensure((size_t)Np * std::max<int64_t>(bp, g->chunk) * sizeof(double));
+  g->forget_z();
   g->VZ.ensure((size_t)Np * bp * sizeof(double));
   g->WZ.ensure((size_t)Np * bp * sizeof(double));
   g->kin_a.ensure((size_t)d * bp * sizeof(double));
@@ -1907,6 +1995,7 @@ int bobe_gp_append(bobe_gp_t* g, const double* X_new, int64_t b, const double* y
   g->N = N1;
   if (!pd) {                               // same outcome as the full refactorisation: NaN state, BOBE_NOT_PD
     g->factored = false;
+    g->forget_z();
     return bobe_gp_factor(g);
   }
   for (int64_t c = 0; c < b; ++c)
@@ -1924,6 +2013,7 @@ int bobe_gp_append(bobe_gp_t* g, const double* X_new, int64_t b, const double* y
   g->solve_alpha(g->Linv.d(), g->w.d(), g->alpha.d(), g->part.d());                     // alpha = Linv^T Linv y
   g->sync();                               // (s22 / hG are host temporaries of this call)
   g->factored = true;
+  g->forget_z();
   g->not_pd = false;
   return BOBE_OK;
   API_END

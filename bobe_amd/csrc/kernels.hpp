@@ -265,9 +265,10 @@ __global__ __launch_bounds__(256) void k_wip_score(const double* __restrict__ cr
 // w[i] = sum_{k <= i} M[i][k] y[k]   (one wave per row, fixed summation order)
 __global__ __launch_bounds__(256) void k_gemv_lower(const double* __restrict__ M, int64_t ld, int64_t np,
                                                     const double* __restrict__ y, double* __restrict__ w,
-                                                    int64_t bsM = 0, int64_t bsW = 0) {
-  M += blockIdx.y * bsM;      // batched: blockIdx.y = slot (y is shared by the slots)
+                                                    int64_t bsM = 0, int64_t bsW = 0, int64_t bsY = 0) {
+  M += blockIdx.y * bsM;      // batched: blockIdx.y = slot (y is shared by the slots unless bsY is given)
   w += blockIdx.y * bsW;
+  y += blockIdx.y * bsY;
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= np) return;
@@ -959,8 +960,23 @@ __global__ __launch_bounds__(256) void k_wip_grad(const double* __restrict__ XsT
       __syncthreads();
       if (live) {
         const int nn_end = (n - n0 < NT) ? (int)(n - n0) : NT;
-        for (int nn = 0; nn < nn_end; ++nn) {
-          const double w = W[(n0 + nn) * ldw + z];
+        // (eight rows of W in flight per thread: one load per iteration left the loop waiting on memory, ~1000 cycles
+        // per training point; the sums keep their order)
+        const double* wp = W + n0 * ldw + z;
+        int nn = 0;
+        for (; nn + 8 <= nn_end; nn += 8) {
+          double w8[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) w8[q] = wp[(int64_t)(nn + q) * ldw];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            acck = __builtin_fma(w8[q], kcv[nn + q], acck);
+#pragma unroll
+            for (int j = 0; j < DCAP; ++j) accw[j] = __builtin_fma(w8[q], T[j][nn + q], accw[j]);
+          }
+        }
+        for (; nn < nn_end; ++nn) {
+          const double w = wp[(int64_t)nn * ldw];
           acck = __builtin_fma(w, kcv[nn], acck);
 #pragma unroll
           for (int j = 0; j < DCAP; ++j) accw[j] = __builtin_fma(w, T[j][nn], accw[j]);
@@ -1026,6 +1042,213 @@ __global__ __launch_bounds__(256) void k_wip_grad(const double* __restrict__ XsT
       }
     }
   }
+}
+
+// ---- the same for a HANDFUL of candidates (the L-BFGS refinement of an acquisition point asks for one at a time) ----
+// The batched path above spends a 128-column MFMA tile pass on each triangular solve of a single column and ONE workgroup
+// on a candidate's whole N x M x d contraction.  Here every stage is matrix-vector work spread over the chip, and the
+// gradient is rearranged so that no stage costs more than O(N M):
+//   sum_z a_z sum_n W[n][z] T[j][n]  =  sum_n T[j][n] q_n,   q = W a      (a_z: the weight of d cross_z in the score)
+// Stages (blockIdx.y / .z = candidate): k_wg_col -> k_gemv_lower (v = Linv k_c) -> k_gemv_t_part + k_colsum_parts
+// (u = Linv^T v) -> k_wg_cross (s, cross_z, the weights, the z-side sums) -> k_wg_rows (q, q', the n-side sums) ->
+// k_wg_final.  All sums in a fixed order.
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_wg_col(const double* __restrict__ XsT, int64_t ldx, int64_t n, int64_t np,
+                                                const double* __restrict__ cand, Hyper h, double* __restrict__ kc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (i >= np) return;
+  double r2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) {
+    const double df = (j < h.d && i < n) ? XsT[j * ldx + i] - cand[c * h.d + j] / h.ls[j] : 0.0;
+    r2 += df * df;
+  }
+  kc[c * np + i] = (i < n) ? kern_eval<KERN>(r2, h.kvar) : 0.0;
+}
+
+constexpr int WG_ZS = 4 + 2 * MAX_D;     // doubles per k_wg_cross partial: sum var+, sum sqrt, sum a2, sum b2, Dv[j], Ds[j]
+constexpr int WG_NS = 3 * MAX_D;         // doubles per k_wg_rows partial: Qv[j], Qs[j], ds[j]
+
+// one workgroup = 64 integration points (lane) x 4 interleaved quarters of the training points (wave)
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_wg_cross(const double* __restrict__ ZsT, int64_t ldz, int64_t m,
+                                                  const double* __restrict__ W, int64_t ldw, int64_t n, int64_t np,
+                                                  const double* __restrict__ kc, const double* __restrict__ v,
+                                                  const double* __restrict__ cand, Hyper h, double kself,
+                                                  const double* __restrict__ basez, double ystd2,
+                                                  double* __restrict__ a1, double* __restrict__ b1, int64_t lda,
+                                                  double* __restrict__ partZ) {
+  extern __shared__ double kcs[];                 // [n]
+  __shared__ double red[4], redz[4][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t c = blockIdx.y;
+  kc += c * np;
+  v += c * np;
+  double sq = 0.0;
+  for (int64_t i = t; i < n; i += 256) {
+    kcs[i] = kc[i];
+    const double vi = v[i];
+    sq += vi * vi;
+  }
+  sq = wave_sum(sq);
+  if (lane == 0) red[wave] = sq;
+  __syncthreads();
+  const double s = kself - ((red[0] + red[1]) + (red[2] + red[3]));
+  const bool sbad = !(s >= 0.0);
+  const int64_t z = (int64_t)blockIdx.x * 64 + lane;
+  double acc = 0.0;
+  {
+    const double* wp = W + z;
+    int64_t i = wave;
+    for (; i + 28 < n; i += 32) {                 // eight rows in flight per thread
+      double w8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w8[q] = wp[(i + 4 * q) * ldw];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc = __builtin_fma(w8[q], kcs[i + 4 * q], acc);
+    }
+    for (; i < n; i += 4) acc = __builtin_fma(wp[i * ldw], kcs[i], acc);
+  }
+  redz[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  const double wk = (redz[0][lane] + redz[1][lane]) + (redz[2][lane] + redz[3][lane]);
+  double sv = 0.0, ss = 0.0, w1 = 0.0, w2 = 0.0, u1 = 0.0, u2 = 0.0, gz = 0.0, dz[DCAP];
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) dz[j] = 0.0;
+  if (z < m) {
+    double r2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < DCAP; ++j) {
+      dz[j] = (j < h.d) ? ZsT[j * ldz + z] - cand[c * h.d + j] / h.ls[j] : 0.0;
+      r2 += dz[j] * dz[j];
+    }
+    const double kz = kern_eval<KERN>(r2, h.kvar);
+    gz = kern_grad_factor<KERN>(r2, h.kvar, kz);
+    const double cross = kz - wk;
+    double vp = basez[z] - (cross * cross) / s;
+    bool floored = sbad;
+    if (vp != vp) floored = true;
+    if (vp < NOISE_FLOOR) floored = true;
+    if (floored) vp = NOISE_FLOOR;
+    const double vs = vp * ystd2, sr = sqrt(vs);
+    sv = vs;
+    ss = sr;
+    if (!floored) {
+      w1 = -2.0 * cross / s * ystd2;
+      w2 = (cross * cross) / (s * s) * ystd2;
+      u1 = w1 / (2.0 * sr);
+      u2 = w2 / (2.0 * sr);
+    }
+  }
+  a1[c * lda + z] = w1;
+  b1[c * lda + z] = u1;
+  double* pz = partZ + (c * gridDim.x + blockIdx.x) * WG_ZS;
+  const double t0 = wave_sum(sv), t1 = wave_sum(ss), t2 = wave_sum(w2), t3 = wave_sum(u2);
+  if (lane == 0) {
+    pz[0] = t0;
+    pz[1] = t1;
+    pz[2] = t2;
+    pz[3] = t3;
+  }
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) {
+    if (j < h.d) {                                // uniform
+      const double a = wave_sum(w1 * gz * dz[j]), b = wave_sum(u1 * gz * dz[j]);
+      if (lane == 0) {
+        pz[4 + j] = a;
+        pz[4 + MAX_D + j] = b;
+      }
+    }
+  }
+}
+
+// one workgroup = 64 training points, 16 per wave one after the other; lanes run over the integration points
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_wg_rows(const double* __restrict__ XsT, int64_t ldx, int64_t n, int64_t np,
+                                                 const double* __restrict__ cand, Hyper h,
+                                                 const double* __restrict__ W, int64_t ldw, int64_t mp,
+                                                 const double* __restrict__ a1, const double* __restrict__ b1,
+                                                 int64_t lda, const double* __restrict__ u,
+                                                 double* __restrict__ partN) {
+  __shared__ double red[4][3][DCAP];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t c = blockIdx.y;
+  a1 += c * lda;
+  b1 += c * lda;
+  u += c * np;
+  const double xl = (lane < h.d) ? cand[c * h.d + lane] / h.ls[lane] : 0.0;      // this lane's coordinate (lane = j)
+  double aq = 0.0, as = 0.0, au = 0.0;
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + wave + 4 * r;
+    if (i >= n) break;                            // uniform per wave
+    double q = 0.0, qs = 0.0;
+    for (int64_t z = lane; z < mp; z += 64) {
+      const double w = W[i * ldw + z];
+      q = __builtin_fma(a1[z], w, q);
+      qs = __builtin_fma(b1[z], w, qs);
+    }
+    q = wave_sum(q);
+    qs = wave_sum(qs);
+    double r2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < DCAP; ++j) {
+      const double df = (j < h.d) ? XsT[j * ldx + i] - cand[c * h.d + j] / h.ls[j] : 0.0;
+      r2 += df * df;
+    }
+    const double kv = kern_eval<KERN>(r2, h.kvar);
+    const double tj = (lane < h.d) ? kern_grad_factor<KERN>(r2, h.kvar, kv) * (XsT[lane * ldx + i] - xl) : 0.0;
+    aq = __builtin_fma(q, tj, aq);
+    as = __builtin_fma(qs, tj, as);
+    au = __builtin_fma(u[i], tj, au);
+  }
+  if (lane < DCAP) {
+    red[wave][0][lane] = aq;
+    red[wave][1][lane] = as;
+    red[wave][2][lane] = au;
+  }
+  __syncthreads();
+  if (t < 3 * DCAP) {
+    const int k = t / DCAP, j = t % DCAP;
+    partN[(c * gridDim.x + blockIdx.x) * WG_NS + k * MAX_D + j] =
+        (red[0][k][j] + red[1][k][j]) + (red[2][k][j] + red[3][k][j]);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_wg_final(const double* __restrict__ partZ, int nzw,
+                                                 const double* __restrict__ partN, int nnw, Hyper h, int64_t m,
+                                                 double* __restrict__ wipv, double* __restrict__ wipstd,
+                                                 double* __restrict__ dwipv, double* __restrict__ dwipstd) {
+  const int j = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const double* pz = partZ + c * nzw * WG_ZS;
+  const double* pn = partN + c * nnw * WG_NS;
+  const double inv_m = 1.0 / (double)m;
+  double sv = 0.0, ss = 0.0, a2 = 0.0, b2 = 0.0;
+  for (int w = 0; w < nzw; ++w) {
+    sv += pz[w * WG_ZS];
+    ss += pz[w * WG_ZS + 1];
+    a2 += pz[w * WG_ZS + 2];
+    b2 += pz[w * WG_ZS + 3];
+  }
+  if (j == 0) {
+    if (wipv) wipv[c] = sv * inv_m;
+    if (wipstd) wipstd[c] = ss * inv_m;
+  }
+  if (j >= h.d) return;
+  double dv = 0.0, dsd = 0.0, qv = 0.0, qs = 0.0, ds = 0.0;
+  for (int w = 0; w < nzw; ++w) {
+    dv += pz[w * WG_ZS + 4 + j];
+    dsd += pz[w * WG_ZS + 4 + MAX_D + j];
+  }
+  for (int w = 0; w < nnw; ++w) {
+    qv += pn[w * WG_NS + j];
+    qs += pn[w * WG_NS + MAX_D + j];
+    ds += pn[w * WG_NS + 2 * MAX_D + j];
+  }
+  const double dsj = -2.0 * ds / h.ls[j];
+  if (dwipv) dwipv[c * h.d + j] = ((dv - qv) / h.ls[j] + a2 * dsj) * inv_m;
+  if (dwipstd) dwipstd[c * h.d + j] = ((dsd - qs) / h.ls[j] + b2 * dsj) * inv_m;
 }
 
 // mode 0: EI, 1: LogEI.  out = +EI / +logEI (the reference minimises the negative)

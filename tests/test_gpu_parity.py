@@ -835,3 +835,12 @@ def test_wip_gradient_against_values_and_central_differences(kernel, d, m):
     # a candidate on top of a training point: s ~ noise, every fantasy variance is at or near its floor -> finite output
     wv0, ws0, dv0, ds0 = gp.wip_grad(X[:2], Z)
     assert np.all(np.isfinite(wv0)) and np.all(np.isfinite(dv0)) and np.all(np.isfinite(ds0))
+    # up to 16 candidates take the matrix-vector path, more the batched (tile) path: same numbers from both
+    big = np.vstack([cand, X[:2], rng.uniform(0.1, 0.9, size=(9, d))])
+    bw = gp.wip_grad(big, Z)
+    scale_v, scale_s = np.max(np.abs(bw[2])), np.max(np.abs(bw[3]))
+    assert np.allclose(wv, bw[0][:9], rtol=1e-11) and np.allclose(ws, bw[1][:9], rtol=1e-11)
+    assert np.allclose(dv, bw[2][:9], rtol=1e-8, atol=1e-7 * scale_v) and np.allclose(dsd, bw[3][:9], rtol=1e-8, atol=1e-7 * scale_s)
+    assert np.allclose(wv0, bw[0][9:11], rtol=1e-11) and np.allclose(dv0, bw[2][9:11], rtol=1e-8, atol=1e-7 * scale_v)
+    one = gp.wip_grad(cand[4], Z)                                          # a single candidate (what L-BFGS sends)
+    assert np.array_equal(one[2][0], dv[4]) and one[0][0] == wv[4]      # a candidate does not depend on its batch
