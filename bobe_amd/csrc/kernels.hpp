@@ -733,6 +733,21 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
     eps_s = ad[0];
   }
   const unsigned long long ckey = hmc_mix64(seed ^ hmc_mix64((unsigned long long)c));
+  // Up to RMAX training points per thread are loaded ONCE per launch (a launch is hundreds of leapfrog steps, each of
+  // which would otherwise wait for the same global loads again); points past n carry alpha = 0.
+  constexpr int RMAX = 64 / DCAP;
+  const bool cached = n <= (int64_t)256 * RMAX;
+  const int nrow = (int)((n + 255) / 256);
+  double cx[RMAX][DCAP], ca[RMAX];
+  if (cached) {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const int64_t i = t + 256 * r;
+      ca[r] = (i < n) ? alpha[i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) cx[r][j] = (j < d && i < n) ? XsT[j * ldx + i] : 0.0;
+    }
+  }
   __syncthreads();
   for (int it = 0; it < niter; ++it) {
     const unsigned long long ikey = ckey + ((unsigned long long)(it0 + it) << 12);
@@ -761,20 +776,40 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
       double ms = 0.0, gm[DCAP];
 #pragma unroll
       for (int j = 0; j < DCAP; ++j) gm[j] = 0.0;
-      for (int64_t i = t; i < n; i += 256) {
-        double df[DCAP];
-        double r2 = 0.0;
+      if (cached) {                                            // this thread's training points stay in registers
 #pragma unroll
-        for (int j = 0; j < DCAP; ++j) {
-          df[j] = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
-          r2 += df[j] * df[j];
+        for (int r = 0; r < RMAX; ++r) {
+          if (r < nrow) {                                      // uniform
+            double df[DCAP];
+            double r2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < DCAP; ++j) {
+              df[j] = (j < d) ? cx[r][j] - xs[j] : 0.0;
+              r2 += df[j] * df[j];
+            }
+            const double kv = kern_eval<KERN>(r2, h.kvar);
+            const double ag = ca[r] * kern_grad_factor<KERN>(r2, h.kvar, kv);
+            ms += ca[r] * kv;
+#pragma unroll
+            for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
+          }
         }
-        const double kv = kern_eval<KERN>(r2, h.kvar);
-        const double a = alpha[i];
-        const double ag = a * kern_grad_factor<KERN>(r2, h.kvar, kv);
-        ms += a * kv;
+      } else {
+        for (int64_t i = t; i < n; i += 256) {
+          double df[DCAP];
+          double r2 = 0.0;
 #pragma unroll
-        for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
+          for (int j = 0; j < DCAP; ++j) {
+            df[j] = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
+            r2 += df[j] * df[j];
+          }
+          const double kv = kern_eval<KERN>(r2, h.kvar);
+          const double a = alpha[i];
+          const double ag = a * kern_grad_factor<KERN>(r2, h.kvar, kv);
+          ms += a * kv;
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
+        }
       }
       ms = wave_sum(ms);
       if (lane == 0) red[wave][DCAP] = ms;
@@ -793,12 +828,14 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
         g[t] = gv;
         pm[t] += ((s < L - 1) ? eps : 0.5 * eps) * gv;
       }
-      if (t == 0) {
-        const double m = (((red[0][DCAP] + red[1][DCAP]) + red[2][DCAP]) + red[3][DCAP]) * ystd + ymean;
-        double jac = 0.0;
-        for (int j = 0; j < d; ++j) jac += log(x[j]) + log1p(-x[j]);
-        mean_s = m;
-        lp_s = m / temp + jac;
+      if (wave == 1) {                                         // (wave 0 is busy with the gradient lanes)
+        double jl = (lane < d) ? log(x[lane]) + log1p(-x[lane]) : 0.0;
+        jl = wave_sum(jl);
+        if (lane == 0) {
+          const double m = (((red[0][DCAP] + red[1][DCAP]) + red[2][DCAP]) + red[3][DCAP]) * ystd + ymean;
+          mean_s = m;
+          lp_s = m / temp + jl;
+        }
       }
       __syncthreads();
     }
