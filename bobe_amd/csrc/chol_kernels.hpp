@@ -139,8 +139,14 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
       const int li = lane & 15;
       const bool ident = (lane >= 16) && (lane < 32);
       double r[16];
+      // (every lane loads its row li - the identity lanes read the same 128 bytes as their twins and discard them:
+      // eight 16-byte LDS reads with no EXEC games, instead of sixteen conditional 8-byte ones)
 #pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = ident ? ((c == li) ? 1.0 : 0.0) : S[(o + li) * PLD + o + c];
+      for (int c = 0; c < 16; c += 2) {
+        const v2d v = *reinterpret_cast<const v2d*>(S + (o + li) * PLD + o + c);
+        r[c] = ident ? ((c == li) ? 1.0 : 0.0) : v[0];
+        r[c + 1] = ident ? ((c + 1 == li) ? 1.0 : 0.0) : v[1];
+      }
       bool bad = false;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -155,8 +161,10 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
         }
       }
       if (lane < 16) {
+        // (the whole row: what lands right of the diagonal is never read as an operand, and block_store_lower writes
+        // zeros there when the block leaves LDS)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) S[(o + li) * PLD + o + c] = (c <= li) ? r[c] : 0.0;
+        for (int c = 0; c < 16; c += 2) *reinterpret_cast<v2d*>(S + (o + li) * PLD + o + c) = (v2d){r[c], r[c + 1]};
       } else if (ident) {
         // lane 16+i holds row i of Lpp^-T: r[c] = inv(Lpp)[c][i]
 #pragma unroll

@@ -1,0 +1,36 @@
+"""Snapshot / compare the bits of factorisation-dependent outputs (before/after a kernel change that must not move them).
+   python tools/bits_snapshot.py save|check FILE"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bobe_amd.gp import GP  # noqa: E402
+
+out = {}
+for N, d, kern in ((17, 2, "rbf"), (100, 3, "matern"), (129, 4, "rbf"), (641, 5, "rbf"), (1500, 8, "matern"), (2048, 8, "rbf"), (4096, 8, "rbf")):
+    rng = np.random.default_rng(N)
+    X = rng.uniform(size=(N, d))
+    y = np.sin(X.sum(1)) + 0.1 * rng.normal(size=N)
+    gp = GP(X, y, noise=1e-5, kernel=kern, lengthscales=np.full(d, 0.5))
+    out[f"L_{N}"] = np.array(gp.cholesky)
+    m, g = gp.mll_data(np.full(d, 0.45), 1.3)
+    out[f"m_{N}"], out[f"g_{N}"] = np.array(m), np.array(g)
+    B = 4
+    lsb = np.full((B, d), 0.4) + 0.03 * np.arange(B)[:, None]
+    mb, gb = gp.mll_data_batch(lsb, np.ones(B))
+    out[f"mb_{N}"], out[f"gb_{N}"] = np.array(mb), np.array(gb)
+    mu, var = gp.predict_batched(rng.uniform(size=(50, d)))
+    out[f"mu_{N}"], out[f"var_{N}"] = np.array(mu), np.array(var)
+import hashlib
+import json
+out = {k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for k, v in out.items()}
+if sys.argv[1] == "save":
+    json.dump(out, open(sys.argv[2], "w"), indent=0)
+    print("saved", len(out), "digests")
+else:
+    ref = json.load(open(sys.argv[2]))
+    bad = [k for k in out if out[k] != ref[k]]
+    print("BITS DIFFER in:" if bad else "all bits identical", bad)
+    sys.exit(1 if bad else 0)
