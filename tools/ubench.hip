@@ -56,6 +56,26 @@ int main() {
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_potf2<true, true>), dim3(1), dim3(256), POTF2_SMEM_BYTES, 0, A, (int64_t)N, Linv, (int64_t)N, 1, info, st);
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+  {
+    CK(hipFuncSetAttribute((const void*)k_chol_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_SMEM_BYTES));
+    double* dg;
+    CK(hipMalloc(&dg, (size_t)8 * 128 * 128 * 8));
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemcpy(A, K.data(), K.size() * 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((k_chol_panel<true>), dim3(14, 1), dim3(256), POTF2_SMEM_BYTES, 0, A, (int64_t)N, (int64_t)0, Linv, (int64_t)N,
+                         (int64_t)0, 0, 14, info, 128, dg, (int64_t)0, st);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost));
+      unsigned long long ta = 0, tb = 0, tc = 0;
+      for (int p = 0; p < 8; ++p) {
+        ta += h[3 + 3 * p] - h[2 + 3 * p];
+        tb += h[4 + 3 * p] - h[3 + 3 * p];
+        tc += (p < 7 ? h[5 + 3 * p] : h[26]) - h[4 + 3 * p];
+      }
+      printf("chol_panel rep %d (cycles): stage-in %llu | factor a=%llu b=%llu c=%llu | L_kk out %llu | row solve %llu | rows out %llu | total %llu\n",
+             rep, h[1] - h[0], ta, tb, tc, h[27] - h[26], h[28] - h[27], h[29] - h[28], h[29] - h[0]);
+    }
+  }
   printf("potf2 wall %.2f us per launch (back-to-back)\n", ms * 1e3 / 20);
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_trsm_panel<true>), dim3(2 * 7), dim3(256), TRSM_SMEM_BYTES, 0, A, (int64_t)N, (const double*)Linv, (int64_t)N, 0, st);
