@@ -356,14 +356,14 @@ def main():
         # advancing in lock step through one batched launch sequence, and (round 1's form) B on private streams
         chol = {}
         ms_ = C.c_double()
-        _lib.check(lib.bobe_debug_time_potrf(h, 3, C.byref(ms_)), "time_potrf")
+        _lib.check(lib.bobe_debug_time_potrf(h, 10, C.byref(ms_)), "time_potrf")
         potrf_ms = ms_.value
         flops_potrf = N ** 3 / 3.0
         for B in (4, 8):
-            _lib.check(lib.bobe_debug_time_potrf_lockstep(h, B, 3, C.byref(ms_)), "time_potrf_lockstep")
+            _lib.check(lib.bobe_debug_time_potrf_lockstep(h, B, 10, C.byref(ms_)), "time_potrf_lockstep")
             chol[f"lockstep_{B}"] = {"in_flight": B, "ms_all": ms_.value, "gflops": B * flops_potrf / (ms_.value * 1e-3) / 1e9,
                                      "frac_of_fp64_mfma_peak": B * flops_potrf / (ms_.value * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
-        _lib.check(lib.bobe_debug_time_potrf_batch(h, 4, 3, C.byref(ms_)), "time_potrf_batch")
+        _lib.check(lib.bobe_debug_time_potrf_batch(h, 4, 10, C.byref(ms_)), "time_potrf_batch")
         chol["streams_4"] = {"in_flight": 4, "ms_all": ms_.value, "gflops": 4 * flops_potrf / (ms_.value * 1e-3) / 1e9,
                              "frac_of_fp64_mfma_peak": 4 * flops_potrf / (ms_.value * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
         chunk = args.chunk or 8192

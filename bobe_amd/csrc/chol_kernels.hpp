@@ -23,18 +23,19 @@ constexpr int POTF2_DLD = 17;                     // leading dimension of a stag
 // coalesced 128x128 block <-> LDS (16-byte accesses, one row per wave per step).  LOWER: only the lower
 // triangle is needed; lanes right of the diagonal re-read the diagonal's 16-byte granule (same cache line,
 // no branch), which halves the distinct lines fetched.  The strictly upper part of S is then unspecified.
-template <bool LOWER = false>
+template <bool LOWER = false, int NWAVES = 4>
 __device__ __forceinline__ void block_load(double* S, const double* __restrict__ G, int64_t ld) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  v2d v[32];
+  constexpr int NI = TILE / NWAVES;
+  v2d v[NI];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int r = 4 * i + wave;
+  for (int i = 0; i < NI; ++i) {
+    const int r = NWAVES * i + wave;
     const int c = LOWER ? ((2 * lane <= r) ? 2 * lane : (r & ~1)) : 2 * lane;
     v[i] = *reinterpret_cast<const v2d*>(G + (int64_t)r * ld + c);
   }
 #pragma unroll
-  for (int i = 0; i < 32; ++i) *reinterpret_cast<v2d*>(S + (4 * i + wave) * PLD + 2 * lane) = v[i];
+  for (int i = 0; i < NI; ++i) *reinterpret_cast<v2d*>(S + (NWAVES * i + wave) * PLD + 2 * lane) = v[i];
 }
 // store the lower triangle (zeros above the diagonal)
 __device__ __forceinline__ void block_store_lower(const double* S, double* __restrict__ G, int64_t ld) {
@@ -123,9 +124,17 @@ __device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0
 // NW = waves of the workgroup that take part (4 for the 256-thread kernels, 16 in k_chol_step): wave 0 owns the
 // serial leaf, the others share the deferred updates and the row solves (which tile a wave gets does not change any
 // tile's arithmetic).
-template <bool STAMP, int NW = 4>
+struct NoSideJob {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// SIDE: work the helper waves (1 .. NW-1) do in phase A of step p after their deferred updates, called as side(p - 1):
+// it may read everything steps <= p-1 produced (the L tiles of block row p-1, its 16x16 inverse) - k_chol_panel solves
+// its rows below the block there, under the leaf of wave 0, instead of after the factor.
+// SKIPW > 0: that wave takes no phase-A work (with more than four waves, wave SKIPW = 4 shares the leaf wave's SIMD, and
+// MFMAs issued there slow the leaf down by half: measured 4.4-4.9 k -> 5.7-6.4 k cycles per step).
+template <bool STAMP, int NW = 4, class SIDE = NoSideJob, int SKIPW = -1>
 __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int nsteps, int colbase, int* __restrict__ info,
-                                                 unsigned long long* __restrict__ stamps) {
+                                                 unsigned long long* __restrict__ stamps, SIDE side = SIDE()) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
@@ -172,20 +181,22 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
       }
       if (bad && lane == 0) atomicMin(info, colbase + o + 1);
       }
-    } else if (p > 0) {
+    } else if (p > 0 && wave != SKIPW) {
       // ---- phase A, waves 1..3: deferred updates of step p-1: every tile (ti, tj), p <= tj <= ti <= 7,
       //      except the diagonal tile (p, p), which wave 0 updated right after the previous phase B ----
       const int op = o - 16;
       const int nt = 8 - p;                 // tiles p..7
       const int ntiles = nt * (nt + 1) / 2 - 1;
-      constexpr int NU = NW - 1;            // updater waves
-      for (int q = wave - 1; q < ntiles; q += 2 * NU) {
+      constexpr int NU = NW - 1 - (SKIPW > 0 ? 1 : 0);            // updater waves
+      const int hw = wave - 1 - ((SKIPW > 0 && wave > SKIPW) ? 1 : 0);
+      for (int q = hw; q < ntiles; q += 2 * NU) {
         int a0, b0, a1, b1;
         tri_decode_small(q + 1, a0, b0);    // index 0 is (p, p): skipped
         const bool two = (q + NU) < ntiles;
         tri_decode_small(two ? q + NU + 1 : q + 1, a1, b1);
         potf2_update2(S, op, p + a0, p + b0, p + a1, p + b1, two, lane);
       }
+      side(p - 1);
     }
     __syncthreads();
     BOBE_STAMP(3 + 3 * p);
@@ -212,12 +223,13 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
 }
 
 // stage-in of a diagonal block for the factor loop: lower part of the block, identity inverses for the padding steps
+template <int NWAVES = 4>
 __device__ __forceinline__ void potf2_stage_in(double* S, double* Dall, const double* __restrict__ Ab, int64_t lda,
                                                int nsteps) {
   const int t = threadIdx.x;
-  block_load<true>(S, Ab, lda);
+  block_load<true, NWAVES>(S, Ab, lda);
   if (nsteps < 8)
-    for (int e = t; e < (8 - nsteps) * 16 * 16; e += 256) {
+    for (int e = t; e < (8 - nsteps) * 16 * 16; e += 64 * NWAVES) {
       const int pp = nsteps + (e >> 8), rr = (e >> 4) & 15, cc = e & 15;
       Dall[(pp * 16 + rr) * POTF2_DLD + cc] = (rr == cc) ? 1.0 : 0.0;
     }
@@ -539,18 +551,147 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ A, int64_t 
   BOBE_STAMP(29);
 }
 
-// panel k of every slot as ONE 256-thread launch (grid = npanel x nbatch): the body above without an update half.
-// Replaces the k_potf2 + k_trsm_panel pair when all nbatch*npanel workgroups fit on the chip at once (the redundant
-// factorisations then cost nothing and one kernel boundary plus the L_kk round trip through global memory go away).
+// The panel as its own launch: EIGHT waves.  Wave 0 is the factor's leaf wave; wave 4 (same SIMD) does nothing while the
+// leaf runs; waves 1, 2, 3, 5, 6, 7 are the helpers of the factor (deferred tile updates), and 1, 2, 3, 5 each own 16 of
+// the workgroup's 64 rows below the block.  The
+// solve of those rows by sub-block p (X^T_p = invD_p (A^T_p - sum_{q<p} L_kk[p][q] X^T_q), the MFMA sequence of
+// k_trsm_panel, same bits) only needs what factor step p produced, so the helpers run it in phase A of step p+1, under
+// wave 0's leaf, instead of after the factor: of the 144 MFMAs per wave (12 k cycles after a 52 k factor) only the last
+// sub-block's four stay exposed.
+constexpr int PANEL_THREADS = 512;
+template <bool STAMP>
+__device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
+                                                 int64_t ldl, int k, int pw, int npanel, int* __restrict__ info,
+                                                 int nvalid, double* __restrict__ Lkk_out,
+                                                 unsigned long long* __restrict__ stamps) {
+  const bool has_rows = npanel > 1;
+  extern __shared__ double S[];
+  double* Dall = S + TILE * PLD;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int nsteps = (nvalid + 15) >> 4;
+  const int64_t col0 = (int64_t)k * TILE;
+  double* Ab = A + col0 * lda + col0;
+  double* Ib = Linv + col0 * ldl + col0;
+  BOBE_STAMP(0);
+  potf2_stage_in<8>(S, Dall, Ab, lda, nsteps);
+  __builtin_amdgcn_sched_barrier(0);
+  // solver wave (1, 2, 3, 5 = strip 0..3): rows (k+1)*128 + 64*pw + 16*strip .. +15 of block column k, straight into
+  // transposed-accumulator layout (lane (li, g), register r of tile p = A[row li][16p + g + 4r]); in flight during the
+  // first factor steps
+  const int strip = wave < 4 ? wave - 1 : 3;
+  const bool solver = has_rows && ((wave >= 1 && wave <= 3) || wave == 5);
+  const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)pw * 64 + strip * 16;
+  double* Aw = A + row0 * lda + col0;
+  v4d X[8];
+  if (solver) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[p][r] = Aw[(int64_t)li * lda + 16 * p + g + 4 * r];
+  }
+  __syncthreads();
+  BOBE_STAMP(1);
+  // sub-block p in two parts: accumulate<p> (x = A^T_p - sum_{q<p} L_kk[p][q] X^T_q: needs the factor's steps < p only)
+  // and finish<p> (X^T_p = invD_p x: needs leaf p).  Every LDS operand of a part is read first (one latency for all).
+  auto accumulate = [&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    double lv[(p > 0 ? p : 1) * 4];
+#pragma unroll
+    for (int q = 0; q < p; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lv[4 * q + r] = -S[(16 * p + li) * PLD + 16 * q + g + 4 * r];
+    __builtin_amdgcn_sched_barrier(0);
+    v4d x = X[p];
+#pragma unroll
+    for (int q = 0; q < p; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[4 * q + r], X[q][r], x, 0, 0, 0);
+    X[p] = x;
+  };
+  auto finish = [&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    double dv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dv[r] = Dall[(p * 16 + li) * POTF2_DLD + g + 4 * r];
+    v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[r], X[p][r], y, 0, 0, 0);
+    X[p] = y;
+  };
+  // phase A of factor step pd + 1: finish sub-block pd, then the whole accumulation of sub-block pd + 1
+  // (X is indexed with constants only: it must stay in registers)
+#define BOBE_SIDE_CASE(PD)                                    \
+  case PD:                                                    \
+    finish(std::integral_constant<int, PD>());                \
+    accumulate(std::integral_constant<int, PD + 1>());        \
+    break
+  auto side = [&](int pd) {
+    if (!solver) return;
+    switch (pd) {
+      BOBE_SIDE_CASE(0);
+      BOBE_SIDE_CASE(1);
+      BOBE_SIDE_CASE(2);
+      BOBE_SIDE_CASE(3);
+      BOBE_SIDE_CASE(4);
+      BOBE_SIDE_CASE(5);
+      BOBE_SIDE_CASE(6);
+      default: break;
+    }
+  };
+#undef BOBE_SIDE_CASE
+  potf2_factor_lds<STAMP, 8, decltype(side), 4>(S, Dall, nsteps, (int)col0, info, stamps, side);
+  BOBE_STAMP(26);
+  // L_kk and the 16x16 inverses leave LDS once per slot: every workgroup of the launch holds the same factor, so
+  // workgroup pw writes the rows pw, pw + npanel, ... of L_kk (zeros above the diagonal) and pw = 0 the inverses
+  {
+    const int np_eff = npanel < TILE ? npanel : TILE;
+    for (int r = pw + np_eff * wave; r < TILE; r += np_eff * 8) {
+      const int c = 2 * lane;
+      v2d v = *reinterpret_cast<const v2d*>(S + r * PLD + c);
+      if (c > r) v[0] = 0.0;
+      if (c + 1 > r) v[1] = 0.0;
+      *reinterpret_cast<v2d*>(Lkk_out + (int64_t)r * TILE + c) = v;
+    }
+    if (pw == 0 && t < 256) {
+      const int bb = t >> 5, rr = (t >> 1) & 15, hh = t & 1;
+      const double* src = Dall + (bb * 16 + rr) * POTF2_DLD + 8 * hh;
+      double* dst = Ib + (int64_t)(16 * bb + rr) * ldl + 16 * bb + 8 * hh;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) dst[c] = src[c];
+    }
+  }
+  BOBE_STAMP(27);
+  if (!has_rows) return;
+  // (a block with rows below it is never the ragged last one: nsteps = 8 and the steps 0..6 ran under the leaves)
+  if (solver) finish(std::integral_constant<int, 7>());
+  __syncthreads();   // every wave is done with L_kk (and pw 0 with writing it back): reuse the block as transposer
+  BOBE_STAMP(28);
+  if (!solver) return;
+  double* Sw = S + (strip * 16) * PLD;
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sw[li * PLD + 16 * p + g + 4 * r] = X[p][r];
+  // (each wave reads back only its own slab: no barrier needed, the wave's LDS accesses are ordered)
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    *reinterpret_cast<v2d*>(Aw + (int64_t)i * lda + 2 * lane) = *reinterpret_cast<const v2d*>(Sw + i * PLD + 2 * lane);
+  BOBE_STAMP(29);
+}
+
+// panel k of every slot as ONE launch (grid = npanel x nbatch, PANEL_THREADS threads).  Replaces the k_potf2 +
+// k_trsm_panel pair when all nbatch*npanel workgroups fit on the chip at once (the redundant factorisations then cost
+// nothing and one kernel boundary plus the L_kk round trip through global memory go away).
 template <bool STAMP = false>
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
-                                                    double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
-                                                    int npanel, int* __restrict__ info, int nvalid,
-                                                    double* __restrict__ diag, int64_t bsD,
-                                                    unsigned long long* __restrict__ stamps = nullptr) {
+__global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
+                                                              double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
+                                                              int npanel, int* __restrict__ info, int nvalid,
+                                                              double* __restrict__ diag, int64_t bsD,
+                                                              unsigned long long* __restrict__ stamps = nullptr) {
   const int slot = blockIdx.y;
-  chol_panel_body<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel > 1, info + slot, nvalid,
-                         diag + slot * bsD + (int64_t)k * TILE * TILE, stamps);
+  chol_panel_body5<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel, info + slot,
+                          nvalid, diag + slot * bsD + (int64_t)k * TILE * TILE, stamps);
 }
 
 // A[blk][blk] <- scratch block blk for blk = first + blockIdx.x (slot = blockIdx.y): the L_kk the panel launches left aside

@@ -213,8 +213,9 @@ int bobe_debug_gemm(int device, int layoutA, int layoutB, int64_t M, int64_t N, 
 int bobe_debug_kinv(bobe_gp_t* gp, double* Kinv);
 /* L^-1 (N x N lower) from the current factorisation */
 int bobe_debug_linv(bobe_gp_t* gp, double* Linv);
-/* run only the Cholesky factorisation of the current K `reps` times and return the mean device
- * time per factorisation in milliseconds (HIP events on the handle's stream) */
+/* run only the Cholesky factorisation of the current K `reps` times after ONE untimed pass (first touch of the
+ * workspace, clocks) and return the mean device time per factorisation in milliseconds (HIP events on the handle's
+ * stream).  The two batch forms below time the same way. */
 int bobe_debug_time_potrf(bobe_gp_t* gp, int reps, double* ms);
 /* B factorisations in flight at once (one evaluation slot each); *ms = device time for all B together */
 int bobe_debug_time_potrf_batch(bobe_gp_t* gp, int B, int reps, double* ms);

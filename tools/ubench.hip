@@ -62,7 +62,7 @@ int main() {
     CK(hipMalloc(&dg, (size_t)8 * 128 * 128 * 8));
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipMemcpy(A, K.data(), K.size() * 8, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL((k_chol_panel<true>), dim3(14, 1), dim3(256), POTF2_SMEM_BYTES, 0, A, (int64_t)N, (int64_t)0, Linv, (int64_t)N,
+      hipLaunchKernelGGL((k_chol_panel<true>), dim3(14, 1), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, 0, A, (int64_t)N, (int64_t)0, Linv, (int64_t)N,
                          (int64_t)0, 0, 14, info, 128, dg, (int64_t)0, st);
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost));
@@ -71,6 +71,7 @@ int main() {
         ta += h[3 + 3 * p] - h[2 + 3 * p];
         tb += h[4 + 3 * p] - h[3 + 3 * p];
         tc += (p < 7 ? h[5 + 3 * p] : h[26]) - h[4 + 3 * p];
+        if (rep == 1) printf("  panel p%d a=%llu b=%llu\n", p, h[3 + 3 * p] - h[2 + 3 * p], h[4 + 3 * p] - h[3 + 3 * p]);
       }
       printf("chol_panel rep %d (cycles): stage-in %llu | factor a=%llu b=%llu c=%llu | L_kk out %llu | row solve %llu | rows out %llu | total %llu\n",
              rep, h[1] - h[0], ta, tb, tc, h[27] - h[26], h[28] - h[27], h[29] - h[28], h[29] - h[0]);
