@@ -105,7 +105,6 @@ void configure_kernels_once() {
   allow_big_lds(k_potf2<false, false>, POTF2_SMEM_BYTES);
   allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
   allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
-  allow_big_lds(k_chol_step<false>, STEP_SMEM_BYTES);
   allow_big_lds(k_chol_panel<false>, POTF2_SMEM_BYTES);
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
@@ -138,16 +137,14 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, chol_lookahead, lookahead_max_rem, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 1, 39, 300, 4, 1, 2048, 1024, 1};
+    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_CHOL_LEGACY")) v.chol_legacy = std::atoi(e);   // always potf2 / trsm / syrk launches
-    if (const char* e = std::getenv("BOBE_CHOL_LOOKAHEAD")) v.chol_lookahead = std::atoi(e);   // 0: no fused step for B = 1
-    if (const char* e = std::getenv("BOBE_LOOKAHEAD_MAX_REM")) v.lookahead_max_rem = std::atoi(e);
     if (const char* e = std::getenv("BOBE_PAIR_MIN")) v.pair_min = std::atoi(e);   // K = 256 update pairs while B*rem^2 > this (0: never)
     if (const char* e = std::getenv("BOBE_LOCKSTEP_MIN_N")) v.lockstep_min_n = std::atoi(e);
     if (const char* e = std::getenv("BOBE_MLL_SLOTS")) v.mll_slots = std::atoi(e);
@@ -467,48 +464,18 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
 //             k_potf2 + k_trsm_panel pair (one factorisation per slot).
 //   update    A22 -= L21 L21^T on the lower tiles (k_syrk_trail).
 //             Update-bound steps go in pairs: one K = 256 pass for two panels (see the loop).
-// A batch shares the latency-bound panel chain (32 x ~38 us at N = 4096, the same for 1 or 8 matrices) and gives the
-// update 4-8x the tiles: 38 % of the fp64 MFMA peak with four in flight, 47 % with eight, against 17 % alone and 22 %
+// A batch shares the latency-bound panel chain (32 x ~28 us at N = 4096, the same for 1 or 8 matrices) and gives the
+// update 4-8x the tiles: 41 % of the fp64 MFMA peak with four in flight, 49 % with eight, against 18 % alone and 28 %
 // for four on private streams (whose 150 KB-LDS panel kernels wait for a CU the others' update tiles keep occupied).
-// A LONE factorisation (B = 1) takes the one-step lookahead form in its chain-bound steps:
-//   1. k_syrk_trail (colmode 1): block column k receives panel k-1 - the only part of the update panel k waits for;
-//   2. k_chol_step: panel k side by side with the rest of the update by panel k-1, in one launch.
 // Every matrix element sees the same operation sequence in all forms (same bits).
 void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
   const Tuning& tu = tuning();
   if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches
   const int64_t bsD = (int64_t)nb * TILE * TILE;
-  // The one-launch lookahead step is for a LONE factorisation (on an evaluation slot the other slots' kernels share
-  // the chip, and its 1024-thread / 150 KB workgroups would make the update half wait for EMPTY CUs too), and only
-  // for the steps whose update is shorter than the panel chain: its update half runs at 33-36 TFLOP/s against 48 for
-  // the separate launch, which wins from rem ~ 40 blocks up (N = 12288 alone: 35 TFLOP/s with the separate
-  // launches in the early steps, 32 with the lookahead everywhere).
-  const bool can_look = B == 1 && !in_slot && !tu.chol_legacy && tu.chol_lookahead;
-  bool pending = false;                                       // panel k-1 not yet applied right of block column k-1
   int first_aside = nb;                                       // first step whose L_kk was left in the scratch blocks
   for (int k = 0; k < nb; ++k) {
     const int rem = nb - 1 - k;
-    const int nvalid = (int)std::min<int64_t>(TILE, N - (int64_t)k * TILE);
-    const int npanel = rem > 0 ? 2 * rem : 1;                 // 64 rows of the panel per workgroup
-    if (can_look && rem <= tu.lookahead_max_rem) {
-      if (pending) {
-        prof_begin(BOBE_PROF_SYRK);
-        syrk(a, k - 1, k, k, 1, B, bsA);                      // block column k receives panel k-1
-        prof_end(BOBE_PROF_SYRK);
-      }
-      const int n64 = 2 * rem;
-      const int ntiles = pending ? n64 * (n64 + 1) / 2 : 0;   // rest of the update by panel k-1, beside panel k
-      first_aside = std::min(first_aside, k);
-      prof_begin(BOBE_PROF_POTF2);
-      hipLaunchKernelGGL(k_chol_step<false>, dim3(B * npanel + (B * ntiles + 3) / 4), dim3(STEP_THREADS), STEP_SMEM_BYTES,
-                         stream, a, Np, bsA, linv, Np, bsL, k, B, npanel, ntiles, info_dev, nvalid, dg, bsD,
-                         (unsigned long long*)nullptr);
-      prof_end(BOBE_PROF_POTF2);
-      pending = true;
-      continue;
-    }
-    // panel and update as separate launches
-    auto panel = [&](int kk) {
+    auto panel = [&](int kk) {                                // (64 rows of the panel per workgroup)
       const int rr = nb - 1 - kk;
       const int np_ = rr > 0 ? 2 * rr : 1;
       const int nv = (int)std::min<int64_t>(TILE, N - (int64_t)kk * TILE);
@@ -535,8 +502,7 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
     // with both panels (K = 256): half the passes over the trailing matrix and a tile kernel that runs 15 % faster at
     // K = 256 than at 128, for one narrow launch more on the chain.  Same bits (every element still receives panel k
     // before panel k+1).
-    if (!tu.chol_legacy && tu.pair_min > 0 && rem >= 2 && (int64_t)B * rem * rem > tu.pair_min &&
-        !(can_look && rem - 1 <= tu.lookahead_max_rem)) {
+    if (!tu.chol_legacy && tu.pair_min > 0 && rem >= 2 && (int64_t)B * rem * rem > tu.pair_min) {
       panel(k);
       prof_begin(BOBE_PROF_SYRK);
       syrk(a, k, k + 1, k + 1, 1, B, bsA);
@@ -555,7 +521,7 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
       prof_end(BOBE_PROF_SYRK);
     }
   }
-  // (the scratch blocks of a k_chol_panel / k_chol_step step; k_potf2 steps wrote in place, and come first:
+  // (the scratch blocks of the k_chol_panel steps; k_potf2 steps wrote in place, and come first:
   // B * npanel and rem only shrink with k)
   if (first_aside < nb)
     hipLaunchKernelGGL(k_copy_diag, dim3(nb - first_aside, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD,

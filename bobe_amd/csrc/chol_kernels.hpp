@@ -1,11 +1,10 @@
 // Blocked Cholesky, triangular inverse and K^-1/gradient kernels (gfx950).  Included by kernels.hpp.
 //
-// Right-looking blocked Cholesky with NB = 128, one-step lookahead inside a single launch, batched over slots:
-//   k_chol_step    step k of every factorisation of the batch in ONE launch: the panel workgroups factor the
-//                  diagonal block (k,k) in LDS (each one redundantly: no hand-off) and solve their 64 rows of
-//                  block column k, while the other workgroups apply panel k-1 to the trailing tiles right of
-//                  block column k (four 64x64 tiles per 1024-thread workgroup)
-//   k_syrk_trail   A22 -= L21 L21^T on lower tiles; between two steps it brings block column k up to date
+// Right-looking blocked Cholesky with NB = 128, batched over slots:
+//   k_chol_panel   panel k of every factorisation of the batch in ONE launch: every workgroup factors the diagonal
+//                  block (k,k) in LDS (each one redundantly: no hand-off) and solves its 64 rows of block column k
+//                  under the factor's leaves
+//   k_syrk_trail   A22 -= L21 L21^T on lower tiles (one K = 256 pass per two panels where the update dominates)
 //   k_potf2 / k_trsm_panel   the two halves of a panel as separate launches (restore path, diagnostics,
 //                  BOBE_CHOL_LEGACY=1)
 // Every kernel takes the slot of a batch from its last grid dimension and offsets its matrices by a slot stride.
@@ -121,7 +120,7 @@ __device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0
 // Called by the first 256 threads of a workgroup (waves 0..3); colbase = global index of the block's first column
 // (for *info).  Leaves L (lower; the diagonal 16x16 tiles zero-filled above the diagonal) in S and the inverses of
 // the eight diagonal 16x16 sub-blocks in Dall.  Ends with a barrier.
-// NW = waves of the workgroup that take part (4 for the 256-thread kernels, 16 in k_chol_step): wave 0 owns the
+// NW = waves of the workgroup that take part (4 for the 256-thread kernels, 8 in k_chol_panel): wave 0 owns the
 // serial leaf, the others share the deferred updates and the row solves (which tile a wave gets does not change any
 // tile's arithmetic).
 struct NoSideJob {
@@ -449,108 +448,16 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
   BOBE_STAMP(3);
 }
 
-// ---- one step of the batched factorisation: panel k  ||  trailing update with panel k-1 -----------------------
-// Grid (1-D, 1024 threads, STEP_SMEM_BYTES of LDS = one workgroup per CU):
-//   workgroups [0, nbatch*npanel): PANEL.  slot = wg / npanel, pw = wg % npanel, npanel = 2*(nb-1-k), at least 1; only
-//       the first 256 threads stay.
-//       Every panel workgroup stages block (k,k) in LDS and factors it itself (the factor is needed by all of them
-//       and takes as long on one CU as on sixty: recomputing it replaces a kernel boundary and a global round
-//       trip); pw = 0 also writes the 16x16 inverses back and L_kk to a scratch block (see chol_panel_body).  Its
-//       four waves then solve rows
-//       (k+1)*128 + 64*pw + 16*wave .. +15 of block column k exactly like k_trsm_panel (same MFMA sequence, same
-//       bits), reading L_kk and the inverses from the workgroup's LDS; the rows are fetched into registers in
-//       accumulator layout BEFORE the factor loop, so their latency is hidden.
-//       Precondition: block column k is up to date with panels 0..k-1 (the k_syrk_trail colmode-1 launch before).
-//   the other workgroups: TRAILING UPDATE with panel k-1 of the lower 64x64 tiles right of block column k (tiles start
-//       at 128-block k+1; ntiles per slot, nbatch slots): four consecutive tiles per workgroup, one per 256-thread
-//       group with its own 36 KB LDS slice - the per-CU residency of four 256-thread k_syrk_trail<64,16> workgroups.
-//       All groups run the same K loop (K = 128), so the workgroup-wide barriers of gemm_tile line up; a group
-//       without a tile recomputes the last tile and does not store.
-// MEASURED (tools/ubench_upd.hip, profiles/r02_*): four tiles in one 1024-thread workgroup update at 33-36 TFLOP/s,
-// four 256-thread workgroups per CU at 48 - with static or queued tiles, hardware or per-group LDS barriers, either
-// wave-to-group mapping.  The fused step therefore only pays for a LONE factorisation (chain-bound at every step:
-// 1.72 vs 1.94 ms at N = 4096); batches go through the separate launches below, in lock step.
-// The two halves touch disjoint data: the panel writes block column k, the update reads block column k-1 and writes
-// tiles whose column is >= 128 (k+1).  Panel workgroups have the lowest indices, so they are dispatched first and the
-// update fills the CUs they leave (and theirs, once they are done); the launch lasts max(panel chain, update)
-// instead of their sum.
-constexpr int STEP_THREADS = 1024;
-constexpr int STEP_TILE_SMEM_DOUBLES = gemm_smem_doubles_exact<KC, KC, 64, 64, 16>();       // 4608 doubles = 36,864 B
-constexpr int STEP_SMEM_BYTES = POTF2_SMEM_BYTES;                                           // 150,528 B
-static_assert(4 * STEP_TILE_SMEM_DOUBLES * 8 <= STEP_SMEM_BYTES, "four update tiles must fit beside each other");
-
-// Lkk_out: where pw = 0 leaves L_kk (a dense 128 x 128 scratch block, NOT the diagonal block itself: the other panel
-// workgroups of the launch read A_kk whenever they get a CU - on a busy GPU possibly after pw = 0 has finished - so
-// the block must stay intact until the launch is over; k_copy_diag moves the scratch blocks into place afterwards).
-template <bool STAMP>
-__device__ __forceinline__ void chol_panel_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                                int64_t ldl, int k, int pw, bool has_rows, int* __restrict__ info,
-                                                int nvalid, double* __restrict__ Lkk_out,
-                                                unsigned long long* __restrict__ stamps) {
-  extern __shared__ double S[];
-  double* Dall = S + TILE * PLD;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int g = lane >> 4, li = lane & 15;
-  const int nsteps = (nvalid + 15) >> 4;
-  const int64_t col0 = (int64_t)k * TILE;
-  double* Ab = A + col0 * lda + col0;
-  double* Ib = Linv + col0 * ldl + col0;
-  BOBE_STAMP(0);
-  potf2_stage_in(S, Dall, Ab, lda, nsteps);
-  // (keep the block's 64 staging registers and the 64 of X from being live together: 128 VGPRs per thread is all a
-  // 1024-thread workgroup gets)
-  __builtin_amdgcn_sched_barrier(0);
-  // this wave's 16 rows of the panel, straight into transposed-accumulator layout
-  // (lane (li, g), register r of tile p = A[row li][16p + g + 4r]); in flight during the whole factor loop
-  const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)pw * 64 + wave * 16;
-  double* Aw = A + row0 * lda + col0;
-  v4d X[8];
-  if (has_rows) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X[p][r] = Aw[(int64_t)li * lda + 16 * p + g + 4 * r];
-  }
-  __syncthreads();
-  BOBE_STAMP(1);
-  potf2_factor_lds<STAMP, 4>(S, Dall, nsteps, (int)col0, info, stamps);
-  BOBE_STAMP(26);
-  if (pw == 0) potf2_stage_out(S, Dall, Lkk_out, TILE, Ib, ldl);
-  BOBE_STAMP(27);
-  if (!has_rows) return;
-  // X^T_p = invD_p * (A^T_p - sum_{q<p} L_kk[p][q] X^T_q), the MFMA sequence of k_trsm_panel
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    v4d x = X[p];
-#pragma unroll
-    for (int q = 0; q < p; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double av = -S[(16 * p + li) * PLD + 16 * q + g + 4 * r];
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[q][r], x, 0, 0, 0);
-      }
-    v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double av = Dall[(p * 16 + li) * POTF2_DLD + g + 4 * r];
-      y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, x[r], y, 0, 0, 0);
-    }
-    X[p] = y;
-  }
-  __syncthreads();   // every wave is done with L_kk (and pw 0 with writing it back): reuse the block as transposer
-  BOBE_STAMP(28);
-  double* Sw = S + (wave * 16) * PLD;
-#pragma unroll
-  for (int p = 0; p < 8; ++p)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Sw[li * PLD + 16 * p + g + 4 * r] = X[p][r];
-  // (each wave reads back only its own slab: no barrier needed, the wave's LDS accesses are ordered)
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-    *reinterpret_cast<v2d*>(Aw + (int64_t)i * lda + 2 * lane) = *reinterpret_cast<const v2d*>(Sw + i * PLD + 2 * lane);
-  BOBE_STAMP(29);
-}
-
+// ---- panel k of the batched factorisation ------------------------------------------------------------------------
+// Every panel workgroup stages block (k,k) in LDS and factors it itself (the factor is needed by all of them and takes as
+// long on one CU as on sixty: recomputing it replaces a kernel boundary and a global round trip).  L_kk goes to a dense
+// 128 x 128 scratch block, NOT to the diagonal block itself: the workgroups of the launch read A_kk whenever they get a
+// CU - on a busy GPU possibly after others have finished - so the block must stay intact until the launch is over;
+// k_copy_diag moves the scratch blocks into place afterwards.
+// (A fused form - panel k side by side with the rest of the update by panel k-1 in one 1024-thread launch, k_chol_step -
+// served the lone factorisation until the panel below made the separate launches as fast: 1.58 ms either way at
+// N = 4096, 0.63 vs 0.66 ms at 2048; removed.  Its update half ran at 33-36 TFLOP/s against 48 for four 256-thread
+// workgroups per CU, tools/ubench_upd.hip.)
 // The panel as its own launch: EIGHT waves.  Wave 0 is the factor's leaf wave; wave 4 (same SIMD) does nothing while the
 // leaf runs; waves 1, 2, 3, 5, 6, 7 are the helpers of the factor (deferred tile updates), and 1, 2, 3, 5 each own 16 of
 // the workgroup's 64 rows below the block.  The
@@ -706,39 +613,6 @@ __global__ __launch_bounds__(256) void k_copy_diag(double* __restrict__ A, int64
     const int r = 4 * i + wave;
     *reinterpret_cast<v2d*>(dst + (int64_t)r * lda + 2 * lane) = *reinterpret_cast<const v2d*>(src + r * TILE + 2 * lane);
   }
-}
-
-template <bool STAMP = false>
-__global__ __launch_bounds__(STEP_THREADS) void k_chol_step(double* __restrict__ A, int64_t lda, int64_t bsA,
-                                                            double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
-                                                            int nbatch, int npanel, int ntiles,
-                                                            int* __restrict__ info, int nvalid,
-                                                            double* __restrict__ diag, int64_t bsD,
-                                                            unsigned long long* __restrict__ stamps = nullptr) {
-  extern __shared__ double smem[];
-  const int wg = blockIdx.x;
-  if (wg < nbatch * npanel) {
-    if (threadIdx.x >= 256) return;     // (a barrier waits only for the waves still alive)
-    const int slot = wg / npanel, pw = wg - slot * npanel;
-    chol_panel_body<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, pw, npanel > 1, info + slot, nvalid,
-                           diag + slot * bsD + (int64_t)k * TILE * TILE, stamps);
-    return;
-  }
-  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
-  const int total = nbatch * ntiles;
-  int tl = (wg - nbatch * npanel) * 4 + grp;
-  const bool live = tl < total;
-  if (!live) tl = total - 1;
-  const int slot = tl / ntiles;
-  double* As = A + slot * bsA;
-  int a, b;
-  tri_decode(tl - slot * ntiles, a, b);
-  const int64_t base = (int64_t)(k + 1) * TILE;
-  v4d acc[2][2];
-  load_tile<64, 64>(acc, As, lda, base + (int64_t)a * 64, base + (int64_t)b * 64, tid);
-  gemm_tile<KC, KC, 64, 64, 16, true>(acc, As, lda, base + (int64_t)a * 64, As, lda, base + (int64_t)b * 64,
-                                      (int64_t)(k - 1) * TILE, (int64_t)k * TILE, smem + grp * STEP_TILE_SMEM_DOUBLES, tid);
-  if (live) store_tile<64, 64>(acc, As, lda, base + (int64_t)a * 64, base + (int64_t)b * 64, 1.0, 0.0, tid);
 }
 
 // ---- trailing update: A[i][j] -= sum_{k0 <= k < k1} L[i][k] L[j][k]^T over lower T x T tiles ---------------

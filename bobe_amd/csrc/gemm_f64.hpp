@@ -126,12 +126,12 @@ __device__ __forceinline__ void acc_zero(v4d (&acc)[FM][FN]) {
 // acc += A(m0.., k) * B(n0.., k) for k in [kbeg, kend); (kend - kbeg) must be a multiple of BK
 // (K ranges are multiples of 128 for the 128x128 callers and of 64 for the 64x64 callers).
 // smem: gemm_smem_doubles<TM,TN,BK>() doubles.  All 256 threads must call.  `tid` (0..255) is the thread's index
-// inside its 256-thread tile group: threadIdx.x for the one-tile-per-workgroup kernels; k_chol_step runs four tile
+// inside its 256-thread tile group: threadIdx.x for the one-tile-per-workgroup kernels; tools/ubench_upd.hip runs four tile
 // groups in one 1024-thread workgroup (each with its own smem slice; the barriers inside are workgroup-wide, so
 // every group must run the same number of K-steps).
 // NEGA: accumulate -A*B (the A fragment is negated on the way into the MFMA).
 // Barrier policies of gemm_tile.  WgSync: the whole workgroup computes one tile.  GroupSync: the workgroup holds
-// several independent 256-thread tile groups (k_chol_step); a group synchronises its four waves on a counter in
+// several independent 256-thread tile groups (tools/ubench_upd.hip); a group synchronises its four waves on a counter in
 // LDS (release-add, acquire-spin by lane 0 of each wave), so the groups drift apart like separate workgroups do and
 // one group's loads hide behind another's MFMAs.  The spin is bounded; on timeout *failed is set and the caller's
 // results are invalid (reported through the factorisation's info word).

@@ -1,4 +1,4 @@
-"""Correctness + timing of the batched one-launch-per-step Cholesky (k_chol_step) on the GPU box.
+"""Correctness + timing of the batched (lock-step) Cholesky on the GPU box.
 
   * L from bobe_gp_factor against LAPACK on the same K (several N incl. ragged and single-block sizes)
   * bobe_gp_mll_batch (lock-step pipeline) against one-at-a-time bobe_gp_mll: bitwise
