@@ -28,6 +28,7 @@ int main() {
   CK(hipMemset(Linv, 0, K.size() * 8));
   CK(hipMemset(info, 0x7f, 4));
   CK(hipFuncSetAttribute((const void*)k_potf2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_SMEM_BYTES));
+  CK(hipFuncSetAttribute((const void*)k_potf2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_SMEM_BYTES));
   CK(hipFuncSetAttribute((const void*)k_trsm_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_SMEM_BYTES));
   unsigned long long h[64];
   for (int rep = 0; rep < 3; ++rep) {
@@ -75,6 +76,15 @@ int main() {
       }
       printf("chol_panel rep %d (cycles): stage-in %llu | factor a=%llu b=%llu c=%llu | L_kk out %llu | row solve %llu | rows out %llu | total %llu\n",
              rep, h[1] - h[0], ta, tb, tc, h[27] - h[26], h[28] - h[27], h[29] - h[28], h[29] - h[0]);
+    }
+  }
+  {  // block load with the block already in this XCD's L2 (second launch on untouched memory) vs first touch
+    for (int rep = 0; rep < 2; ++rep) {
+      if (rep == 0) CK(hipMemcpy(A, K.data(), K.size() * 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((k_potf2<false, true>), dim3(1), dim3(256), POTF2_SMEM_BYTES, 0, A, (int64_t)N, Linv, (int64_t)N, 0, info, st);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost));
+      printf("block load (128 KB through registers into LDS, 4 waves), %s: %llu cycles\n", rep ? "again (L2 / MALL hot)" : "after a host upload", h[1] - h[0]);
     }
   }
   printf("potf2 wall %.2f us per launch (back-to-back)\n", ms * 1e3 / 20);
