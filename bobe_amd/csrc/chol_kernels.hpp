@@ -52,7 +52,7 @@ __device__ __forceinline__ void block_store_lower(const double* S, double* __res
 // diagnostic cycle stamps (template-disabled in the production instantiations)
 #define BOBE_STAMP(idx)                                                        \
   do {                                                                         \
-    if (STAMP && threadIdx.x == 0) stamps[(idx)] = __builtin_amdgcn_s_memtime(); \
+    if (STAMP && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) stamps[(idx)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
 // 1/sqrt(a): hardware estimate + two Newton steps (error ~1 ulp); NaN for a < 0, +inf for a = 0.
@@ -483,6 +483,7 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
   BOBE_STAMP(0);
   potf2_stage_in<8>(S, Dall, Ab, lda, nsteps);
   __builtin_amdgcn_sched_barrier(0);
+
   // solver wave (1, 2, 3, 5 = strip 0..3): rows (k+1)*128 + 64*pw + 16*strip .. +15 of block column k, straight into
   // transposed-accumulator layout (lane (li, g), register r of tile p = A[row li][16p + g + 4r]); in flight during the
   // first factor steps
@@ -497,7 +498,9 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
 #pragma unroll
       for (int r = 0; r < 4; ++r) X[p][r] = Aw[(int64_t)li * lda + 16 * p + g + 4 * r];
   }
-  __syncthreads();
+  // (a raw barrier behind a wait for the LDS writes only: __syncthreads() would also wait for vmcnt(0), i.e. for the 32
+  // scattered loads of X just issued - 6 k cycles that are meant to pass under the first leaf)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   BOBE_STAMP(1);
   // sub-block p in two parts: accumulate<p> (x = A^T_p - sum_{q<p} L_kk[p][q] X^T_q: needs the factor's steps < p only)
   // and finish<p> (X^T_p = invD_p x: needs leaf p).  Every LDS operand of a part is read first (one latency for all).
