@@ -1,5 +1,6 @@
 """Snapshot / compare the bits of factorisation-dependent outputs (before/after a kernel change that must not move them).
-   python tools/bits_snapshot.py save|check FILE"""
+   python tools/bits_snapshot.py save|check FILE        (BITS_MAX_N=1500 skips the large sizes; `print` writes the digests
+   as one JSON line to stdout)"""
 import os
 import sys
 
@@ -9,7 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bobe_amd.gp import GP  # noqa: E402
 
 out = {}
+MAX_N = int(os.environ.get("BITS_MAX_N", 1 << 30))
 for N, d, kern in ((17, 2, "rbf"), (100, 3, "matern"), (129, 4, "rbf"), (641, 5, "rbf"), (1500, 8, "matern"), (2048, 8, "rbf"), (4096, 8, "rbf")):
+    if N > MAX_N:
+        continue
     rng = np.random.default_rng(N)
     X = rng.uniform(size=(N, d))
     y = np.sin(X.sum(1)) + 0.1 * rng.normal(size=N)
@@ -26,7 +30,9 @@ for N, d, kern in ((17, 2, "rbf"), (100, 3, "matern"), (129, 4, "rbf"), (641, 5,
 import hashlib
 import json
 out = {k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for k, v in out.items()}
-if sys.argv[1] == "save":
+if sys.argv[1] == "print":
+    print(json.dumps(out))
+elif sys.argv[1] == "save":
     json.dump(out, open(sys.argv[2], "w"), indent=0)
     print("saved", len(out), "digests")
 else:
