@@ -72,7 +72,10 @@ __global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t
   out += blockIdx.y * bsO;
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= npad) return;
-  for (int j = 0; j < h.d; ++j) out[j * ldo + i] = (i < n) ? in[i * h.d + j] / h.ls[j] : 0.0;
+  // (constant indices into h.ls: a runtime index would send the by-value struct through scratch memory)
+#pragma unroll
+  for (int j = 0; j < MAX_D; ++j)
+    if (j < h.d) out[j * ldo + i] = (i < n) ? in[i * h.d + j] / h.ls[j] : 0.0;
 }
 
 // ---- kernel-matrix assembly ---------------------------------------------------------------
