@@ -305,7 +305,7 @@ struct bobe_gp {
   // Batched forms (B > 1): slot b of a batch works on base + b * stride of every matrix / vector it is given and
   // reads its hyper-parameters from hdev[b]; B = 1 with zero strides is the plain call.
   void scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo,
-             const Hyper* hdev = nullptr, int B = 1, int64_t bsO = 0);
+             const Hyper* hdev = nullptr, int B = 1, int64_t bsO = 0, int* info_reset = nullptr);
   void kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT, int64_t ldb,
                            int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo);
   void assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev = nullptr, int B = 1,
@@ -386,9 +386,9 @@ void bobe_gp::alloc_for_n() {
 }
 
 void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo,
-                    const Hyper* hdev, int B, int64_t bsO) {
+                    const Hyper* hdev, int B, int64_t bsO, int* info_reset) {
   hipLaunchKernelGGL(k_scale_coords, dim3((unsigned)((npad + 255) / 256), (unsigned)B), dim3(256), 0, stream, in, n, npad,
-                     h, out, ldo, hdev, bsO);
+                     h, out, ldo, hdev, bsO, info_reset);
   LAUNCH_CHECK();
 }
 
@@ -603,9 +603,8 @@ void bobe_gp::solve_alpha(const double* linv, double* wv, double* al, double* pr
 
 void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al,
                           const Hyper* hdev) {
-  scale(X.d(), N, Np, h, xst, Np, hdev);
+  scale(X.d(), N, Np, h, xst, Np, hdev, 1, 0, static_cast<int*>(info.p));
   assemble_kxx(h, xst, a, hdev);
-  HIPCHK(hipMemsetAsync(info.p, 0x7f, sizeof(int), stream));
   potrf(a, linv, static_cast<int*>(info.p));
   trtri(a, linv, Tmp.d());
   solve_alpha(linv, wv, al, part.d());
@@ -668,7 +667,7 @@ void bobe_gp::mll_enqueue_body(const Hyper& h, bool want_grad, const Hyper* hdev
   if (hdev) HIPCHK(hipMemcpyAsync(eg.hyp_dev.p, eg.h_hyp, sizeof(Hyper), hipMemcpyHostToDevice, stream));
   factor_into(h, XsT2.d(), A2.d(), Linv2.d(), w2.d(), alpha2.d(), hdev);
   hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w2.d(), (const double*)A2.d(), Np, Np,
-                     res.d());
+                     res.d(), (int64_t)0, (int64_t)0, (int64_t)0, (const int*)info.p);
   if (want_grad) {
     const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
     const int ntiles = lauum(h, Linv2.d(), alpha2.d(), XsT2.d(), nullptr, dcap, hdev);
@@ -676,8 +675,7 @@ void bobe_gp::mll_enqueue_body(const Hyper& h, bool want_grad, const Hyper* hdev
                        dcap, res.d() + 2);
   }
   LAUNCH_CHECK();
-  HIPCHK(hipMemcpyAsync(h_res, res.p, (size_t)(3 + d) * sizeof(double), hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipMemcpyAsync(h_res + 100, info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(h_res, res.p, 101 * sizeof(double), hipMemcpyDeviceToHost, stream));   // [100] = info (k_mll_terms)
 }
 
 void bobe_gp::mll_enqueue(const Hyper& h, bool want_grad) {

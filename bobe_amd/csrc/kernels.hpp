@@ -67,10 +67,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Batched launches: blockIdx.y = slot picks hp[slot] and offsets `out` by bsO doubles per slot.
 __global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t npad, Hyper h,
                                double* __restrict__ out, int64_t ldo, const Hyper* __restrict__ hp = nullptr,
-                               int64_t bsO = 0) {
+                               int64_t bsO = 0, int* __restrict__ info_reset = nullptr) {
   if (hp) h = hp[blockIdx.y];
   out += blockIdx.y * bsO;
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // (first kernel of an evaluation: it also arms the factorisation's info word - one memset launch less)
+  if (info_reset && i == 0) info_reset[blockIdx.y] = 0x7f7f7f7f;
   if (i >= npad) return;
   // (constant indices into h.ls: a runtime index would send the by-value struct through scratch memory)
 #pragma unroll
@@ -320,10 +322,13 @@ __global__ void k_colsum_parts(const double* __restrict__ part, int64_t ldp, int
 // res[0] = sum_i w_i^2 ; res[1] = sum_i log L_ii        (single workgroup, fixed order)
 __global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
                                                    int64_t np, double* __restrict__ res, int64_t bsW = 0,
-                                                   int64_t bsL = 0, int64_t bsR = 0) {
+                                                   int64_t bsL = 0, int64_t bsR = 0,
+                                                   const int* __restrict__ info = nullptr) {
   w += blockIdx.x * bsW;      // batched: blockIdx.x = slot
   L += blockIdx.x * bsL;
   res += blockIdx.x * bsR;
+  // (the factorisation's info word rides along in res[100], so that one copy brings everything to the host)
+  if (info && threadIdx.x == 0) reinterpret_cast<int*>(res + 100)[0] = info[blockIdx.x];
   __shared__ double r0[4], r1[4];
   double a = 0.0, b = 0.0;
   for (int64_t i = threadIdx.x; i < np; i += 256) {
