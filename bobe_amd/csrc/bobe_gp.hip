@@ -666,13 +666,14 @@ const std::vector<hipStream_t>& bobe_gp::slot_stream_set() {
 void bobe_gp::mll_enqueue_body(const Hyper& h, bool want_grad, const Hyper* hdev) {
   if (hdev) HIPCHK(hipMemcpyAsync(eg.hyp_dev.p, eg.h_hyp, sizeof(Hyper), hipMemcpyHostToDevice, stream));
   factor_into(h, XsT2.d(), A2.d(), Linv2.d(), w2.d(), alpha2.d(), hdev);
-  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w2.d(), (const double*)A2.d(), Np, Np,
-                     res.d(), (int64_t)0, (int64_t)0, (int64_t)0, (const int*)info.p);
   if (want_grad) {
     const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
     const int ntiles = lauum(h, Linv2.d(), alpha2.d(), XsT2.d(), nullptr, dcap, hdev);
-    hipLaunchKernelGGL(k_grad_reduce, dim3(d + 1), dim3(64), 0, stream, (const double*)gpart.d(), ntiles, dcap + 1, d,
-                       dcap, res.d() + 2);
+    hipLaunchKernelGGL(k_mll_grad_reduce, dim3(d + 2), dim3(256), 0, stream, (const double*)gpart.d(), ntiles, dcap + 1, d,
+                       dcap, res.d(), (const double*)w2.d(), (const double*)A2.d(), Np, Np, (const int*)info.p);
+  } else {
+    hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w2.d(), (const double*)A2.d(), Np, Np,
+                       res.d(), (int64_t)0, (int64_t)0, (int64_t)0, (const int*)info.p);
   }
   LAUNCH_CHECK();
   HIPCHK(hipMemcpyAsync(h_res, res.p, 101 * sizeof(double), hipMemcpyDeviceToHost, stream));   // [100] = info (k_mll_terms)

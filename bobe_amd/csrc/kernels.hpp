@@ -320,15 +320,14 @@ __global__ void k_colsum_parts(const double* __restrict__ part, int64_t ldp, int
 
 // ---- scalar reductions ------------------------------------------------------------------------------
 // res[0] = sum_i w_i^2 ; res[1] = sum_i log L_ii        (single workgroup, fixed order)
-__global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
-                                                   int64_t np, double* __restrict__ res, int64_t bsW = 0,
-                                                   int64_t bsL = 0, int64_t bsR = 0,
-                                                   const int* __restrict__ info = nullptr) {
-  w += blockIdx.x * bsW;      // batched: blockIdx.x = slot
-  L += blockIdx.x * bsL;
-  res += blockIdx.x * bsR;
+__device__ __forceinline__ void mll_terms_body(int slot, const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
+                                                   int64_t np, double* __restrict__ res, int64_t bsW,
+                                                   int64_t bsL, int64_t bsR, const int* __restrict__ info) {
+  w += slot * bsW;      // batched: blockIdx.x = slot
+  L += slot * bsL;
+  res += slot * bsR;
   // (the factorisation's info word rides along in res[100], so that one copy brings everything to the host)
-  if (info && threadIdx.x == 0) reinterpret_cast<int*>(res + 100)[0] = info[blockIdx.x];
+  if (info && threadIdx.x == 0) reinterpret_cast<int*>(res + 100)[0] = info[slot];
   __shared__ double r0[4], r1[4];
   double a = 0.0, b = 0.0;
   for (int64_t i = threadIdx.x; i < np; i += 256) {
@@ -347,6 +346,12 @@ __global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w,
     res[1] = ((r1[0] + r1[1]) + r1[2]) + r1[3];
   }
 }
+__global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
+                                                   int64_t np, double* __restrict__ res, int64_t bsW = 0,
+                                                   int64_t bsL = 0, int64_t bsR = 0,
+                                                   const int* __restrict__ info = nullptr) {
+  mll_terms_body((int)blockIdx.x, w, L, ld, np, res, bsW, bsL, bsR, info);      // batched: blockIdx.x = slot
+}
 
 // res[j] = 0.5 * sum_tiles partial[tile*stride + src(j)]: one wave per component, lane-strided partial
 // sums combined by a fixed butterfly (deterministic).  grid = d+1 blocks of 64 threads.
@@ -361,6 +366,24 @@ __global__ __launch_bounds__(64) void k_grad_reduce(const double* __restrict__ p
   for (int q = threadIdx.x; q < ntiles; q += 64) s += partial[(int64_t)q * stride + src];
   s = wave_sum(s);
   if (threadIdx.x == 0) res[j] = 0.5 * s;
+}
+// the two reductions that end an evaluation in ONE launch (single matrix): workgroups 0..d are k_grad_reduce's (their
+// first wave, same order of summation), workgroup d+1 is k_mll_terms
+__global__ __launch_bounds__(256) void k_mll_grad_reduce(const double* __restrict__ partial, int ntiles, int stride, int d,
+                                                         int dcap, double* __restrict__ res,
+                                                         const double* __restrict__ w, const double* __restrict__ L,
+                                                         int64_t ld, int64_t np, const int* __restrict__ info) {
+  if ((int)blockIdx.x == d + 1) {
+    mll_terms_body(0, w, L, ld, np, res, 0, 0, 0, info);
+    return;
+  }
+  if (threadIdx.x >= 64) return;
+  const int j = blockIdx.x;
+  const int src = (j == d) ? dcap : j;
+  double s = 0.0;
+  for (int q = threadIdx.x; q < ntiles; q += 64) s += partial[(int64_t)q * stride + src];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) res[2 + j] = 0.5 * s;
 }
 
 // ---- sweep finalisers -------------------------------------------------------------------------------
