@@ -311,8 +311,12 @@ struct bobe_gp {
   void assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev = nullptr, int B = 1,
                     int64_t bsX = 0, int64_t bsA = 0);
   void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0);
-  void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0, double* dg = nullptr);
-  void trtri(const double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
+  // defer_diag: leave the L_kk scratch blocks where they are; the trtri() that follows puts them in place (one launch less)
+  void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0, double* dg = nullptr,
+             bool defer_diag = false);
+  int aside_first = 1 << 30;       // set by potrf(defer_diag = true), consumed by the next trtri()
+  const double* aside_dg = nullptr;
+  void trtri(double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
   int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
             const Hyper* hdev = nullptr, double* gp_out = nullptr, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
             int64_t bsX = 0, int64_t bsP = 0);
@@ -468,7 +472,7 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
 // update 4-8x the tiles: 41 % of the fp64 MFMA peak with four in flight, 49 % with eight, against 18 % alone and 28 %
 // for four on private streams (whose 150 KB-LDS panel kernels wait for a CU the others' update tiles keep occupied).
 // Every matrix element sees the same operation sequence in all forms (same bits).
-void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg) {
+void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg, bool defer_diag) {
   const Tuning& tu = tuning();
   if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches
   const int64_t bsD = (int64_t)nb * TILE * TILE;
@@ -523,17 +527,28 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
   }
   // (the scratch blocks of the k_chol_panel steps; k_potf2 steps wrote in place, and come first:
   // B * npanel and rem only shrink with k)
-  if (first_aside < nb)
-    hipLaunchKernelGGL(k_copy_diag, dim3(nb - first_aside, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD,
-                       first_aside);
+  aside_first = 1 << 30;
+  aside_dg = nullptr;
+  if (first_aside < nb) {
+    if (defer_diag) {
+      aside_first = first_aside;
+      aside_dg = dg;
+    } else {
+      hipLaunchKernelGGL(k_copy_diag, dim3(nb - first_aside, B), dim3(256), 0, stream, a, Np, bsA, (const double*)dg, bsD,
+                         first_aside);
+    }
+  }
   LAUNCH_CHECK();
 }
 
 // Linv = L^-1: diagonal 128-blocks in one batched launch, then recursive doubling (two GEMM launches per level)
-void bobe_gp::trtri(const double* a, double* linv, double* tmp, int B, int64_t bsA, int64_t bsL, int64_t bsT) {
+void bobe_gp::trtri(double* a, double* linv, double* tmp, int B, int64_t bsA, int64_t bsL, int64_t bsT) {
   const Tuning& tu = tuning();
   prof_begin(BOBE_PROF_TRTRI);
-  hipLaunchKernelGGL(k_trti_diag, dim3(nb, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, bsA, bsL);
+  hipLaunchKernelGGL(k_trti_diag, dim3(nb, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, bsA, bsL, aside_dg,
+                     (int64_t)nb * TILE * TILE, aside_first);
+  aside_first = 1 << 30;
+  aside_dg = nullptr;
   prof_end(BOBE_PROF_TRTRI);
   for (int dd = (int)depths.size() - 1; dd >= 0; --dd) {
     const Depth& D = depths[dd];
@@ -605,7 +620,7 @@ void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, 
                           const Hyper* hdev) {
   scale(X.d(), N, Np, h, xst, Np, hdev, 1, 0, static_cast<int*>(info.p));
   assemble_kxx(h, xst, a, hdev);
-  potrf(a, linv, static_cast<int*>(info.p));
+  potrf(a, linv, static_cast<int*>(info.p), 1, 0, 0, nullptr, true);
   trtri(a, linv, Tmp.d());
   solve_alpha(linv, wv, al, part.d());
 }
@@ -789,7 +804,7 @@ void bobe_gp::mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad) {
   scale(X.d(), N, Np, hs[0], bw.XsT.d(), Np, hdev, B, xs);
   assemble_kxx(hs[0], bw.XsT.d(), bw.A.d(), hdev, B, xs, mat);
   HIPCHK(hipMemsetAsync(inf, 0x7f, (size_t)B * sizeof(int), stream));
-  potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat, bw.diag.d());
+  potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat, bw.diag.d(), true);
   trtri(bw.A.d(), bw.Linv.d(), bw.Tmp.d(), B, mat, mat, mat);
   solve_alpha(bw.Linv.d(), bw.w.d(), bw.alpha.d(), bw.part.d(), B, mat, vec, prt);
   hipLaunchKernelGGL(k_mll_terms, dim3(B), dim3(256), 0, stream, (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np,

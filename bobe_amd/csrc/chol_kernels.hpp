@@ -297,17 +297,26 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t l
 // ---- inverse of every diagonal 128x128 block (grid = nb) --------------------------------------------
 // in: L[blk][blk] (lower) and the 16x16 diagonal inverses left in Linv[blk][blk] by k_potf2.
 // out: Linv[blk][blk] = L[blk][blk]^-1 (lower, zeros above).
-__global__ __launch_bounds__(256) void k_trti_diag(const double* __restrict__ L, int64_t lda,
+// diag / first_aside: the factorisation left the L_kk of blocks >= first_aside in its scratch blocks (k_chol_panel); they
+// are read from there and put in place on the way (what k_copy_diag does when no inverse follows the factorisation).
+__global__ __launch_bounds__(256) void k_trti_diag(double* __restrict__ L, int64_t lda,
                                                    double* __restrict__ Linv, int64_t ldl, int64_t bsA = 0,
-                                                   int64_t bsL = 0) {
+                                                   int64_t bsL = 0, const double* __restrict__ diag = nullptr,
+                                                   int64_t bsD = 0, int first_aside = 1 << 30) {
   extern __shared__ double S[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int blk = blockIdx.x;
   L += blockIdx.y * bsA;
   Linv += blockIdx.y * bsL;
-  const double* Lb = L + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
+  double* Lb = L + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
   double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
-  block_load(S, Lb, lda);
+  if (diag && blk >= first_aside) {
+    block_load(S, diag + blockIdx.y * bsD + (int64_t)blk * TILE * TILE, TILE);
+    __syncthreads();
+    block_store_lower(S, Lb, lda);
+  } else {
+    block_load(S, Lb, lda);
+  }
   __syncthreads();
   if (t < 128) {   // overwrite the diagonal 16x16 sub-blocks with their inverses
     const int bb = t >> 4, col = t & 15, o = 16 * bb;
