@@ -23,7 +23,11 @@ status; under torchrun it insists that WORLD_SIZE == N.
         (np.array_split bounds), the fit's 4 restarts split over the ranks the way the reference's MPI pool splits
         them (BOBE/pool.py:298-326); value = cycles / wall time.
 Either way the ranks exchange (min score, global index) with one all-gather per sweep and (best mll, theta) with one
-per fit.
+per fit: through torch.distributed (default) or, with ``--exchange rccl``, through the C ABI's own entry points
+(bobe_mgpu_wip_sweep = shard sweep + ncclAllGather + merge in one call, bobe_mgpu_best_fit).
+With N > 1 in the weak mode the line also carries a ``shard`` sub-record: after the weak timed region the same ranks time
+the STRONG config-4 cycle (262 144 candidates and the fit's restarts split N ways) - what the scaling curve of the weak
+mode, N independent cycles, cannot say.  ``--no-secondary``: timed cycles only (for kernel traces that read per cycle).
 
 Prints ONE JSON line (rank 0).
 """
@@ -55,6 +59,10 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="headline", choices=["tiny", "small", "headline", "large", "shard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="only the timed cycles: no phase timers, Cholesky timers, L-BFGS fit or CPU baseline afterwards "
+                         "(a rocprofv3 kernel trace of such a run reads per cycle)")
+    ap.add_argument("--no-shard-record", action="store_true", help="N > 1, weak mode: skip the strong config-4 sub-record")
     ap.add_argument("--profile-class", default="trimul", help="kernel class timed with HIP events for the roofline")
     ap.add_argument("--fit-concurrency", type=int, default=4, help="restarts of the fit in flight together (1 = sequential)")
     ap.add_argument("--fit-mode", default="slots", choices=["slots", "batch"],
@@ -169,21 +177,13 @@ def main():
     dev = torch.device("cuda", local)
     coll_dev = dev if args.backend == "nccl" else None   # where the all-gather payload lives
     from bobe_amd.dist_sweep import merge_argmin, merge_best_fit, shard_bounds
-    if args.exchange == "rccl":                        # the C ABI's exchange step instead of torch's collectives
+    use_rccl = args.exchange == "rccl"                 # the C ABI's exchange step instead of torch's collectives
+    if use_rccl:
         from bobe_amd import mgpu
         mgpu.init_from_torch(local)
 
-        def merge_argmin(score, gidx, device=None):                    # noqa: F811
-            mine = np.array([score, 0.0])
-            mine[1:].view(np.int64)[0] = gidx
-            # (one (score, index) pair through the same all-gather + merge bobe_mgpu_wip_sweep uses)
-            best, th = mgpu.best_fit(-score if np.isfinite(score) else -np.inf, mine)
-            return float(th[0]), int(th[1:].view(np.int64)[0])
-
-        def merge_best_fit(mll_, theta_, device=None):                 # noqa: F811
-            return mgpu.best_fit(mll_, theta_)
-
     strong = args.config == "shard"
+    from bobe_amd.synthetic import sobol_candidates
     if strong:
         N, d, _, M = CONFIGS["headline"]
         c_total = int(args.shard_candidates)
@@ -200,13 +200,18 @@ def main():
     lib, h = gp._lib, gp._h
     if args.chunk:
         _lib.check(lib.bobe_gp_set_chunk(h, args.chunk), "set_chunk")
-    # inputs resident in HBM; outputs stay in HBM
-    cand_d = torch.from_numpy(cand).to(dev)
     Z_d = torch.from_numpy(Z).to(dev)
-    out_mean = torch.empty(Cn, dtype=torch.float64, device=dev)
-    out_var = torch.empty_like(out_mean)
-    out_wipv = torch.empty_like(out_mean)
-    out_wipstd = torch.empty_like(out_mean)
+
+    def make_work(cand_np, lo, total):
+        """a candidate set resident in HBM with its output vectors (which stay in HBM)"""
+        n = cand_np.shape[0]
+        w = {"cand": torch.from_numpy(cand_np).to(dev), "n": n, "lo": lo, "total": total}
+        for k in ("mean", "var", "wipv", "wipstd"):
+            w[k] = torch.empty(max(n, 1), dtype=torch.float64, device=dev)
+        return w
+    work = make_work(cand, c_lo, c_total)
+    Cn = work["n"]
+    out_wipstd = work["wipstd"]
     torch.cuda.synchronize()
 
     ls_last = np.ascontiguousarray(np.exp(thetas[-1, :d]))
@@ -218,7 +223,8 @@ def main():
 
     R_total = max(1, args.fit_concurrency)              # restarts of the fit (= evaluations in flight on one GPU)
     # restarts this rank runs: all of them (weak: its own fit), or its np.array_split share (strong: pool.py:298-326)
-    my_restarts = list(range(R_total)) if not strong else list(range(*shard_bounds(R_total, world, rank)))
+    restart_share = list(range(*shard_bounds(R_total, world, rank)))
+    my_restarts = list(range(R_total)) if not strong else restart_share
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, R_total))
     ls_all = np.ascontiguousarray(np.exp(thetas[:, :d]))
@@ -264,19 +270,47 @@ def main():
 
     fit_mode = "sequential" if R_total == 1 else args.fit_mode
 
-    def cycle():
-        best = fit_evals(my_restarts, fit_mode)
+    def local_sweep(w):
+        _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(w["cand"]), w["n"], _lib.ptr(Z_d), M, 1.0, _lib.ptr(w["wipv"]),
+                                         _lib.ptr(w["wipstd"]), _lib.ptr(w["mean"]), _lib.ptr(w["var"]),
+                                         C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
+
+    def cycle(w=None, restarts=None, phase=None):
+        """one cycle on candidate set ``w`` with the fit's ``restarts`` on this rank; ``phase`` collects wall times"""
+        w = work if w is None else w
+        restarts = my_restarts if restarts is None else restarts
+        t_0 = time.perf_counter()
+        best = fit_evals(restarts, fit_mode if len(restarts) > 1 else "sequential")
+        t_1 = time.perf_counter()
         _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")
         _lib.check(lib.bobe_gp_factor(h), "factor")
-        _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
-                                         _lib.ptr(out_wipstd), _lib.ptr(out_mean), _lib.ptr(out_var),
-                                         C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
+        t_2 = time.perf_counter()
         # the path's exchange step: one all-gather of (min score, global index) — lowest global index wins
         # ties (jnp.argmin) — and one of (best mll, theta) for the restart-sharded fit (pool.py:322-326)
-        gmin, gidx = merge_argmin(ms.value, c_lo + asd.value, device=coll_dev)
-        bmll, bth = merge_best_fit(best[0], best[1], device=coll_dev)
+        if use_rccl:
+            # the shipped entry point: shard sweep + ncclAllGather + merge inside the library
+            _lib.check(lib.bobe_mgpu_wip_sweep(h, _lib.ptr(w["cand"]) if w["n"] else None, w["n"], w["lo"], _lib.ptr(Z_d), M, 1.0,
+                                               _lib.ptr(w["wipv"]), _lib.ptr(w["wipstd"]), _lib.ptr(w["mean"]),
+                                               _lib.ptr(w["var"]), C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)),
+                       "mgpu_wip_sweep")
+            t_3 = time.perf_counter()
+            gmin, gidx = ms.value, asd.value
+            bmll, bth = mgpu.best_fit(best[0], best[1])
+        else:
+            if w["n"]:
+                local_sweep(w)
+                loc = (ms.value, w["lo"] + asd.value)
+            else:
+                loc = (float("inf"), 2 ** 52)                          # a rank without candidates never wins
+            t_3 = time.perf_counter()
+            gmin, gidx = merge_argmin(loc[0], loc[1], device=coll_dev)
+            bmll, bth = merge_best_fit(best[0], best[1], device=coll_dev)
+        t_4 = time.perf_counter()
+        if phase is not None:
+            for k_, v_ in (("fit", t_1 - t_0), ("refactor", t_2 - t_1), ("sweep", t_3 - t_2), ("exchange", t_4 - t_3)):
+                phase[k_] = phase.get(k_, 0.0) + v_
         if os.environ.get("BENCH_DEBUG"):
-            print(f"[rank {rank}] restarts {my_restarts} local best {best[0]!r} merged {bmll!r} mll_b {np.round(mll_b, 3).tolist()}",
+            print(f"[rank {rank}] restarts {restarts} local best {best[0]!r} merged {bmll!r} mll_b {np.round(mll_b, 3).tolist()}",
                   file=sys.stderr, flush=True)
         last.update(best_mll=float(bmll), argmin=int(gidx), min_wipstd=float(gmin))
 
@@ -304,6 +338,34 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- N > 1, weak mode: the same ranks now time the STRONG config-4 cycle (candidates and restarts split N ways)
+    shard_rec = None
+    weak_check = dict(last)
+    if world > 1 and not strong and not args.no_shard_record:
+        s_total = int(args.shard_candidates)
+        s_lo, s_hi = shard_bounds(s_total, world, rank)
+        swork = make_work(sobol_candidates(d, s_hi - s_lo, s_lo), s_lo, s_total)
+        cycle(swork, restart_share)                                        # untimed: workspace growth, first touch
+        barrier()
+        ph = {}
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            cycle(swork, restart_share, ph)
+        barrier()
+        s_el = time.perf_counter() - t1
+        vals = torch.tensor([s_el, ph["fit"], ph["refactor"], ph["sweep"], ph["exchange"]], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)                        # the slowest rank sets each figure
+        vals = (vals / args.steps * 1e3).tolist()
+        shard_rec = {"workload": f"N={N} d={d}, {s_total} candidates split over {world} GPUs, the fit's {R_total} restarts "
+                                 f"split over the ranks (BASELINE.json configs[3])",
+                     "scaling": "strong", "cycles_per_s": 1e3 / vals[0], "ms_per_cycle": vals[0], "fit_ms": vals[1],
+                     "refactor_ms": vals[2], "sweep_ms": vals[3], "exchange_ms": vals[4], "candidates_total": s_total,
+                     "candidates_per_gpu": s_hi - s_lo, "restarts_rank0": restart_share, "steps": args.steps,
+                     "check": dict(last),
+                     "note": "max over ranks per phase; with --exchange rccl the sweep's all-gather is inside sweep_ms "
+                             "(bobe_mgpu_wip_sweep) and exchange_ms is bobe_mgpu_best_fit alone"}
+        del swork
+
     def timed(fn, reps=2):
         fn()
         lib.bobe_gp_sync(h)
@@ -313,8 +375,9 @@ def main():
         lib.bobe_gp_sync(h)
         return (time.perf_counter() - t1) * 1e3 / reps
 
+    secondary = rank == 0 and not args.no_secondary
     fit_ms, sub_ms, lbfgs, gpu_check = {}, {}, None, None
-    if rank == 0:               # secondary measurements, outside the timed region: the three phases of a cycle on rank 0
+    if secondary:               # secondary measurements, outside the timed region: the three phases of a cycle on rank 0
         all_r = list(range(R_total))
         fit_ms["sequential"] = timed(lambda: fit_evals(all_r, "sequential"), 1)
         if R_total > 1:
@@ -327,12 +390,8 @@ def main():
             _lib.check(lib.bobe_gp_set_hyper(h, _lib.ptr(ls_last), kv_last, noise), "set_hyper")
             _lib.check(lib.bobe_gp_factor(h), "factor")
 
-        def sweep():
-            _lib.check(lib.bobe_gp_wip_sweep(h, _lib.ptr(cand_d), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(out_wipv),
-                                             _lib.ptr(out_wipstd), _lib.ptr(out_mean), _lib.ptr(out_var),
-                                             C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
         key = "sequential" if R_total == 1 else (f"slots_{R_total}" if args.fit_mode == "slots" else f"lockstep_{R_total}")
-        sub_ms = {"fit": fit_ms[key], "refactor": timed(refactor), "sweep": timed(sweep)}
+        sub_ms = {"fit": fit_ms[key], "refactor": timed(refactor), "sweep": timed(lambda: local_sweep(work))}
         gpu_check = {"mll0": float(mll_b[0]), "grad0": grad_b[0].copy(), "wipstd": out_wipstd.cpu().numpy()}
         if args.config not in ("tiny",):
             # GP.fit as the BO loop calls it for N >= 750 (bo.py:651-653): 4 restarts (pool.py:277-286 recipe), maxiter 200
@@ -352,20 +411,6 @@ def main():
             lbfgs = {"restarts": 4, "maxiter": 200, "seconds": t5 - t4, "evaluations": calls[0],
                      "ms_per_evaluation": (t5 - t4) * 1e3 / max(calls[0], 1), "mll": float(r_fit["mll"])}
     if rank == 0:
-        # Cholesky: mean device time of the factorisation alone (HIP events on the handle's stream): a lone one, B
-        # advancing in lock step through one batched launch sequence, and (round 1's form) B on private streams
-        chol = {}
-        ms_ = C.c_double()
-        _lib.check(lib.bobe_debug_time_potrf(h, 10, C.byref(ms_)), "time_potrf")
-        potrf_ms = ms_.value
-        flops_potrf = N ** 3 / 3.0
-        for B in (4, 8):
-            _lib.check(lib.bobe_debug_time_potrf_lockstep(h, B, 10, C.byref(ms_)), "time_potrf_lockstep")
-            chol[f"lockstep_{B}"] = {"in_flight": B, "ms_all": ms_.value, "gflops": B * flops_potrf / (ms_.value * 1e-3) / 1e9,
-                                     "frac_of_fp64_mfma_peak": B * flops_potrf / (ms_.value * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
-        _lib.check(lib.bobe_debug_time_potrf_batch(h, 4, 10, C.byref(ms_)), "time_potrf_batch")
-        chol["streams_4"] = {"in_flight": 4, "ms_all": ms_.value, "gflops": 4 * flops_potrf / (ms_.value * 1e-3) / 1e9,
-                             "frac_of_fp64_mfma_peak": 4 * flops_potrf / (ms_.value * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
         chunk = args.chunk or 8192
         # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 per candidate, triangular) fused with
         # the cross-covariance rows W_Z^T K(X,C) (2 N M per candidate)
@@ -386,14 +431,29 @@ def main():
                     "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(launches.value),
                     "flops_per_launch": flops_per_launch,
                     "note": "largest single kernel of the cycle by time (the sweep's GEMM); the fit phase is priced in roofline_fit"}
-        # the fit phase as a whole: 20 value+gradient evaluations = 20 N^3 flops (potrf N^3/3 + inverse N^3/3 + K^-1/gradient N^3/3)
-        fit_s = sub_ms["fit"] * 1e-3
-        fit_ach = len(thetas) * float(N) ** 3 / fit_s / 1e12
-        roof_fit = {"bound": "mfma", "phase": f"fit: {len(thetas)} x value+gradient ({key})", "achieved": fit_ach,
-                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fit_ach / FP64_MFMA_PEAK_TFLOPS,
-                    "flops": len(thetas) * float(N) ** 3, "ms": sub_ms["fit"],
-                    "share_of_cycle": sub_ms["fit"] / (sub_ms["fit"] + sub_ms["refactor"] + sub_ms["sweep"]),
-                    "potrf_ms_alone": potrf_ms, "potrf_frac_of_peak_alone": flops_potrf / (potrf_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+        chol, potrf_ms, roof_fit = {}, None, None
+        flops_potrf = N ** 3 / 3.0
+        if secondary:
+            # Cholesky: mean device time of the factorisation alone (HIP events on the handle's stream): a lone one, B
+            # advancing in lock step through one batched launch sequence, and (round 1's form) B on private streams
+            ms_ = C.c_double()
+            _lib.check(lib.bobe_debug_time_potrf(h, 10, C.byref(ms_)), "time_potrf")
+            potrf_ms = ms_.value
+            for B in (4, 8):
+                _lib.check(lib.bobe_debug_time_potrf_lockstep(h, B, 10, C.byref(ms_)), "time_potrf_lockstep")
+                chol[f"lockstep_{B}"] = {"in_flight": B, "ms_all": ms_.value, "gflops": B * flops_potrf / (ms_.value * 1e-3) / 1e9,
+                                         "frac_of_fp64_mfma_peak": B * flops_potrf / (ms_.value * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+            _lib.check(lib.bobe_debug_time_potrf_batch(h, 4, 10, C.byref(ms_)), "time_potrf_batch")
+            chol["streams_4"] = {"in_flight": 4, "ms_all": ms_.value, "gflops": 4 * flops_potrf / (ms_.value * 1e-3) / 1e9,
+                                 "frac_of_fp64_mfma_peak": 4 * flops_potrf / (ms_.value * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+            # the fit phase as a whole: 20 value+gradient evaluations = 20 N^3 flops (potrf N^3/3 + inverse N^3/3 + K^-1/gradient N^3/3)
+            fit_s = sub_ms["fit"] * 1e-3
+            fit_ach = len(thetas) * float(N) ** 3 / fit_s / 1e12
+            roof_fit = {"bound": "mfma", "phase": f"fit: {len(thetas)} x value+gradient ({key})", "achieved": fit_ach,
+                        "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fit_ach / FP64_MFMA_PEAK_TFLOPS,
+                        "flops": len(thetas) * float(N) ** 3, "ms": sub_ms["fit"],
+                        "share_of_cycle": sub_ms["fit"] / (sub_ms["fit"] + sub_ms["refactor"] + sub_ms["sweep"]),
+                        "potrf_ms_alone": potrf_ms, "potrf_frac_of_peak_alone": flops_potrf / (potrf_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
         cfg_name = {"headline": "(BASELINE.json configs[2])", "small": "(BASELINE.json configs[1])",
                     "shard": "(BASELINE.json configs[3])"}.get(args.config, "(not a BASELINE.json config)")
         out = {
@@ -411,22 +471,27 @@ def main():
                        if R_total > 1 else f"{len(thetas)} sequential value+gradient evaluations",
                        "parallelism": f"candidate-sharded x{world}" + (", restart-sharded fit" if strong else ""),
                        "backend": args.backend if world > 1 else None, "exchange": args.exchange},
-            "cholesky_gflops": flops_potrf / (potrf_ms * 1e-3) / 1e9,
+            "cholesky_gflops": flops_potrf / (potrf_ms * 1e-3) / 1e9 if potrf_ms else None,
             "cholesky_ms": potrf_ms,
-            "cholesky_concurrent": chol["lockstep_4"],
+            "cholesky_concurrent": chol.get("lockstep_4"),
             "cholesky": chol,
             "fit_ms": fit_ms,
             "sub_ms": sub_ms,
             "lbfgs_fit": lbfgs,
-            "check": last,
+            "check": last if shard_rec is None else weak_check,
             "roofline": roof,
             "roofline_fit": roof_fit,
+            # what rank 0 saw of the job: ranks, who carried the collectives
+            "world_size": (dist.get_world_size() if world > 1 else 1),
+            "backend": (str(dist.get_backend()) if world > 1 else None),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if shard_rec is not None:
+            out["shard"] = shard_rec
+        if not args.no_cpu_baseline and world == 1 and secondary:
             out["cpu_baseline"] = cpu_baseline(X, y, cand, Z, thetas, noise, gpu_check)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if args.exchange == "rccl":
+    if use_rccl:
         mgpu.finalize()
     if world > 1:
         dist.barrier()              # rank 0's secondary measurements are done: leave together

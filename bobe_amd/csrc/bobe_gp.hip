@@ -1877,9 +1877,17 @@ int bobe_gp_append(bobe_gp_t* g, const double* X_new, int64_t b, const double* y
   g->sync();
   const int d = g->d;
   const int64_t N0 = g->N, N1 = N0 + b, Np0 = g->Np, Np1 = round_up(N1, TILE);
+  // The handle is rebuilt in stages (X, the padded frame, y, then the new rows).  Until the last stage is through it
+  // counts as holding nothing: an error on the way (out of memory in the new frame, a failed launch) leaves a handle
+  // that every later call refuses ("call bobe_gp_set_data first") instead of one with N0 points' factor under N1
+  // points' data; bobe_gp_set_data + bobe_gp_factor then rebuild it from scratch (what GP.update falls back to).
+  g->factored = false;
+  g->have_data = false;
+  g->forget_z();
+  DBuf nx, oa, ol;
+  try {
   // ---- training data: X gains b rows, every y changes (the caller re-standardised them, gp.py:520-536)
   {
-    DBuf nx;
     nx.ensure((size_t)N1 * d * sizeof(double));
     HIPCHK(hipMemcpyAsync(nx.p, g->X.p, (size_t)N0 * d * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipMemcpyAsync(static_cast<double*>(nx.p) + N0 * d, X_new, (size_t)b * d * sizeof(double),
@@ -1890,7 +1898,6 @@ int bobe_gp_append(bobe_gp_t* g, const double* X_new, int64_t b, const double* y
   }
   // ---- a larger padded size: move L and Linv into the new [[., 0], [0, I]] frame
   if (Np1 != Np0) {
-    DBuf oa, ol;
     std::swap(oa, g->A);
     std::swap(ol, g->Linv);
     g->Np = Np1;
@@ -1974,8 +1981,7 @@ int bobe_gp_append(bobe_gp_t* g, const double* X_new, int64_t b, const double* y
   }
   g->N = N1;
   if (!pd) {                               // same outcome as the full refactorisation: NaN state, BOBE_NOT_PD
-    g->factored = false;
-    g->forget_z();
+    g->have_data = true;
     return bobe_gp_factor(g);
   }
   for (int64_t c = 0; c < b; ++c)
@@ -1992,6 +1998,16 @@ int bobe_gp_append(bobe_gp_t* g, const double* X_new, int64_t b, const double* y
   g->scale(g->X.d(), N1, Np, g->hyp, g->XsT.d(), Np);                                    // all points again
   g->solve_alpha(g->Linv.d(), g->w.d(), g->alpha.d(), g->part.d());                     // alpha = Linv^T Linv y
   g->sync();                               // (s22 / hG are host temporaries of this call)
+  } catch (...) {
+    nx.release();
+    oa.release();
+    ol.release();
+    g->N = 0;
+    g->Np = 0;                              // forces bobe_gp_set_data to size every buffer again
+    g->nb = 0;
+    throw;
+  }
+  g->have_data = true;
   g->factored = true;
   g->forget_z();
   g->not_pd = false;
@@ -2221,29 +2237,56 @@ int bobe_mgpu_wip_sweep(bobe_gp_t* g, const double* cand, int64_t C, int64_t glo
                         double y_std, double* wipv, double* wipstd, double* mean, double* var, int64_t* argmin_v,
                         double* min_v, int64_t* argmin_s, double* min_s) {
   API_BEGIN
+  // (argument errors are programming errors and the same on every rank; they are raised before the collective)
   if (!g || !Z) throw Err(BOBE_ERR_ARG, "NULL argument");
   if (C < 0 || global_offset < 0) throw Err(BOBE_ERR_ARG, "bad shard");
+  if (C > 0 && !cand) throw Err(BOBE_ERR_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (!g_rccl.comm) throw Err(BOBE_ERR_STATE, "call bobe_mgpu_init first");
-  g->use();
+  if (g->device != g_rccl.device)
+    throw Err(BOBE_ERR_ARG, "the handle lives on another device than the communicator of bobe_mgpu_init");
+  // A failure of the LOCAL sweep (unfactored handle, out of memory, a failed launch) must not keep this rank out of the
+  // collective - the others would wait in ncclAllGather for ever.  The rank joins with a status word in its payload
+  // and every rank raises after the merge.
   int64_t lv = -1, ls = -1;
   double mv = std::nan(""), msd = std::nan("");
+  int local_rc = BOBE_OK;
+  std::string local_msg;
   if (C > 0) {
-    if (!cand) throw Err(BOBE_ERR_ARG, "NULL argument");
-    g->sweep(cand, C, Z, M, y_std, wipv, wipstd, mean, var, 1, &lv, &mv, &ls, &msd, nullptr);
-    lv += global_offset;
-    ls += global_offset;
+    try {
+      g->use();
+      g->sweep(cand, C, Z, M, y_std, wipv, wipstd, mean, var, 1, &lv, &mv, &ls, &msd, nullptr);
+      lv += global_offset;
+      ls += global_offset;
+    } catch (const Err& e) {
+      local_rc = e.code;
+      local_msg = e.what();
+    } catch (const std::exception& e) {
+      local_rc = BOBE_ERR_HIP;
+      local_msg = e.what();
+    }
+    if (local_rc != BOBE_OK) {
+      lv = ls = -1;                                            // a rank without a result never wins the merge
+      mv = msd = std::nan("");
+    }
   }
-  double mine[4];
+  double mine[5];
   mine[0] = mv;
   std::memcpy(&mine[1], &lv, sizeof(lv));
   mine[2] = msd;
   std::memcpy(&mine[3], &ls, sizeof(ls));
-  std::lock_guard<std::mutex> lock(g_rccl_mutex);
-  const double* all = g_rccl.all_gather(mine, 4);            // ONE collective per acquisition: 32 B per rank
+  mine[4] = (double)local_rc;
+  const double* all = g_rccl.all_gather(mine, 5);            // ONE collective per acquisition: 40 B per rank
+  for (int r = 0; r < g_rccl.world; ++r) {
+    const int rc = (int)all[(size_t)r * 5 + 4];
+    if (rc != BOBE_OK)
+      throw Err(rc, "bobe_mgpu_wip_sweep: the sweep of rank " + std::to_string(r) + " failed" +
+                        (r == g_rccl.rank ? ": " + local_msg : std::string(" (see that rank's bobe_last_error)")));
+  }
   double bv, bs;
   int64_t iv, is;
-  merge_pairs(all, g_rccl.world, 4, 0, &bv, &iv);
-  merge_pairs(all, g_rccl.world, 4, 2, &bs, &is);
+  merge_pairs(all, g_rccl.world, 5, 0, &bv, &iv);
+  merge_pairs(all, g_rccl.world, 5, 2, &bs, &is);
   if (argmin_v) *argmin_v = iv;
   if (min_v) *min_v = bv;
   if (argmin_s) *argmin_s = is;
@@ -2256,6 +2299,8 @@ int bobe_mgpu_best_fit(double mll, const double* theta, int n, double* best_mll,
   API_BEGIN
   if (!theta || !best_mll || !best_theta || n < 1 || n > 126) throw Err(BOBE_ERR_ARG, "bad argument");
   std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (!g_rccl.comm) throw Err(BOBE_ERR_STATE, "call bobe_mgpu_init first");
+  // (no local compute here that could fail on one rank only: the caller passes its restart's result, NaN included)
   std::vector<double> mine((size_t)n + 1);
   mine[0] = mll;
   std::memcpy(mine.data() + 1, theta, (size_t)n * sizeof(double));

@@ -112,6 +112,7 @@ class GP:
 
         self.append_updates = True             # update(): rank-b append (O(b N^2)) instead of a full refactorisation
         self._chol_cache = self._alpha_cache = None
+        self._pushed_hyper = None              # hyper-parameters of the factor on the device (set by _push_hyper)
         self.not_pd = False
         self._push_data()
         if _factor:
@@ -154,6 +155,12 @@ class GP:
         ls = _lib.as_f64(self.lengthscales).reshape(-1)
         _lib.check(self._lib.bobe_gp_set_hyper(self._h, _lib.ptr(ls), float(self.kernel_variance), float(self.noise)),
                    "bobe_gp_set_hyper")
+        self._pushed_hyper = self._hyper_key()
+
+    def _hyper_key(self):
+        """The hyper-parameters as the device holds them after a ``_push_hyper`` (what the current factor was built with)."""
+        return (tuple(np.asarray(self.lengthscales, dtype=np.float64).reshape(-1).tolist()), float(self.kernel_variance),
+                float(self.noise))
 
     # ------------------------------------------------------------------ priors / bounds
     def _setup_kernel_variance_prior(self, kernel_variance_prior):
@@ -414,20 +421,31 @@ class GP:
             self._refresh_after_update(len(pts))
 
     def _refresh_after_update(self, n_new: int):
-        """K, L, alpha for the grown training set (gp.py:541).  The hyper-parameters have not changed, so the factor
-        of the old points is still valid: the new rows are appended on the GPU (``bobe_gp_append``, the b-row form of
-        the reference's own ``fast_update_cholesky``, gp.py:181-197) and alpha is re-solved for the re-standardised
-        targets — O(b N^2) instead of O(N^3).  Falls back to the full refactorisation when there is no usable
-        factor (NaN state) or the batch is large."""
-        if self.append_updates and not self.not_pd and 1 <= n_new <= 64 and self.train_x.shape[0] > n_new:
-            xn = _lib.as_f64(self.train_x[-n_new:])
-            ya = _lib.as_f64(self.train_y).reshape(-1)
-            st = _lib.check(self._lib.bobe_gp_append(self._h, _lib.ptr(xn), n_new, _lib.ptr(ya)), "bobe_gp_append")
-            self._chol_cache = self._alpha_cache = None
-            self.not_pd = (st == _lib.BOBE_NOT_PD)
-            return
+        """K, L, alpha for the grown training set (gp.py:541).  While the hyper-parameters are the ones the factor on
+        the device was built with, the factor of the old points is still valid: the new rows are appended on the GPU
+        (``bobe_gp_append``, the b-row form of the reference's own ``fast_update_cholesky``, gp.py:181-197) and alpha
+        is re-solved for the re-standardised targets — O(b N^2) instead of O(N^3).  Everything else takes the
+        reference's route, ``recompute_cholesky()`` from the CURRENT attributes (gp.py:541-550, "useful if
+        hyperparameters are changed manually"): lengthscales / kernel_variance / noise set by hand since the last
+        factorisation, no usable factor (NaN state), a large batch, or an append that failed."""
+        if (self.append_updates and not self.not_pd and 1 <= n_new <= 64 and self.train_x.shape[0] > n_new
+                and self._pushed_hyper == self._hyper_key()):
+            try:
+                st = self._append_rows(n_new)
+            except _lib.BobeLibraryError as e:
+                # (the library leaves a failed append as an empty handle: rebuild it from the host copy of the data)
+                log.warning(f"append of {n_new} rows failed ({e}); refactorising")
+            else:
+                self._chol_cache = self._alpha_cache = None
+                self.not_pd = (st == _lib.BOBE_NOT_PD)
+                return
         self._push_data()
         self.recompute_cholesky()
+
+    def _append_rows(self, n_new: int) -> int:
+        xn = _lib.as_f64(self.train_x[-n_new:])
+        ya = _lib.as_f64(self.train_y).reshape(-1)
+        return _lib.check(self._lib.bobe_gp_append(self._h, _lib.ptr(xn), n_new, _lib.ptr(ya)), "bobe_gp_append")
 
     # ------------------------------------------------------------------ fantasy variance / sweep
     def fantasy_var(self, new_x, mc_points, k_train_mc=None):
@@ -594,6 +612,7 @@ class GP:
             gp.not_pd = bool(_clone_of.not_pd)
             # the host copy of the standardisation too, bit for bit (a state_dict round trip re-derives it)
             gp.train_y, gp.y_mean, gp.y_std = np.array(_clone_of.train_y), _clone_of.y_mean, _clone_of.y_std
+            gp._pushed_hyper = _clone_of._pushed_hyper       # (the clone carries the source's device hyper-parameters)
             gp._chol_cache, gp._alpha_cache = None, None
         elif L is not None and a is not None and np.all(np.isfinite(np.asarray(L, dtype=np.float64))):
             L = _lib.as_f64(L)

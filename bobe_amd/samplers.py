@@ -167,23 +167,29 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
     since_update = 0
     it = 0
     update_every = max(1, nlive // 5)
+    gave_up = truncated = False
     while True:
         worst = int(np.argmin(live_logl))
         lstar = float(live_logl[worst])
+        # Stop BEFORE the worst point is retired — it then stays among the final live points and is counted once
+        # (dynesty checks at the top of its iteration too).  Remaining evidence bound (dynesty's stopping rule):
+        # dlogz = log(z + Lmax X) - log z.
+        lmax = float(np.max(live_logl))
+        if it > 0 and np.logaddexp(logz, lmax - it / nlive) - logz < dlogz:
+            break
+        if ncall >= maxcall:
+            truncated = True
+            break
         logdx = -it / nlive + math.log1p(-math.exp(-1.0 / nlive))      # log(X_{i-1} - X_i)
-        logz_new = np.logaddexp(logz, lstar + logdx)
+        logz_before = logz
+        logz = np.logaddexp(logz, lstar + logdx)
         dead_x.append(live[worst].copy())
         dead_logl.append(lstar)
-        logz = logz_new
         it += 1
-        # remaining evidence bound (dynesty's stopping rule): dlogz = log(z + Lmax X) - log z
-        lmax = float(np.max(live_logl))
-        if np.logaddexp(logz, lmax - it / nlive) - logz < dlogz or ncall >= maxcall:
-            break
         # replacement with L > L*: pop pre-scored proposals, refill the pool in GPU batches
         found = False
         tries = 0
-        while not found:
+        while not found and not gave_up:
             while pool_pos < len(pool_l):
                 if pool_l[pool_pos] > lstar:
                     live[worst] = pool_x[pool_pos]
@@ -203,11 +209,7 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
                 # keep the acceptance rate of a step near one half (dynesty adapts its scale the same way)
                 rw_scale = float(np.clip(rw_scale * math.exp((rate - 0.5) / max(ndim, 1) * 4.0), 1e-4, 4.0))
                 tries += 1
-                if tries > 200 or ncall >= maxcall:
-                    if tries > 200:
-                        log.warning("nested sampling: no acceptable replacement found; stopping early")
-                    found = True
-                    ncall = maxcall
+                gave_up = tries > 200 or ncall >= maxcall
                 continue
             if since_update >= update_every or tries > 0 or len(pool_l) == 0:
                 mask = np.ones(nlive, dtype=bool)
@@ -220,17 +222,25 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
             pool_x, pool_l, pool_pos = x, loglike(x), 0
             ncall += len(x)
             tries += 1
-            if tries > 200:                                   # plateau / degenerate surrogate: give up cleanly
-                log.warning("nested sampling: no acceptable replacement found; stopping early")
-                found = True
-                ncall = maxcall
+            gave_up = tries > 200                             # plateau / degenerate surrogate
+        if gave_up and not found:
+            # No replacement: the point just retired is still a live point.  Take the retirement back (it is counted once,
+            # among the final live points) and end the run as TRUNCATED - its evidence is not a converged one.
+            dead_x.pop()
+            dead_logl.pop()
+            it -= 1
+            logz = logz_before
+            truncated = True
+            if tries > 200:
+                log.warning("nested sampling: no acceptable replacement found; stopping early (run marked unsuccessful)")
+            break
         since_update += 1
     # final live points, appended in order of increasing logl (dynesty add_final_live)
     order = np.argsort(live_logl)
     niter = len(dead_logl)
     logvol_dead = -np.arange(1, niter + 1) / nlive
-    logvol_live = logvol_dead[-1] + np.log1p(-(np.arange(nlive) + 1.0) / (nlive + 1.0))
-    samples_x = np.vstack([np.array(dead_x), live[order]])
+    logvol_live = (logvol_dead[-1] if niter else 0.0) + np.log1p(-(np.arange(nlive) + 1.0) / (nlive + 1.0))
+    samples_x = np.vstack([np.array(dead_x).reshape(-1, ndim), live[order]])
     logl = np.concatenate([np.array(dead_logl), live_logl[order]])
     logvol = np.concatenate([logvol_dead, logvol_live])
     cum = compute_integrals(logl=logl, logvol=logvol)
@@ -242,10 +252,12 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
     w = np.exp(logwt - mean)
     h_info = float(np.sum(w * (logl - mean)))
     logz_err = math.sqrt(max(h_info, 0.0) / nlive)
-    success = bool(~np.all(logl == logl[0]))                                  # samplers.py:167
+    # samplers.py:167; a run that ended because no replacement could be found is NOT a successful one: bo.py must not
+    # call logZ converged on it (a run cut by maxcall alone is reported the way dynesty's would be, with a flag)
+    success = bool(~np.all(logl == logl[0])) and not gave_up
 
     logz_dict = logz_from_samples(gp, samples_x, logl, logvol, mean, logz_err)
-    logz_dict.update(ncall=int(ncall), niter=int(niter))
+    logz_dict.update(ncall=int(ncall), niter=int(niter), truncated=bool(truncated))
     best_pt = samples_x[int(np.argmax(logl))]
     weights = renormalise_log_weights(logwt)
     if equal_weights:
@@ -353,11 +365,18 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
             it = cut
             if not last:                                       # mass matrix from the spread of the batch
                 inv_mass = np.var(hist.reshape(-1, d), axis=0) + 1e-3
+                # restart the dual averaging for the new metric (NumPyro / Stan do at every window): mu, hbar,
+                # log_eps_bar AND the step counter m - with m left at several hundred, eta = m^-0.75 is ~0.01 and the
+                # zeroed log_eps_bar keeps a quarter of its weight to the end of the warm-up (step size biased to 1)
                 adapt[:, 1] = np.log(10.0 * adapt[:, 0])
                 adapt[:, 2] = 0.0
                 adapt[:, 3] = 0.0
+                adapt[:, 4] = 0.0
         if warmup_steps > 0:                                   # the averaged step size of the warm-up
             adapt[:, 0] = np.where(adapt[:, 3] != 0.0, np.clip(np.exp(adapt[:, 3]), 1e-4, 2.0), adapt[:, 0])
+        if isinstance(kwargs.get("diagnostics"), dict):        # (tests: the state the sampling phase starts from)
+            kwargs["diagnostics"].update(eps=adapt[:, 0].copy(), inv_mass=np.array(inv_mass), state=state.copy(),
+                                         adapt=adapt.copy(), seed=seed, it=it)
         _, keep, _ = gp.hmc_run(state, adapt, inv_mass, seed, it, keep_per_chain * thinning, False, temp, thin=thinning)
         samples_x = keep[:, :, :d].reshape(-1, d)[:n_keep_total]
         logps = keep[:, :, d].reshape(-1)[:n_keep_total]
@@ -367,6 +386,7 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     windows = {int(warmup_steps * f) for f in (0.25, 0.5, 0.75)}
     recent = []
     xs, lps = [], []
+    da_start = 0                                               # first iteration of the current dual-averaging run
     for it in range(total):
         L = int(rng.integers(4, 13))
         p0 = rng.normal(size=U.shape) / np.sqrt(inv_mass)
@@ -389,19 +409,20 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
         mean = np.where(accept, meann, mean)
         X = np.where(accept[:, None], Xn, X)
         if it < warmup_steps:
-            m_ = it + 1
+            m_ = it + 1 - da_start                             # steps since the averaging was (re)started
             hbar = (1.0 - 1.0 / (m_ + t0)) * hbar + (target - float(np.mean(acc_prob))) / (m_ + t0)
             log_eps = mu - math.sqrt(m_) / gamma * hbar
             eta = m_ ** (-kappa)
             log_eps_bar = eta * log_eps + (1.0 - eta) * log_eps_bar
             eps = float(np.clip(math.exp(log_eps), 1e-4, 2.0))
             recent.append(U.copy())
-            if m_ in windows:                                  # mass matrix from the spread of the batch
+            if it + 1 in windows:                              # mass matrix from the spread of the batch
                 pool = np.concatenate(recent[len(recent) // 2:], axis=0)
                 inv_mass = np.var(pool, axis=0) + 1e-3
                 recent = []
                 mu, hbar, log_eps_bar = math.log(10.0 * eps), 0.0, 0.0
-            if m_ == warmup_steps:
+                da_start = it + 1                              # ... and its step counter (see the device path)
+            if it + 1 == warmup_steps:
                 eps = float(np.clip(math.exp(log_eps_bar), 1e-4, 2.0)) if log_eps_bar != 0.0 else eps
         elif (it - warmup_steps + 1) % thinning == 0:
             xs.append(X.copy())

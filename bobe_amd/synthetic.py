@@ -37,12 +37,18 @@ def synthetic_problem(N: int, d: int, C: int, M: int = 512, ls_star: float = 0.6
     L = cholesky(K, lower=True, check_finite=False)
     y = L @ rng.standard_normal(N)
     y = (y - y.mean()) / y.std()
-    sob = qmc.Sobol(d, scramble=True, seed=5678)
-    if cand_offset:
-        sob.fast_forward(cand_offset)
-    cand = sob.random(C)
+    cand = sobol_candidates(d, C, cand_offset)
     Z = qmc.Sobol(d, scramble=True, seed=9012).random(M)
     return X, y, cand, Z
+
+
+def sobol_candidates(d: int, C: int, offset: int = 0) -> np.ndarray:
+    """rows [offset, offset + C) of the candidate set: scrambled Sobol, seed 5678 (a rank generates its own shard)"""
+    from scipy.stats import qmc
+    sob = qmc.Sobol(d, scramble=True, seed=5678)
+    if offset:
+        sob.fast_forward(offset)
+    return sob.random(C) if C > 0 else np.empty((0, d))
 
 
 def theta_schedule(d: int, ls_star: float = 0.6, n: int = 20) -> np.ndarray:

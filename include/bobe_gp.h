@@ -186,9 +186,11 @@ int bobe_gp_append(bobe_gp_t* gp, const double* X_new, int64_t b, const double* 
  *   rank 0:      bobe_mgpu_unique_id(id)  -> ship the BOBE_MGPU_ID_BYTES bytes to the other ranks (any channel)
  *   every rank:  bobe_mgpu_init(id, world, rank, device)
  * bobe_mgpu_wip_sweep = bobe_gp_wip_sweep on this rank's contiguous shard [global_offset, global_offset + C) of the
- * candidates (C may be 0), then ONE ncclAllGather of (min wipv, index, min wipstd, index) - 32 bytes per rank - and the
- * merge every rank repeats: smallest score, ties to the lowest GLOBAL index (jnp.argmin's first occurrence,
+ * candidates (C may be 0), then ONE ncclAllGather of (min wipv, index, min wipstd, index, status) - 40 bytes per rank -
+ * and the merge every rank repeats: smallest score, ties to the lowest GLOBAL index (jnp.argmin's first occurrence,
  * acquisition.py:397), NaN counts as minimal.  argmin_* / min_* are the global results; the score vectors stay local.
+ * A rank whose local sweep fails still joins the collective (status word): EVERY rank then returns that error code
+ * instead of the healthy ones waiting in the all-gather for ever.  The handle must live on bobe_mgpu_init's device.
  * bobe_mgpu_best_fit = all-gather of (mll, theta) and max by mll (pool.py:322-326) for the restart-sharded fit. */
 #define BOBE_MGPU_ID_BYTES 128
 int bobe_mgpu_unique_id(char* id128);

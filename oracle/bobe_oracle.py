@@ -673,13 +673,23 @@ def get_mc_points(mc_samples_x: np.ndarray, mc_points_size: int, rng) -> np.ndar
 # --------------------------------------------------------------------------------------
 # the benchmark "cycle" on the CPU — bench.py's cpu_baseline leg
 # --------------------------------------------------------------------------------------
-def cycle_value_and_grad(X, y, ls, kvar, noise):
-    """One value+grad evaluation of the RBF data-term MLL the way a NumPy/LAPACK port does it:
-    dpotrf + dpotrs + dpotri (N^3 flops) and d+1 fused N^2 reductions."""
+def cycle_value_and_grad(X, y, ls, kvar, noise, kernel="rbf"):
+    """One value+grad evaluation of the data-term MLL the way a NumPy/LAPACK port does it: dpotrf + dpotrs + dpotri
+    (N^3 flops) and d+1 fused N^2 reductions.  Same formulas as ``mll_value_and_grad`` (gp.py:124-178 under
+    optim.py:306-309), with K^-1 from dpotri instead of N solves — the form that is affordable at N of several thousand."""
     from scipy.linalg import lapack
     n, d = X.shape
     Xs = X / ls
-    Kt = kvar * np.exp(-0.5 * dist_sq(Xs, Xs))
+    dsq = dist_sq(Xs, Xs)
+    if kernel == "rbf":
+        Kt = kvar * np.exp(-0.5 * dsq)
+        G = Kt                                   # dKt/dlog ls_j = Kt * D_j
+    else:                                        # Matern-5/2 (gp.py:156-168), r^2 floored at 1e-30 before the sqrt
+        r = np.sqrt(np.where(dsq < 1e-30, 1e-30, dsq))
+        e = np.exp(-SQRT5 * r)
+        Kt = kvar * (1.0 + r * (SQRT5 + r * 5.0 / 3.0)) * e
+        G = np.where(dsq < 1e-30, 0.0, kvar * (5.0 / 3.0) * (1.0 + SQRT5 * r) * e)
+    del dsq
     K = Kt + noise * np.eye(n)
     L, info = lapack.dpotrf(K, lower=1, clean=1, overwrite_a=0)
     if info != 0:
@@ -688,10 +698,11 @@ def cycle_value_and_grad(X, y, ls, kvar, noise):
     mll = float(-0.5 * y @ alpha - np.sum(np.log(np.diag(L))) - 0.5 * n * LOG_2PI)
     Kinv, _ = lapack.dpotri(L, lower=1)
     Kinv = np.tril(Kinv) + np.tril(Kinv, -1).T
-    WK = (np.outer(alpha, alpha) - Kinv) * Kt
+    W = np.outer(alpha, alpha) - Kinv
+    WG = W * G
     g = np.empty(d + 1)
     for j in range(d):
         diff = Xs[:, j][:, None] - Xs[:, j][None, :]
-        g[j] = 0.5 * np.sum(WK * diff * diff)
-    g[d] = 0.5 * np.sum(WK)
+        g[j] = 0.5 * np.sum(WG * diff * diff)
+    g[d] = 0.5 * np.sum(W * Kt)
     return mll, g

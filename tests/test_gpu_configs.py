@@ -71,10 +71,41 @@ def test_bench_gpus_2_really_runs_two_ranks_weak_and_strong():
     # restart-sharded fit: the same best restart (the synthetic y comes from a multi-threaded host Cholesky whose
     # blocking depends on the process's thread count, so the two runs' data agree to ~1e-16, not to the bit)
     assert two["check"]["best_mll"] == pytest.approx(one["check"]["best_mll"], rel=1e-10)
-    weak = _run_bench(["--gpus", "2", "--backend", "gloo", "--config", "tiny"])
+    weak = _run_bench(["--gpus", "2", "--backend", "gloo", "--config", "tiny", "--shard-candidates", "4096"])
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and "N=256" in weak["metric"] and weak["value"] > 0
+    assert weak["world_size"] == 2 and weak["backend"] == "gloo"
     for k in ("roofline", "roofline_fit", "cholesky", "fit_ms", "sub_ms"):
         assert k in weak
+    # N > 1 in the weak mode also times the STRONG cycle (candidates and restarts split over the ranks): same pick as
+    # one rank sweeping the whole set, all four phases reported
+    sh = weak["shard"]
+    assert sh["scaling"] == "strong" and sh["candidates_total"] == 4096 and sh["candidates_per_gpu"] == 2048
+    assert sh["cycles_per_s"] > 0 and sh["steps"] == 1
+    assert all(sh[k] >= 0 for k in ("fit_ms", "refactor_ms", "sweep_ms", "exchange_ms"))
+    assert sh["ms_per_cycle"] >= max(sh["sweep_ms"], sh["fit_ms"]) * 0.999
+    solo = _run_bench(["--gpus", "1", "--config", "tiny", "--no-secondary"])
+    assert solo["world_size"] == 1 and solo["backend"] is None and "shard" not in solo
+    assert solo["fit_ms"] == {} and solo["roofline_fit"] is None and "cpu_baseline" not in solo and solo["value"] > 0
+    from bobe_amd import GP
+    from bobe_amd.synthetic import CONFIGS, sobol_candidates, synthetic_problem, theta_schedule
+    N, d, _, M = CONFIGS["tiny"]
+    X, y, _, Z = synthetic_problem(N, d, 8, M, noise=1e-6)
+    th = theta_schedule(d)
+    gp = GP(X, y, noise=1e-6, lengthscales=np.exp(th[-1, :d]), kernel_variance=float(np.exp(th[-1, d])))
+    full = gp.wip_sweep(sobol_candidates(d, 4096), Z)
+    assert sh["check"]["argmin"] == full["argmin_s"]
+    assert sh["check"]["min_wipstd"] == pytest.approx(full["min_s"], rel=1e-10)
+
+
+def test_bench_exchange_rccl_goes_through_the_shipped_entry_points():
+    """--exchange rccl: the cycle's sweep is bobe_mgpu_wip_sweep itself (shard sweep + ncclAllGather + merge inside the
+    library) and the fit merge bobe_mgpu_best_fit - one rank here (RCCL refuses two ranks on one device), same pick."""
+    a = _run_bench(["--gpus", "1", "--config", "tiny", "--no-secondary"])
+    b = _run_bench(["--gpus", "1", "--config", "tiny", "--no-secondary", "--exchange", "rccl"])
+    assert b["config"]["exchange"] == "rccl" and a["config"]["exchange"] == "torch"
+    assert a["check"]["argmin"] == b["check"]["argmin"]
+    assert b["check"]["min_wipstd"] == pytest.approx(a["check"]["min_wipstd"], rel=1e-10)
+    assert b["check"]["best_mll"] == pytest.approx(a["check"]["best_mll"], rel=1e-10)
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
@@ -135,7 +166,7 @@ def test_library_owned_rccl_exchange_single_rank():
     """bobe_mgpu_*: the C ABI's own RCCL all-gather + merge.  One GPU on the box means one rank (RCCL refuses two
     ranks on one device), which still runs ncclCommInitRank / ncclAllGather for real: the merged result must be the
     plain sweep's, global offsets applied, and an empty shard must not win."""
-    from bobe_amd import GP, mgpu
+    from bobe_amd import GP, _lib, mgpu
     rng = np.random.default_rng(8)
     X = rng.uniform(size=(500, 4))
     y = np.sin(X.sum(1))
@@ -152,6 +183,16 @@ def test_library_owned_rccl_exchange_single_rank():
         assert got["argmin_v"] == 1000 + plain["argmin_v"] and got["min_v"] == plain["min_v"]
         bm, bt = mgpu.best_fit(-12.5, np.array([0.1, 0.2, 0.3]))
         assert bm == -12.5 and np.array_equal(bt, [0.1, 0.2, 0.3])
+        # a failing LOCAL sweep (here: hyper-parameters set, factor not rebuilt) still joins the collective and comes
+        # back as that error on every rank - it does not leave the other ranks waiting in the all-gather
+        gp._push_hyper()
+        with pytest.raises(_lib.BobeLibraryError, match="rank 0"):
+            mgpu.wip_sweep(gp, cand, 0, Z)
+        gp.recompute_cholesky()
+        again = mgpu.wip_sweep(gp, cand, 0, Z)
+        assert again["argmin_s"] == plain["argmin_s"]
+        empty = mgpu.wip_sweep(gp, cand[:0], 0, Z)                                # a rank without candidates
+        assert empty["argmin_s"] == -1 and np.isnan(empty["min_s"])
         with pytest.raises(Exception):
             mgpu.init(b"\0" * 128, 1, 0, 0)               # already initialised
     finally:

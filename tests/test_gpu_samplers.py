@@ -137,6 +137,30 @@ def test_hmc_sampler_same_statistics_fused_and_stepwise():
     assert np.array_equal(a["x"], a2["x"])                       # same seed, same chains
 
 
+def test_warmup_step_size_gives_the_target_acceptance():
+    """Dual averaging aims at 0.8 mean acceptance (NumPyro's default target).  Its averaged iterate is only meaningful
+    if the averaging restarts with the metric at each mass-matrix window — counter included; with the counter left
+    running the adopted step size came out as eps^0.73 (biased towards 1) and the sampling phase accepted far less."""
+    from bobe_amd import GP
+    from bobe_amd.samplers import sample_GP_NUTS
+    d = 4
+    mu, sig = np.full(d, 0.5), np.array([0.05, 0.08, 0.11, 0.07])
+    X = qmc.Sobol(d, scramble=True, seed=9).random(768)
+    y = -0.5 * np.sum(((X - mu) / sig) ** 2, axis=1)
+    gp = GP(X, y, noise=1e-8, lengthscales=[0.6] * d, kernel_variance=50.0)
+    diag = {}
+    sample_GP_NUTS(gp, np_rng=np.random.default_rng(3), num_chains=4, warmup_steps=512, num_samples=64, diagnostics=diag)
+    st, ad = diag["state"], diag["adapt"]
+    acc = []
+    for k in range(48):                                         # 48 more trajectories of the 64 chains, step size frozen
+        _, _, dbg = gp.hmc_run(st, ad, diag["inv_mass"], seed=diag["seed"], it0=diag["it"] + k, niter=1, do_adapt=False,
+                               debug=True)
+        acc.append(dbg[:, d + 2])
+    mean_acc = float(np.mean(acc))
+    assert 0.68 <= mean_acc <= 0.92, mean_acc
+    assert np.all(diag["eps"] > 1e-3) and np.all(diag["eps"] < 2.0)
+
+
 def _hmc_state(gp, U, temp):
     from scipy.special import expit
     X = np.clip(expit(U), 1e-12, 1 - 1e-12)

@@ -118,3 +118,32 @@ def test_nested_sampler_recovers_a_known_evidence(d, s, method):
     assert lz["ncall"] < 2e6 and lz["lower"] <= lz["mean"] <= lz["upper"]
     w = smp["weights"] / smp["weights"].sum()
     assert np.allclose(np.sum(w[:, None] * smp["x"], axis=0), 0.5, atol=5 * s / math.sqrt(200))
+
+
+class _CappedSurface(_GaussSurface):
+    """a Gaussian well with its top cut off: once every live point sits on the plateau no replacement with L > L*
+    exists, which is the sampler's give-up case"""
+
+    def predict_mean_batched(self, u):
+        return np.minimum(super().predict_mean_batched(u), -2.0)
+
+
+@pytest.mark.parametrize("method", ["ellipsoid", "rwalk"])
+def test_nested_sampler_terminations_count_every_point_once(method):
+    """Every sample of a run is either a dead point or a final live point, never both (the worst point of the last
+    iteration used to be retired AND kept); a run cut by maxcall says so; a run that could not find a replacement is
+    not a successful one (bo.py must not call its logZ converged)."""
+    from bobe_amd import samplers
+    # (1) normal termination
+    smp, lz, ok = samplers.nested_sampling(_GaussSurface(2, 0.05), ndim=2, rng=np.random.default_rng(3), sample_method=method)
+    assert ok and not lz["truncated"]
+    assert len(np.unique(smp["x"], axis=0)) == len(smp["x"]) == lz["niter"] + 500
+    # (2) cut by maxcall: flagged, still every point once
+    smp, lz, ok = samplers.nested_sampling(_GaussSurface(2, 0.05), ndim=2, rng=np.random.default_rng(3), sample_method=method,
+                                           maxcall=20000)
+    assert lz["truncated"] and len(np.unique(smp["x"], axis=0)) == len(smp["x"]) == lz["niter"] + 500
+    # (3) plateau: nothing above L* exists any more -> gives up, unsuccessful, every point once
+    smp, lz, ok = samplers.nested_sampling(_CappedSurface(2, 0.2), ndim=2, rng=np.random.default_rng(3), sample_method=method,
+                                           nlive=100, batch=512)
+    assert not ok and lz["truncated"]
+    assert len(np.unique(smp["x"], axis=0)) == len(smp["x"]) == lz["niter"] + 100
