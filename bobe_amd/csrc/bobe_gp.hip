@@ -106,6 +106,7 @@ void configure_kernels_once() {
   allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
   allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
   allow_big_lds(k_chol_panel<false>, POTF2_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<false, true>), POTF2_SMEM_BYTES);
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_syrk_trail<64, SYRK64_BK>, SYRK64_SMEM);
@@ -137,10 +138,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1};
+    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -151,6 +152,9 @@ const Tuning& tuning() {
     if (const char* e = std::getenv("BOBE_OWN_QUEUES")) v.own_queues = std::atoi(e);
     if (const char* e = std::getenv("BOBE_GRAPH_MAX_N")) v.graph_max_n = std::atoi(e);
     if (const char* e = std::getenv("BOBE_XCD_SHARES")) v.xcd_shares = std::atoi(e);   // 0: row-major tile order on every XCD
+    // timing experiment: stand-in MFMA workgroups on the CUs a panel launch leaves empty (results unaffected)
+    if (const char* e = std::getenv("BOBE_FILLER_ITERS")) v.filler_iters = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_FILLER_KEEP")) v.filler_keep = std::atoi(e);      // CUs left empty anyway
     return v;
   }();
   return t;
@@ -188,6 +192,7 @@ struct bobe_gp {
   int num_cus = 0;
   // sweep / predict workspace
   DBuf wg_ws;     // workspace of bobe_gp_wip_grad's few-candidates path
+  DBuf filler_ws; // BOBE_FILLER_ITERS experiment
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
   std::vector<Depth> depths;
@@ -486,8 +491,16 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
       if (!tu.chol_legacy && B * np_ <= std::max(num_cus, 1)) {
         first_aside = std::min(first_aside, kk);
         prof_begin(BOBE_PROF_POTF2);
-        hipLaunchKernelGGL(k_chol_panel<false>, dim3(np_, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
-                           kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr);
+        const int fill = tu.filler_iters > 0 ? std::max(0, (num_cus - tu.filler_keep - B * np_) / B) : 0;
+        if (fill > 0) {
+          filler_ws.ensure((size_t)B * (np_ + fill) * PANEL_THREADS * sizeof(double));
+          hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + fill, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np,
+                             bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, tu.filler_iters,
+                             filler_ws.d());
+        } else {
+          hipLaunchKernelGGL(k_chol_panel<false>, dim3(np_, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
+                             kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr);
+        }
         prof_end(BOBE_PROF_POTF2);
       } else {
         prof_begin(BOBE_PROF_POTF2);
@@ -1070,7 +1083,7 @@ void bobe_gp_destroy(bobe_gp_t* g) {
   DBuf* bufs[] = {&g->X, &g->y, &g->XsT, &g->XsT2, &g->A, &g->Linv, &g->A2, &g->Linv2, &g->Tmp, &g->alpha, &g->w,
                   &g->alpha2, &g->w2, &g->part, &g->gpart, &g->res, &g->info, &g->probs, &g->flags, &g->diag, &g->in_stage, &g->z_stage,
                   &g->CsT, &g->ZsT, &g->kXC, &g->kXZ, &g->VZ, &g->WZ, &g->basez, &g->sc, &g->qpart, &g->pv, &g->ps,
-                  &g->o_mean, &g->o_var, &g->o_wipv, &g->o_wipstd, &g->o_misc, &g->kin_a, &g->kin_b, &g->kout};
+                  &g->o_mean, &g->o_var, &g->o_wipv, &g->o_wipstd, &g->o_misc, &g->kin_a, &g->kin_b, &g->kout, &g->wg_ws, &g->filler_ws};
   for (DBuf* b : bufs) b->release();
   for (auto& pr : g->prof_events) {
     (void)hipEventDestroy(pr.first);

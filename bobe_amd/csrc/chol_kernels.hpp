@@ -602,12 +602,31 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
 // panel k of every slot as ONE launch (grid = npanel x nbatch, PANEL_THREADS threads).  Replaces the k_potf2 +
 // k_trsm_panel pair when all nbatch*npanel workgroups fit on the chip at once (the redundant factorisations then cost
 // nothing and one kernel boundary plus the L_kk round trip through global memory go away).
-template <bool STAMP = false>
+// FILL (timing experiments only, BOBE_FILLER_ITERS): workgroups with blockIdx.x >= npanel run fill_iters rounds of eight
+// independent MFMAs per wave instead of panel work - a stand-in for GEMM tiles placed in the shadow of the panel chain
+// (same launch, same 150 KB / 512-thread shape), to measure what such tiles would cost the panel.  Results discarded.
+template <bool STAMP = false, bool FILL = false>
 __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
                                                               double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
                                                               int npanel, int* __restrict__ info, int nvalid,
                                                               double* __restrict__ diag, int64_t bsD,
-                                                              unsigned long long* __restrict__ stamps = nullptr) {
+                                                              unsigned long long* __restrict__ stamps = nullptr,
+                                                              int fill_iters = 0, double* __restrict__ fill_out = nullptr) {
+  if (FILL && (int)blockIdx.x >= npanel) {
+    v4d acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < fill_iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double sres = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sres += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (fill_out) fill_out[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * PANEL_THREADS + threadIdx.x] = sres;
+    return;
+  }
   const int slot = blockIdx.y;
   chol_panel_body5<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel, info + slot,
                           nvalid, diag + slot * bsD + (int64_t)k * TILE * TILE, stamps);

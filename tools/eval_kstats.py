@@ -1,6 +1,7 @@
 """Per-kernel totals of ONE lock-step value+gradient batch (bobe_gp_mll_batch) from a rocprofv3 kernel trace.
   run   : rocprofv3 --kernel-trace --output-format csv -d DIR -- python tools/eval_kstats.py run N B
-  parse : python tools/eval_kstats.py parse <kernel_trace.csv>"""
+  parse : python tools/eval_kstats.py parse <kernel_trace.csv>
+  timeline : python tools/eval_kstats.py timeline <kernel_trace.csv>   (every launch of the last batch: start, duration, gap)"""
 import collections
 import csv
 import os
@@ -25,6 +26,15 @@ else:
                 for r in rows)
     last = max(i for i, e in enumerate(ev) if "k_scale_coords" in e[2])
     seg = ev[last:]
+    if sys.argv[1] == "timeline":
+        t0, prev_end = seg[0][0], seg[0][0]
+        print("   start_us   dur_us   gap_us  kernel")
+        for s_, e_, n in seg:
+            print(f"{(s_ - t0) / 1e3:11.1f} {(e_ - s_) / 1e3:8.2f} {(s_ - prev_end) / 1e3:8.2f}  {n}")
+            prev_end = max(prev_end, e_)
+        busy = sum(e_ - s_ for s_, e_, _ in seg) / 1e3
+        print(f"span {(seg[-1][1] - t0) / 1e3:.1f} us, kernel time {busy:.1f} us, gaps {(seg[-1][1] - t0) / 1e3 - busy:.1f} us")
+        sys.exit(0)
     tot, cnt = collections.defaultdict(float), collections.Counter()
     for s, e, n in seg:
         tot[n] += (e - s) / 1e3
