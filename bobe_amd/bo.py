@@ -5,6 +5,11 @@ Mirrors the parts of ``BOBE/bo.py`` that *call* the hot path: Sobol initialisati
 WIPV / WIPStd / EI iteration (bo.py:1174-1224, 1226-1390: mc points -> get_next_batch -> evaluate ->
 update_gp) and the refit policy of ``update_gp`` (bo.py:620-668, strict ``<`` size classes included).
 
+Run-level resume (bo.py:327-381): ``save=True`` writes ``<save_dir>/<name>_gp.npz`` (the reference's file) plus
+``<name>_run.json`` / ``<name>_mc.npz`` (what its results manager keeps: iteration, evaluation count, acquisition
+history, convergence state — and, so that a resumed run CONTINUES the interrupted one, the generator state and the
+current integration samples); ``BOBE(..., resume=True, resume_file=<save_dir>/<name>)`` picks them up.
+
 Not reproduced: the MPI pool itself (its restart sharding is, over torch.distributed: ``gp_fit``),
 NUTS.  The logZ convergence test (bo.py:886-891)
 runs on ``bobe_amd.samplers.nested_sampling`` (batched on the GPU GP) instead of dynesty; the loop also stops
@@ -13,6 +18,8 @@ reference's ``'uniform'`` (scrambled Sobol, acquisition.py:476-479) or ``'NS'`` 
 """
 from __future__ import annotations
 
+import json
+import os
 import time
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -59,6 +66,15 @@ def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.r
     return res
 
 
+def load_gp_file(filename: str, clf: bool, device: int = 0):
+    """bo.py:25-43: a ``GP`` or ``GPwithClassifier`` from ``<filename>.npz`` (L and alpha restored without a
+    factorisation for the plain GP, gp.py:671-675)."""
+    if clf:
+        from .clf_gp import GPwithClassifier
+        return GPwithClassifier.load(filename, device=device)
+    return GP.load(filename, device=device)
+
+
 def refit_policy(n_train_before: int, n_since_last_fit: int, n_new: int, fit_n_points: int):
     """The size classes of ``update_gp`` (bo.py:632-655) -> (refit, n_restarts, maxiter, points since the last fit).
     Strict '<' on both sides as in the reference: N == 200 and N >= 750 both land in the last branch."""
@@ -84,14 +100,15 @@ class BOBE:
                  clf_use_size: int = 10, clf_update_step: int = 1, minus_inf: float = -1e10,
                  seed: Optional[int] = None, verbosity: str = "INFO", device: int = 0):
         """Keywords of the reference constructor (bo.py:69-96) plus ``device``.  ``loglikelihood`` must be a callable
-        on physical parameters (Cobaya likelihoods and ``resume`` belong to the parts that are not built, DESIGN.md 7);
-        ``save`` writes ``<save_dir>/<likelihood_name>_gp.npz`` every ``save_step`` iterations (bo.py:239);
-        ``use_clf`` selects ``GPwithClassifier`` (SVM) with the thresholds derived from ``clf_nsigma_threshold``."""
+        on physical parameters (Cobaya likelihoods belong to the parts that are not built, DESIGN.md 7);
+        ``save`` writes ``<save_dir>/<likelihood_name>_gp.npz`` (+ the run state) every ``save_step`` iterations
+        (bo.py:239); ``resume=True, resume_file=<save_dir>/<likelihood_name>`` continues from those files instead of
+        drawing and evaluating an initial design (bo.py:205-206, 327-381; a file that cannot be loaded falls back to a
+        fresh start, as there); ``use_clf`` selects ``GPwithClassifier`` (SVM) with the thresholds derived from
+        ``clf_nsigma_threshold``."""
         import logging
         if not callable(loglikelihood):
             raise NotImplementedError("only a callable log-likelihood is supported (Cobaya adaptors are out of scope)")
-        if resume:
-            raise NotImplementedError("resume is not built; reload a saved GP with GP.load and pass init_train_x/y")
         if param_list is None or param_bounds is None:
             raise ValueError("param_list and param_bounds are required with a callable log-likelihood")
         logging.getLogger("bobe_amd").setLevel(getattr(logging, str(verbosity).upper(), logging.INFO))
@@ -109,6 +126,12 @@ class BOBE:
         self.timing: Dict[str, float] = {"GP Training": 0.0, "Acquisition Optimization": 0.0,
                                          "True Objective Evaluations": 0.0}
         self.n_points_since_last_fit = 0
+        self.save_path = os.path.join(self.save_dir, self.likelihood_name)
+        self.fresh_start, self._resume_state = True, None
+        if resume and resume_file is not None:
+            self._handle_resume(str(resume_file), use_clf)
+        if not self.fresh_start:
+            return
         # Sobol initial design (bo.py:521-529), optionally after user-supplied points (bo.py:505-519)
         n_sobol = max(2, n_sobol_init)
         sobol = qmc.Sobol(d=self.ndim, scramble=True, seed=self.np_rng).random(n_sobol)
@@ -134,6 +157,53 @@ class BOBE:
             self.gp = GP(x_u, vals, param_names=self.param_list, device=device, **kw)
         gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng)        # bo.py:611
         self.timing["GP Training"] += time.time() - t0
+
+    def _handle_resume(self, resume_file: str, use_clf: bool) -> None:
+        """bo.py:327-381: the GP from ``<resume_file>_gp.npz`` (tested with one prediction), the run state from
+        ``<resume_file>_run.json`` when it is there (a GP file alone resumes at iteration 0 with that training set)."""
+        gp_file = resume_file + "_gp"
+        try:
+            log.info(f"Attempting to resume from file {resume_file}")
+            self.gp = load_gp_file(gp_file, use_clf, device=self.device)
+            _ = self.gp.predict_mean_single(self.gp.train_x[0])
+            log.info(f"Loaded GP with {self.gp.train_x.shape[0]} training points")
+        except Exception as e:
+            log.error(f"Failed to load GP from file {gp_file}: {e}")
+            log.info("Starting a fresh run instead.")
+            self.fresh_start = True
+            return
+        self.fresh_start = False
+        try:
+            with open(resume_file + "_run.json") as fh:
+                st = json.load(fh)
+            if int(st.get("gp_training_set_size", -1)) != int(self.gp.npoints):
+                raise ValueError(f"run state is for {st.get('gp_training_set_size')} training points, the GP file has "
+                                 f"{self.gp.npoints}")
+            mc_file = resume_file + "_mc.npz"
+            if st.get("has_mc") and os.path.exists(mc_file):
+                z = np.load(mc_file, allow_pickle=False)
+                st["mc"] = {k: (z[k] if z[k].shape != () else z[k].item()) for k in z.files}
+            self._resume_state = st
+            log.info(f"Resuming from iteration {st['iteration']} ({st['current_evals']} evaluations so far)")
+        except FileNotFoundError:
+            log.info("No run state beside the GP file: resuming with its training set at iteration 0")
+        except Exception as e:
+            log.warning(f"Run state {resume_file}_run.json unusable ({e}): resuming with the GP file alone")
+
+    def _checkpoint(self, state: dict, mc: Optional[dict]) -> None:
+        """``<save_path>_gp.npz`` (bo.py:239) and, beside it, the run state a resumed run continues from."""
+        os.makedirs(self.save_dir, exist_ok=True)
+        self.gp.save(self.save_path + "_gp")
+        st = dict(state, rng_state=self.np_rng.bit_generator.state, gp_training_set_size=int(self.gp.npoints),
+                  n_points_since_last_fit=int(self.n_points_since_last_fit), timing=dict(self.timing),
+                  has_mc=mc is not None)
+        if mc is not None:                                              # (arrays and scalars; acquisition uses 'x' only)
+            np.savez(self.save_path + "_mc.npz", **{k: np.asarray(v) for k, v in mc.items()
+                                                    if isinstance(v, (np.ndarray, float, int, str, np.generic))})
+        tmp = self.save_path + "_run.json.tmp"
+        with open(tmp, "w") as fh:
+            json.dump(st, fh)
+        os.replace(tmp, self.save_path + "_run.json")                  # (never a half-written state file)
 
     def _evaluate(self, pts: np.ndarray) -> np.ndarray:
         """Safe likelihood wrapper (likelihood.py:69-91): NaN / exceptions / -inf -> minus_inf."""
@@ -220,10 +290,31 @@ class BOBE:
                 return "Maximum GP size reached"
             return None
 
-        if is_wip:
+        mc = None
+        rs = self._resume_state
+        self._resume_state = None                                # (a second run() on this object starts from its current state)
+        if rs is not None and rs.get("acq", acq).lower() == acq.lower():
+            # continue the interrupted run (bo.py:337-372: iteration, histories, convergence state)
+            it, current_evals, n_since_ns, counter = rs["iteration"], rs["current_evals"], rs["n_since_ns"], rs["counter"]
+            acq_hist, logz = list(rs["acq_history"]), dict(rs.get("logz") or {})
+            self.n_points_since_last_fit = int(rs.get("n_points_since_last_fit", 0))
+            for k_, v_ in (rs.get("timing") or {}).items():
+                self.timing[k_] = float(v_)
+            self.np_rng.bit_generator.state = rs["rng_state"]
+            mc = rs.get("mc")
+            if rs.get("converged"):                              # the saved run had already met its stopping rule
+                converged, reason = True, rs.get("termination_reason", "LogZ converged")
+        if is_wip and mc is None:
             t0 = time.time()
             mc = self._mc_samples(*mc_args)
             self.timing["MCMC Sampling"] += time.time() - t0
+
+        def run_state():
+            return {"acq": acq, "iteration": it, "current_evals": int(current_evals), "n_since_ns": int(n_since_ns),
+                    "counter": int(counter), "acq_history": [float(a) for a in acq_hist], "converged": bool(converged),
+                    "termination_reason": reason,
+                    "logz": {k_: (float(v_) if isinstance(v_, (int, float, np.floating, np.integer)) else v_)
+                             for k_, v_ in logz.items() if isinstance(v_, (int, float, bool, np.floating, np.integer))}}
         while not converged:
             it += 1
             t0 = time.time()
@@ -282,8 +373,7 @@ class BOBE:
                 else:
                     counter = 0
             if self.save and it % self.save_step == 0:
-                import os
-                self.gp.save(os.path.join(self.save_dir, f"{self.likelihood_name}_gp"))
+                self._checkpoint(run_state(), mc if is_wip else None)
             if converged:
                 break
             budget = check_budget()
@@ -316,8 +406,7 @@ class BOBE:
             samples = {"x": scale_from_unit(np.asarray(x_u), self.param_bounds), "weights": np.asarray(weights),
                        "logl": np.asarray(logl)}
         if self.save:
-            import os
-            self.gp.save(os.path.join(self.save_dir, f"{self.likelihood_name}_gp"))
+            self._checkpoint(run_state(), mc if is_wip else None)
         y = self.gp.train_y * self.gp.y_std + self.gp.y_mean
         ibest = int(np.argmax(y))
         best_x = scale_from_unit(self.gp.train_x[ibest], self.param_bounds)

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -138,10 +139,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep, fill, fill_near, fill_chunk, fill_slack, fill_phase; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0};
+    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0, 1, 2, 3, 16, 1024};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -155,6 +156,12 @@ const Tuning& tuning() {
     // timing experiment: stand-in MFMA workgroups on the CUs a panel launch leaves empty (results unaffected)
     if (const char* e = std::getenv("BOBE_FILLER_ITERS")) v.filler_iters = std::atoi(e);
     if (const char* e = std::getenv("BOBE_FILLER_KEEP")) v.filler_keep = std::atoi(e);      // CUs left empty anyway
+    // deferred trailing updates in the shadow of the panel launches (potrf): 0 = off (every update in its own launch)
+    if (const char* e = std::getenv("BOBE_FILL")) v.fill = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_FILL_NEAR")) v.fill_near = std::max(1, std::atoi(e));   // last panels of a column: never deferred
+    if (const char* e = std::getenv("BOBE_FILL_CHUNK")) v.fill_chunk = std::max(1, std::atoi(e)); // panels per filler visit of a tile
+    if (const char* e = std::getenv("BOBE_FILL_PHASE")) v.fill_phase = std::atoi(e);   // fillers ride in panel launches with B rem^2 <= this
+    if (const char* e = std::getenv("BOBE_FILL_SLACK")) v.fill_slack = std::max(1, std::atoi(e)); // deferred / caught-up work the plan accepts
     return v;
   }();
   return t;
@@ -193,6 +200,29 @@ struct bobe_gp {
   // sweep / predict workspace
   DBuf wg_ws;     // workspace of bobe_gp_wip_grad's few-candidates path
   DBuf filler_ws; // BOBE_FILLER_ITERS experiment
+  // Launch plan of a factorisation (potrf): which panel launch carries which deferred update tiles, and from which
+  // panel on every block column still has to be updated by each separate update launch.  Host logic only (a function of
+  // the block count, the batch width and the CU count); the tables live on the device.
+  struct CholOp {
+    int kind;             // 0 panel, 1 narrow update (block column `first`), 2 trailing update (block columns >= first)
+    int k;                // panel: block index; updates: one past the last panel to apply (k1)
+    int first;
+    int tab_off, tab_cnt; // panel: filler jobs [off, off + cnt) of `jobs`; updates: offset of the column table in `colk0`
+    int k0_min, k0_max;   // updates: smallest / largest first pending panel over the columns the launch touches
+    bool uniform;         // updates: every column from `first` on takes part with the same first panel (no table needed)
+    int last_active;      // updates: last block column that takes part
+    int k0_plain;         // updates: first pending panel of the columns that are not deferred (they all share it)
+  };
+  struct CholPlan {
+    std::vector<CholOp> ops;
+    std::vector<FillJob> jobs;
+    std::vector<int> colk0;
+    DBuf d_jobs, d_colk0;
+    int far_start = 0;    // first deferred block column (nb: none)
+    int64_t deferred_units = 0, catchup_units = 0;
+  };
+  std::map<uint64_t, CholPlan> chol_plans;
+  const CholPlan& chol_plan(int B, bool fill);
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
   std::vector<Depth> depths;
@@ -315,7 +345,8 @@ struct bobe_gp {
                            int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo);
   void assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev = nullptr, int B = 1,
                     int64_t bsX = 0, int64_t bsA = 0);
-  void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0);
+  void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0, const int* colk0 = nullptr,
+            int far_col = 0, int ncols = 0);
   // defer_diag: leave the L_kk scratch blocks where they are; the trtri() that follows puts them in place (one launch less)
   void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0, double* dg = nullptr,
              bool defer_diag = false);
@@ -445,25 +476,152 @@ void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a, const H
 // per wave (512 / 128 / 32 per 128 of K): small trailing matrices take the smallest tile that still fills the
 // chip, large ones the cheapest by a rounds x tile-time estimate.  (Tile shape does not change the bits: every
 // element accumulates its K range in the same order, four k per MFMA.)
-void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int64_t bsA) {
+// colk0 (device table, one entry per block column): the columns of the launch start at different panels (deferred
+// columns, see potrf) - 64 x 64 tiles only.
+void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int64_t bsA, const int* colk0, int far_col,
+                   int ncols) {
   const Tuning& tu = tuning();
   const int rem = nb - first;                 // 128-blocks in the trailing matrix
-  if (rem <= 0 || k1 <= k0) return;
+  if (rem <= 0 || (!colk0 && k1 <= k0)) return;
   const int kb = k1 - k0;
   const int n64 = 2 * rem, n32 = 4 * rem;
-  const int t64 = colmode ? 2 * n64 - 1 : n64 * (n64 + 1) / 2;
+  // colmode 2: only the first `ncols` block columns of the trailing matrix take part (the rest is deferred)
+  const int nc64 = 2 * ncols;
+  const int t64 = colmode == 2 ? nc64 * n64 - nc64 * (nc64 - 1) / 2 : (colmode ? 2 * n64 - 1 : n64 * (n64 + 1) / 2);
   const int t32 = colmode ? 4 * n32 - 6 : n32 * (n32 + 1) / 2;
   // 64x64 tiles with BK = 16 (36 KB of LDS, four workgroups per CU) have the best saturated throughput of all
   // variants at every K (tools/ubench_syrk.hip); when they would leave most of the chip idle, a single-panel
   // update takes 32x32 tiles, which stage the whole K = 128 panel in one LDS buffer
-  if (kb == 1 && B * t64 < tu.syrk32_below) {
+  if (kb == 1 && !colk0 && colmode != 2 && B * t64 < tu.syrk32_below) {
     hipLaunchKernelGGL((k_syrk_trail<32, SYRK32_BK>), dim3(t32, B), dim3(256), SYRK32_SMEM, stream, a, Np, k0, k1, first,
-                       colmode, n32, bsA);
+                       colmode, n32, bsA, 0, (const int*)nullptr, 0, 0);
     return;
   }
   const TileGrid tg = colmode ? TileGrid{t64, 0} : tile_grid(t64);
   hipLaunchKernelGGL((k_syrk_trail<64, SYRK64_BK>), dim3(tg.grid, B), dim3(256), SYRK64_SMEM, stream, a, Np, k0, k1, first,
-                     colmode, n64, bsA, tg.per);
+                     colmode, n64, bsA, tg.per, colk0, far_col, nc64);
+}
+
+// The launch plan of a factorisation of B matrices in lock step (see potrf).  Block columns >= far_start are DEFERRED:
+// the update launches leave them alone until they are about to be factored (the last `fill_near` panels of a column
+// always come from the update launches), and the panel launches carry their pending updates as filler workgroups on the
+// CUs the panel workgroups do not occupy - whole block columns at a time, `fill_chunk` panels per visit (a filler must
+// not outlast the panel, ~28 us), earliest deadline first.  far_start is the smallest column from which the fillers keep
+// up (what they leave behind is caught up by the update launch that makes the column current, with a longer K range).
+const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill) {
+  const Tuning& tu = tuning();
+  const uint64_t key = ((uint64_t)nb << 32) | ((uint64_t)B << 8) | (fill ? 1u : 0u);
+  auto it = chol_plans.find(key);
+  if (it != chol_plans.end()) return it->second;
+  const int ncu = std::max(num_cus, 1);
+  const int D = tu.fill_near, CH = tu.fill_chunk;
+  auto npanel = [&](int k) { const int rr = nb - 1 - k; return rr > 0 ? 2 * rr : 1; };
+  auto one_launch = [&](int k) { return !tu.chol_legacy && B * npanel(k) <= ncu; };
+  auto tiles_of = [&](int c) { return 4 * (nb - c) - 1; };   // 64 x 64 tiles of block column c from its diagonal block down
+  auto build = [&](int far, CholPlan* out) {
+    std::vector<int> applied(nb, 0);
+    int64_t deferred = 0, catchup = 0;
+    auto panel = [&](int k) {
+      CholOp op{0, k, k, out ? (int)out->jobs.size() : 0, 0, 0, 0, true, k, k};
+      const int64_t remk = nb - 1 - k;
+      if (fill && far < nb && one_launch(k) && (int64_t)B * remk * remk <= tu.fill_phase) {
+        int cap = (ncu - tu.filler_keep - B * npanel(k)) / B;           // filler workgroups per slot, two tiles each
+        for (int c = std::max(far, k + 2); c < nb && cap > 0; ++c) {     // earliest deadline first
+          const int pend = std::min(k, c - D);                           // panels < k are final; the last D are never deferred
+          if (applied[c] >= pend) continue;
+          const int k1 = std::min(applied[c] + CH, pend);
+          const int need = (tiles_of(c) + 1) / 2;
+          if (need > cap) continue;
+          cap -= need;
+          deferred += (int64_t)tiles_of(c) * (k1 - applied[c]);
+          if (out) {
+            for (int tj = 2 * c; tj <= 2 * c + 1; ++tj)
+              for (int ti = tj; ti < 2 * nb; ++ti) out->jobs.push_back({ti, tj, applied[c], k1});
+            const FillJob last = out->jobs.back();                       // an odd count: a twin that is computed, not stored,
+            out->jobs.push_back({-last.ti - 1, last.tj, last.k0, last.k1});  // keeps the two groups of a workgroup in step
+            op.tab_cnt += tiles_of(c) + 1;
+          }
+          applied[c] = k1;
+        }
+      }
+      if (out) out->ops.push_back(op);
+    };
+    auto update = [&](int kind, int first, int k1, int last_near, int newest) {
+      // columns taking part: the block column `first` alone (narrow) or every column from `first` on that is not deferred
+      // or is within `fill_near` panels of being factored (c <= last_near)
+      CholOp op{kind, k1, first, out ? (int)out->colk0.size() : 0, nb, INT_MAX, INT_MIN, true, first, k1};
+      std::vector<int> tab(nb, k1);
+      const int cend = kind == 1 ? first + 1 : nb;
+      for (int c = first; c < cend; ++c) {
+        const bool active = c < far || c <= last_near;
+        if (!active) { op.uniform = false; continue; }
+        tab[c] = applied[c];
+        op.last_active = c;
+        if (c < far) op.k0_plain = applied[c];
+        op.k0_min = std::min(op.k0_min, applied[c]);
+        op.k0_max = std::max(op.k0_max, applied[c]);
+        if (c >= far) catchup += (int64_t)tiles_of(c) * std::max(0, (k1 - applied[c]) - newest);   // beyond the newest panel(s)
+        applied[c] = k1;
+      }
+      if (op.k0_min != op.k0_max) op.uniform = false;
+      if (op.k0_min == INT_MAX) return;                                   // nothing to do
+      if (out) {
+        out->colk0.insert(out->colk0.end(), tab.begin(), tab.end());
+        out->ops.push_back(op);
+      }
+    };
+    for (int k = 0; k < nb;) {
+      const int rem = nb - 1 - k;
+      panel(k);
+      // Update-bound steps go in PAIRS: panel k, block column k+1 <- its pending panels (narrow), panel k+1, then ONE
+      // trailing pass with both panels (K = 256): half the passes over the trailing matrix and a tile kernel that runs
+      // 15 % faster at K = 256 than at 128, for one narrow launch more on the chain.  Same bits (every element still
+      // receives panel k before panel k+1).
+      if (!tu.chol_legacy && tu.pair_min > 0 && rem >= 2 && (int64_t)B * rem * rem > tu.pair_min) {
+        update(1, k + 1, k + 1, nb, 1);
+        panel(k + 1);
+        update(2, k + 2, k + 2, k + 1 + D, 2);
+        k += 2;
+      } else {
+        if (rem > 0) update(2, k + 1, k + 1, k + D, 1);
+        k += 1;
+      }
+    }
+    if (out) {
+      out->far_start = far;
+      out->deferred_units = deferred;
+      out->catchup_units = catchup;
+    }
+    return std::make_pair(deferred, catchup);
+  };
+  int far = nb;
+  if (fill) {
+    for (int f = 1; f < nb; ++f) {
+      const auto dc = build(f, nullptr);
+      if (dc.first > 0 && dc.second * tu.fill_slack <= dc.first) { far = f; break; }
+    }
+  }
+  CholPlan& pl = chol_plans[key];
+  build(far, &pl);
+  for (const FillJob& j : pl.jobs) {           // (the tables drive device addresses: check them on the host)
+    const int ti = j.ti >= 0 ? j.ti : -j.ti - 1;
+    if (ti < j.tj || ti >= 2 * nb || j.tj < 0 || j.k0 < 0 || j.k1 <= j.k0 || j.k1 * 2 > j.tj)
+      throw Err(BOBE_ERR_STATE, "internal error: filler job outside the trailing matrix");
+  }
+  if (!pl.jobs.empty()) {
+    pl.d_jobs.ensure(pl.jobs.size() * sizeof(FillJob));
+    HIPCHK(hipMemcpy(pl.d_jobs.p, pl.jobs.data(), pl.jobs.size() * sizeof(FillJob), hipMemcpyHostToDevice));
+  }
+  bool need_tab = false;                      // (a plan without deferred columns needs no device table: its launches are
+  for (const CholOp& op : pl.ops) need_tab = need_tab || (op.kind != 0 && !op.uniform);   // uniform - and it may be built
+  if (need_tab) {                             //  while a slot's stream is capturing, where allocations are not allowed)
+    pl.d_colk0.ensure(pl.colk0.size() * sizeof(int));
+    HIPCHK(hipMemcpy(pl.d_colk0.p, pl.colk0.data(), pl.colk0.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  if (std::getenv("BOBE_TRACE"))
+    std::fprintf(stderr, "[bobe] chol plan nb=%d B=%d fill=%d: deferred columns from %d, %lld tile-panels in fillers (%zu jobs), %lld caught up\n",
+                 nb, B, (int)fill, pl.far_start, (long long)pl.deferred_units, pl.jobs.size(), (long long)pl.catchup_units);
+  return pl;
 }
 
 // Blocked right-looking Cholesky (NB = 128) of B matrices in lock step on one stream; every launch carries the slot
@@ -472,34 +630,53 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
 //             the diagonal block itself) while all B * 2 * (nb-1-k) workgroups fit on the chip at once, else the
 //             k_potf2 + k_trsm_panel pair (one factorisation per slot).
 //   update    A22 -= L21 L21^T on the lower tiles (k_syrk_trail).
-//             Update-bound steps go in pairs: one K = 256 pass for two panels (see the loop).
+//             Update-bound steps go in pairs: one K = 256 pass for two panels (chol_plan).
 // A batch shares the latency-bound panel chain (32 x ~28 us at N = 4096, the same for 1 or 8 matrices) and gives the
 // update 4-8x the tiles: 41 % of the fp64 MFMA peak with four in flight, 49 % with eight, against 18 % alone and 28 %
 // for four on private streams (whose 150 KB-LDS panel kernels wait for a CU the others' update tiles keep occupied).
+// The panel launches leave most of the chip empty (one 150 KB workgroup per 64 rows): updates of block columns that are
+// not needed soon are DEFERRED and ride in those launches as filler workgroups (chol_plan, k_chol_panel<., true>) - not on
+// an evaluation slot's private stream, where the other slots' kernels want those CUs.
 // Every matrix element sees the same operation sequence in all forms (same bits).
 void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg, bool defer_diag) {
   const Tuning& tu = tuning();
   if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches
   const int64_t bsD = (int64_t)nb * TILE * TILE;
   int first_aside = nb;                                       // first step whose L_kk was left in the scratch blocks
-  for (int k = 0; k < nb; ++k) {
-    const int rem = nb - 1 - k;
-    auto panel = [&](int kk) {                                // (64 rows of the panel per workgroup)
+  // Where the fillers pay (measured, profiles/r03_fill_ab.txt): a lone factorisation of 3072..4608 points - its chain
+  // leaves 3/4 of the chip empty and its update launches are latency-bound (N = 4096: 1.60 -> 1.44 ms).  Smaller: the
+  // updates are a few microseconds each anyway; larger, or several matrices in lock step: the panel launches have few CUs
+  // to spare, a filler workgroup (one per CU, eight waves) runs the tile core at ~3/4 of its usual rate, and a launch
+  // lasts as long as its slowest filler (B = 4 at N = 4096: 2.83 -> 2.85 ms; N = 8192 alone: 5.6 -> 6.2 ms).
+  // BOBE_FILL=2 forces them on everywhere, BOBE_FILL=0 off.
+  const bool fill = tu.fill != 0 && !in_slot && !tu.chol_legacy && tu.filler_iters == 0 &&
+                    (tu.fill == 2 || (B == 1 && nb >= 24 && nb <= 36));
+  const CholPlan& pl = chol_plan(B, fill);
+  const FillJob* jobs = static_cast<const FillJob*>(pl.d_jobs.p);
+  const int* coltab = static_cast<const int*>(pl.d_colk0.p);
+  for (const CholOp& op : pl.ops) {
+    if (op.kind == 0) {                                       // (64 rows of the panel per workgroup)
+      const int kk = op.k;
       const int rr = nb - 1 - kk;
       const int np_ = rr > 0 ? 2 * rr : 1;
       const int nv = (int)std::min<int64_t>(TILE, N - (int64_t)kk * TILE);
       if (!tu.chol_legacy && B * np_ <= std::max(num_cus, 1)) {
         first_aside = std::min(first_aside, kk);
         prof_begin(BOBE_PROF_POTF2);
-        const int fill = tu.filler_iters > 0 ? std::max(0, (num_cus - tu.filler_keep - B * np_) / B) : 0;
-        if (fill > 0) {
-          filler_ws.ensure((size_t)B * (np_ + fill) * PANEL_THREADS * sizeof(double));
-          hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + fill, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np,
-                             bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, tu.filler_iters,
-                             filler_ws.d());
+        const int standin = tu.filler_iters > 0 ? std::max(0, (num_cus - tu.filler_keep - B * np_) / B) : 0;
+        if (op.tab_cnt > 0) {
+          hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + op.tab_cnt / 2, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES,
+                             stream, a, Np, bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr,
+                             jobs + op.tab_off, op.tab_cnt, 0, (double*)nullptr);
+        } else if (standin > 0) {
+          filler_ws.ensure((size_t)B * (np_ + standin) * PANEL_THREADS * sizeof(double));
+          hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + standin, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream,
+                             a, Np, bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr,
+                             (const FillJob*)nullptr, 0, tu.filler_iters, filler_ws.d());
         } else {
-          hipLaunchKernelGGL(k_chol_panel<false>, dim3(np_, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv, Np, bsL,
-                             kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr);
+          hipLaunchKernelGGL(k_chol_panel<false>, dim3(np_, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv,
+                             Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, (const FillJob*)nullptr, 0,
+                             0, (double*)nullptr);
         }
         prof_end(BOBE_PROF_POTF2);
       } else {
@@ -514,27 +691,17 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
           prof_end(BOBE_PROF_TRSM);
         }
       }
-    };
-    // Update-bound steps go in PAIRS: panel k, block column k+1 <- panel k (narrow), panel k+1, then ONE trailing pass
-    // with both panels (K = 256): half the passes over the trailing matrix and a tile kernel that runs 15 % faster at
-    // K = 256 than at 128, for one narrow launch more on the chain.  Same bits (every element still receives panel k
-    // before panel k+1).
-    if (!tu.chol_legacy && tu.pair_min > 0 && rem >= 2 && (int64_t)B * rem * rem > tu.pair_min) {
-      panel(k);
+    } else {
       prof_begin(BOBE_PROF_SYRK);
-      syrk(a, k, k + 1, k + 1, 1, B, bsA);
-      prof_end(BOBE_PROF_SYRK);
-      panel(k + 1);
-      prof_begin(BOBE_PROF_SYRK);
-      syrk(a, k, k + 2, k + 2, 0, B, bsA);
-      prof_end(BOBE_PROF_SYRK);
-      ++k;
-      continue;
-    }
-    panel(k);
-    if (rem > 0) {
-      prof_begin(BOBE_PROF_SYRK);
-      syrk(a, k, k + 1, k + 1, 0, B, bsA);
+      if (op.uniform) {
+        syrk(a, op.k0_min, op.k, op.first, op.kind == 1 ? 1 : 0, B, bsA);
+      } else {
+        // (columns before far_start share one first panel and take it as a scalar; deferred ones read the table.  A launch
+        // whose active columns are few enumerates just those)
+        const int ncols = op.last_active - op.first + 1;
+        const bool few = ncols <= 8 && ncols < nb - op.first;
+        syrk(a, op.k0_plain, op.k, op.first, few ? 2 : 0, B, bsA, coltab + op.tab_off, pl.far_start, few ? ncols : 0);
+      }
       prof_end(BOBE_PROF_SYRK);
     }
   }

@@ -602,29 +602,59 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
 // panel k of every slot as ONE launch (grid = npanel x nbatch, PANEL_THREADS threads).  Replaces the k_potf2 +
 // k_trsm_panel pair when all nbatch*npanel workgroups fit on the chip at once (the redundant factorisations then cost
 // nothing and one kernel boundary plus the L_kk round trip through global memory go away).
-// FILL (timing experiments only, BOBE_FILLER_ITERS): workgroups with blockIdx.x >= npanel run fill_iters rounds of eight
-// independent MFMAs per wave instead of panel work - a stand-in for GEMM tiles placed in the shadow of the panel chain
-// (same launch, same 150 KB / 512-thread shape), to measure what such tiles would cost the panel.  Results discarded.
+// FILL: the launch carries extra workgroups (blockIdx.x >= npanel) that do NOT belong to the panel: they run trailing-
+// update tiles that are not needed yet ("deferred" far columns of the trailing matrix, see potrf() in bobe_gp.hip) on the
+// CUs the panel chain leaves empty.  A filler workgroup = two 256-thread groups, one 64 x 64 tile each, both with the same
+// K range (panels [k0, k1) of its job: columns < k are final while panel k is being factored), on the tile core of
+// k_syrk_trail - the same arithmetic per element as the separate update launch, only earlier and for free.
+// (Measured with stand-in MFMA workgroups first, profiles/r03_filler_standin.txt: up to ~8 MFLOP per filler workgroup the
+// factorisation takes exactly as long as without them; beyond that the launch lasts as long as its slowest filler.)
+// BOBE_FILLER_ITERS > 0 (timing experiments): the fillers run that many rounds of eight MFMAs instead.
+struct FillJob { int ti, tj, k0, k1; };   // 64 x 64 tile (ti, tj) of the padded matrix; panels (128-blocks) [k0, k1)
+#ifndef BOBE_FILL_BK
+#define BOBE_FILL_BK 32
+#endif
+constexpr int FILL_BK = BOBE_FILL_BK;
+constexpr int FILL_SMEM_DOUBLES = gemm_smem_doubles_exact<KC, KC, 64, 64, FILL_BK>();   // per group; two groups fit the panel's 150 KB
 template <bool STAMP = false, bool FILL = false>
 __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
                                                               double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
                                                               int npanel, int* __restrict__ info, int nvalid,
                                                               double* __restrict__ diag, int64_t bsD,
                                                               unsigned long long* __restrict__ stamps = nullptr,
+                                                              const FillJob* __restrict__ jobs = nullptr, int njobs = 0,
                                                               int fill_iters = 0, double* __restrict__ fill_out = nullptr) {
   if (FILL && (int)blockIdx.x >= npanel) {
-    v4d acc[8];
+    if (fill_iters > 0) {
+      v4d acc[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int it = 0; it < fill_iters; ++it) {
+      for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+      const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+      for (int it = 0; it < fill_iters; ++it) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+      }
+      double sres = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sres += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+      if (fill_out) fill_out[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * PANEL_THREADS + threadIdx.x] = sres;
+      return;
     }
-    double sres = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sres += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (fill_out) fill_out[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * PANEL_THREADS + threadIdx.x] = sres;
+    extern __shared__ double S[];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int idx = 2 * ((int)blockIdx.x - npanel) + grp;
+    if (idx >= njobs) return;                 // (never: the job lists have even length, a workgroup = one pair)
+    const FillJob jb = jobs[idx];
+    // a block column has an odd number of tiles: its last pair is completed by a twin (ti stored as -ti-1) that is computed
+    // but not written back, so that both groups of the workgroup pass the same number of workgroup-wide barriers
+    const bool live = jb.ti >= 0;
+    const int64_t r0 = (int64_t)(live ? jb.ti : -jb.ti - 1) * 64, c0 = (int64_t)jb.tj * 64;
+    double* As = A + blockIdx.y * bsA;
+    v4d acc[2][2];
+    load_tile<64, 64>(acc, As, lda, r0, c0, tid);
+    gemm_tile<KC, KC, 64, 64, FILL_BK, true>(acc, As, lda, r0, As, lda, c0, (int64_t)jb.k0 * TILE, (int64_t)jb.k1 * TILE,
+                                        S + grp * FILL_SMEM_DOUBLES, tid);
+    if (live) store_tile<64, 64>(acc, As, lda, r0, c0, 1.0, 0.0, tid);
     return;
   }
   const int slot = blockIdx.y;
@@ -650,9 +680,15 @@ __global__ __launch_bounds__(256) void k_copy_diag(double* __restrict__ A, int64
 // The tiles start at 128-block `first`; n = trailing size in T-tiles.  colmode 0: every lower tile (grid =
 // n(n+1)/2).  colmode 1: only the tiles of 128-block column `first` (the next block column of a super-panel):
 // tile columns b < 128/T, rows b <= a < n, grid = S n - S(S-1)/2 with S = 128/T.
+// colmode 2: the tiles of the first `ncol` T-columns only (rows from the diagonal down) - the few block columns an update
+// touches when everything behind them is deferred.
+// colk0 / far_col (optional, 64x64 tiles only): block columns >= far_col read their first pending panel from colk0[column]
+// (deferred columns: the K range [colk0[c], k1) differs from column to column; colk0[c] >= k1 skips the column); columns
+// before far_col take the scalar k0 without touching memory.
 template <int T, int BK>
 __global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int64_t lda, int k0, int k1, int first,
-                                                    int colmode, int n, int64_t bsA = 0, int per = 0) {
+                                                    int colmode, int n, int64_t bsA = 0, int per = 0,
+                                                    const int* __restrict__ colk0 = nullptr, int far_col = 0, int ncol = 0) {
   extern __shared__ double smem[];
   A += blockIdx.y * bsA;
   int a, b;
@@ -665,16 +701,20 @@ __global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int6
       tri_decode(blockIdx.x, a, b);
     }
   } else {
-    constexpr int S = TILE / T;
+    const int S = colmode == 1 ? TILE / T : ncol;
     int idx = blockIdx.x;
     b = 0;
-#pragma unroll
     for (int c = 0; c < S - 1; ++c)
       if (b == c && idx >= n - c) {
         idx -= n - c;
         b = c + 1;
       }
     a = b + idx;
+  }
+  if (colk0) {
+    const int col = first + (b * T) / TILE;
+    if (col >= far_col) k0 = colk0[col];
+    if (k0 >= k1) return;
   }
   const int64_t base = (int64_t)first * TILE;
   v4d acc[T / 32][T / 32];

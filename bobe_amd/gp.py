@@ -625,8 +625,8 @@ class GP:
         return gp
 
     @classmethod
-    def load(cls, filename, **kwargs):
-        """BOBE/gp.py:679-721."""
+    def load(cls, filename, device: int = 0, **kwargs):
+        """BOBE/gp.py:679-721 (``device``: HIP device of the restored GP)."""
         if not filename.endswith(".npz"):
             filename += ".npz"
         data = np.load(filename, allow_pickle=True)
@@ -635,7 +635,7 @@ class GP:
             value = data[key]
             state[key] = value.item() if isinstance(value, np.ndarray) and value.shape == () else value
         state.update(kwargs)
-        return cls.from_state_dict(state)
+        return cls.from_state_dict(state, device=device)
 
     def save(self, filename="gp"):
         """BOBE/gp.py:723-737."""

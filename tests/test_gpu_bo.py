@@ -52,3 +52,53 @@ def test_gp_fit_restart_recipe_matches_oracle():
     # so the two L-BFGS-B runs may stop a few 1e-7 apart in relative MLL
     assert r["mll"] == pytest.approx(ro["mll"], rel=1e-5)
     assert np.allclose(np.log(gp.get_hyperparams())[:2], ro["params"][:2], atol=5e-2)
+
+
+def test_run_level_resume_continues_the_interrupted_run(tmp_path):
+    """bo.py:327-381: ``BOBE(..., resume=True, resume_file=<save_dir>/<name>)`` rebuilds the run from ``<name>_gp.npz``
+    (L and alpha restored without a factorisation) and the run state saved beside it.  The resumed run must CONTINUE
+    the interrupted one: same kriging-believer picks as an uninterrupted run with the same seed (BASELINE config 1's
+    likelihood and settings, shortened)."""
+    import math
+    from bobe_amd.bo import BOBE
+
+    def banana(x):                                              # examples/Banana.py: curved 2-D likelihood
+        return -0.25 * (5 * (0.2 - x[0])) ** 2 - (20 * (x[1] / 4 - x[0] ** 4)) ** 2
+
+    bounds = np.array([[-1.0, 1.0], [-1.0, 2.0]]).T
+    kw = dict(acq="wipstd", min_evals=100, fit_n_points=4, batch_size=2, mc_points_size=64, mc_points_method="uniform",
+              num_mc_samples=512, logz_threshold=1e-6)
+
+    def make(**extra):
+        return BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=123, likelihood_name="banana", **extra)
+    full = make().run(max_evals=28, **kw)                        # uninterrupted: 8 + 10 x 2 evaluations
+    d1 = str(tmp_path / "run")
+    first = make(save=True, save_dir=d1, save_step=1).run(max_evals=18, **kw)
+    assert first["n_evals"] == 18 and (tmp_path / "run" / "banana_gp.npz").exists()
+    assert (tmp_path / "run" / "banana_run.json").exists() and (tmp_path / "run" / "banana_mc.npz").exists()
+    calls = []
+
+    def counting(x):
+        calls.append(np.array(x))
+        return banana(x)
+    again = BOBE(counting, ["x1", "x2"], bounds, n_sobol_init=8, seed=999, likelihood_name="banana", resume=True,
+                 resume_file=str(tmp_path / "run" / "banana"), save=True, save_dir=d1, save_step=1)
+    assert not again.fresh_start and again.gp.npoints == 18 and not calls          # no initial design is evaluated
+    assert np.array_equal(again.gp.cholesky, first["gp"].cholesky)                  # the factor came from the file
+    res = again.run(max_evals=28, **kw)
+    assert res["n_evals"] == 28 and len(calls) == 10
+    assert len(res["acq_history"]) == len(full["acq_history"]) == 10                # 5 iterations before + 5 after
+    # the same picks as the uninterrupted run (its GP state at the cut came from appends, the resumed one from the
+    # file: last-bit differences in L^-1 only)
+    assert np.allclose(res["gp"].train_x, full["gp"].train_x, atol=1e-6)
+    assert np.allclose(res["acq_history"], full["acq_history"], rtol=1e-5, atol=1e-12)
+    assert np.allclose(res["lengthscales"], full["lengthscales"], rtol=1e-4)
+    assert math.isclose(res["best_val"], full["best_val"], rel_tol=1e-9)
+    # a GP file without run state resumes at iteration 0 with that training set; an unreadable one starts afresh
+    (tmp_path / "run" / "banana_run.json").unlink()
+    bare = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=5, likelihood_name="banana", resume=True,
+                resume_file=str(tmp_path / "run" / "banana"))
+    assert not bare.fresh_start and bare.gp.npoints == 28 and bare._resume_state is None
+    fresh = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=5, likelihood_name="banana", resume=True,
+                 resume_file=str(tmp_path / "nothing_here" / "banana"))
+    assert fresh.fresh_start and fresh.gp.npoints == 8

@@ -28,3 +28,27 @@ def test_every_launch_sequence_gives_the_same_bits():
         other = _digests(variant)
         differing = [k for k in base if base[k] != other[k]]
         assert not differing, (variant, differing)
+
+
+def test_deferred_updates_in_the_panel_shadows_do_not_move_a_bit():
+    """potrf() lets trailing-update tiles of far block columns ride in the panel launches as filler workgroups
+    (k_chol_panel<., true>, chol_plan in bobe_gp.hip).  Where a tile is computed must not change what it holds: the
+    factor, MLL, gradient, batch results and predictions with the fillers forced on everywhere (BOBE_FILL=2: lone and
+    lock-step, ragged and full sizes, both kernels) equal, bit for bit, those with every update in its own launch
+    (BOBE_FILL=0).  The switches are read once per process, hence the child interpreters."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sizes = "300:3:rbf,1500:8:matern,2500:5:rbf,3200:6:matern,4096:8:rbf,5000:4:rbf"
+    digests = {}
+    for mode in ("0", "2", "1"):
+        env = dict(os.environ, BOBE_FILL=mode, BITS_SIZES=sizes, BOBE_LOCKSTEP_MIN_N="1024")
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "bits_snapshot.py"), "print"], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        digests[mode] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert digests["0"].keys() == digests["2"].keys() and len(digests["0"]) == 6 * 7
+    assert digests["2"] == digests["0"]
+    assert digests["1"] == digests["0"]                       # the default (fillers only where they pay)

@@ -11,7 +11,10 @@ from bobe_amd.gp import GP  # noqa: E402
 
 out = {}
 MAX_N = int(os.environ.get("BITS_MAX_N", 1 << 30))
-for N, d, kern in ((17, 2, "rbf"), (100, 3, "matern"), (129, 4, "rbf"), (641, 5, "rbf"), (1500, 8, "matern"), (2048, 8, "rbf"), (4096, 8, "rbf")):
+SIZES = ((17, 2, "rbf"), (100, 3, "matern"), (129, 4, "rbf"), (641, 5, "rbf"), (1500, 8, "matern"), (2048, 8, "rbf"), (4096, 8, "rbf"))
+if os.environ.get("BITS_SIZES"):          # e.g. BITS_SIZES=3000:5:matern,3500:8:rbf
+    SIZES = tuple((int(a), int(b), c) for a, b, c in (t.split(":") for t in os.environ["BITS_SIZES"].split(",")))
+for N, d, kern in SIZES:
     if N > MAX_N:
         continue
     rng = np.random.default_rng(N)

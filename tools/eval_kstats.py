@@ -24,7 +24,7 @@ else:
     rows = list(csv.DictReader(open(sys.argv[2])))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void bobe::", "").replace("bobe::", ""))
                 for r in rows)
-    last = max(i for i, e in enumerate(ev) if "k_scale_coords" in e[2])
+    last = max(i for i, e in enumerate(ev) if "k_scale_coords" in e[2] or "k_kernel_matrix" in e[2] and "k_scale_coords" not in ev[i - 1][2])
     seg = ev[last:]
     if sys.argv[1] == "timeline":
         t0, prev_end = seg[0][0], seg[0][0]
