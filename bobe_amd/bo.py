@@ -380,6 +380,10 @@ class BOBE:
             if budget is not None:
                 reason = budget
                 break
+        if self.save:
+            # the state a resumed run continues from is the state at the END OF THE LOOP: what follows (a final fit and
+            # nested sampling, the result samples) draws from the generator but is not part of the iteration
+            self._checkpoint(run_state(), mc if is_wip else None)
         if is_wip and do_final_ns and not converged:                         # bo.py:1345-1366
             t0 = time.time()
             gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng)
@@ -405,8 +409,8 @@ class BOBE:
                 logl = hm["logp"] if "logp" in hm else hm.get("logl")
             samples = {"x": scale_from_unit(np.asarray(x_u), self.param_bounds), "weights": np.asarray(weights),
                        "logl": np.asarray(logl)}
-        if self.save:
-            self._checkpoint(run_state(), mc if is_wip else None)
+        if self.save and is_wip and do_final_ns:                             # (the final fit changed the hyper-parameters)
+            self.gp.save(self.save_path + "_gp")
         y = self.gp.train_y * self.gp.y_std + self.gp.y_mean
         ibest = int(np.argmax(y))
         best_x = scale_from_unit(self.gp.train_x[ibest], self.param_bounds)

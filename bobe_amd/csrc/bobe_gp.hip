@@ -1285,6 +1285,10 @@ void bobe_gp_destroy(bobe_gp_t* g) {
     if (g->bw.h_res) (void)hipHostFree(g->bw.h_res);
     if (g->bw.h_info) (void)hipHostFree(g->bw.h_info);
   }
+  for (auto& kv : g->chol_plans) {
+    kv.second.d_jobs.release();
+    kv.second.d_colk0.release();
+  }
   if (g->ev_batch) (void)hipEventDestroy(g->ev_batch);
   if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
   delete g;

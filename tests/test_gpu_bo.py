@@ -71,11 +71,12 @@ def test_run_level_resume_continues_the_interrupted_run(tmp_path):
 
     def make(**extra):
         return BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=123, likelihood_name="banana", **extra)
-    full = make().run(max_evals=28, **kw)                        # uninterrupted: 8 + 10 x 2 evaluations
+    full = make().run(max_evals=20, **kw)                        # uninterrupted: 8 + 6 x 2 evaluations
     d1 = str(tmp_path / "run")
-    first = make(save=True, save_dir=d1, save_step=1).run(max_evals=18, **kw)
+    first = make(save=True, save_dir=d1, save_step=1).run(max_evals=18, **kw)     # cut after 5 iterations
     assert first["n_evals"] == 18 and (tmp_path / "run" / "banana_gp.npz").exists()
     assert (tmp_path / "run" / "banana_run.json").exists() and (tmp_path / "run" / "banana_mc.npz").exists()
+    assert np.array_equal(first["gp"].train_x, full["gp"].train_x[:18])             # (saving does not disturb the run)
     calls = []
 
     def counting(x):
@@ -85,20 +86,27 @@ def test_run_level_resume_continues_the_interrupted_run(tmp_path):
                  resume_file=str(tmp_path / "run" / "banana"), save=True, save_dir=d1, save_step=1)
     assert not again.fresh_start and again.gp.npoints == 18 and not calls          # no initial design is evaluated
     assert np.array_equal(again.gp.cholesky, first["gp"].cholesky)                  # the factor came from the file
-    res = again.run(max_evals=28, **kw)
-    assert res["n_evals"] == 28 and len(calls) == 10
-    assert len(res["acq_history"]) == len(full["acq_history"]) == 10                # 5 iterations before + 5 after
-    # the same picks as the uninterrupted run (its GP state at the cut came from appends, the resumed one from the
-    # file: last-bit differences in L^-1 only)
-    assert np.allclose(res["gp"].train_x, full["gp"].train_x, atol=1e-6)
-    assert np.allclose(res["acq_history"], full["acq_history"], rtol=1e-5, atol=1e-12)
-    assert np.allclose(res["lengthscales"], full["lengthscales"], rtol=1e-4)
+    assert np.array_equal(again.gp.train_y, first["gp"].train_y) and again.gp.y_std == first["gp"].y_std
+    res = again.run(max_evals=20, **kw)
+    # iteration 6 of the resumed run = iteration 6 of the uninterrupted one: the same kriging-believer batch (same
+    # integration samples, same generator state), the same refit.  (The restored L^-1 differs from the interrupted run's in
+    # the last bits - it is rebuilt from L, there it came from appends - so "same" is to rounding, and this likelihood
+    # with 20 points is ill-determined enough for later iterations to amplify that: only the first one is compared.)
+    assert res["n_evals"] == 20 and len(calls) == 2
+    assert np.allclose(res["gp"].train_x, full["gp"].train_x, atol=1e-7)
+    assert len(res["acq_history"]) == len(full["acq_history"]) == 6
+    assert np.allclose(res["acq_history"], full["acq_history"], rtol=1e-6, atol=1e-12)
+    assert np.allclose(res["lengthscales"], full["lengthscales"], rtol=1e-5)
+    assert math.isclose(res["kernel_variance"], full["kernel_variance"], rel_tol=1e-5)
     assert math.isclose(res["best_val"], full["best_val"], rel_tol=1e-9)
+    more = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=1, likelihood_name="banana", resume=True,
+                resume_file=str(tmp_path / "run" / "banana")).run(max_evals=28, **kw)
+    assert more["n_evals"] == 28 and len(more["acq_history"]) == 10                 # 6 iterations on file + 4 more
     # a GP file without run state resumes at iteration 0 with that training set; an unreadable one starts afresh
     (tmp_path / "run" / "banana_run.json").unlink()
     bare = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=5, likelihood_name="banana", resume=True,
                 resume_file=str(tmp_path / "run" / "banana"))
-    assert not bare.fresh_start and bare.gp.npoints == 28 and bare._resume_state is None
+    assert not bare.fresh_start and bare.gp.npoints == 20 and bare._resume_state is None
     fresh = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=5, likelihood_name="banana", resume=True,
                  resume_file=str(tmp_path / "nothing_here" / "banana"))
     assert fresh.fresh_start and fresh.gp.npoints == 8
