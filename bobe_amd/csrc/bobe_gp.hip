@@ -122,6 +122,8 @@ void configure_kernels_once() {
   allow_big_lds(k_lauum_grad<1, 32, 64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_trimul, GEMM_SMEM_BYTES);
   allow_big_lds(k_trimul_t, GEMM_SMEM_BYTES);
+  allow_big_lds(k_trimul_v64, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_trimul_t64, GEMM64_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 8, 128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 16, 128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 32, 128>, GEMM_SMEM_BYTES);
@@ -1037,16 +1039,27 @@ void bobe_gp::prepare_z(const double* Z, int64_t M, int64_t Mp) {
   VZ.ensure((size_t)Np * Mp * sizeof(double));
   WZ.ensure((size_t)Np * Mp * sizeof(double));
   basez.ensure((size_t)Mp * sizeof(double));
-  qpart.ensure((size_t)nb * (Mp > chunk ? Mp : chunk) * sizeof(double));
+  qpart.ensure((size_t)2 * nb * (Mp > chunk ? Mp : chunk) * sizeof(double));   // (up to 2 nb row tiles of 64)
   scale(zin, M, Mp, hyp, ZsT.d(), Mp);
   kernel_matrix_cross(XsT.d(), Np, N, Np, ZsT.d(), Mp, M, Mp, hyp, kXZ.d(), Mp);
-  hipLaunchKernelGGL(k_trimul, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
-                     (const double*)Linv.d(), Np, nb, (const double*)kXZ.d(), Mp, VZ.d(), Mp, qpart.d(), Mp,
-                     (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
-  hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, stream,
-                     (const double*)qpart.d(), Mp, nb, Mp, hyp.kvar + hyp.noise, 0, basez.d(), (double*)nullptr);
-  hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
-                     (const double*)Linv.d(), Np, nb, (const double*)VZ.d(), Mp, WZ.d(), Mp);
+  // few integration points: 64 x 64 tiles (8 x 2 nb of them at M = 512) fill the chip where 4 x nb tiles of 128 x 128 do not
+  if ((Mp / TILE) * nb < 2 * std::max(num_cus, 1)) {
+    const int nt = 2 * nb;
+    hipLaunchKernelGGL(k_trimul_v64, dim3((unsigned)(Mp / 64), (unsigned)nt), dim3(256), GEMM64_SMEM_BYTES, stream,
+                       (const double*)Linv.d(), Np, nt, (const double*)kXZ.d(), Mp, VZ.d(), Mp, qpart.d(), Mp);
+    hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, stream,
+                       (const double*)qpart.d(), Mp, nt, Mp, hyp.kvar + hyp.noise, 0, basez.d(), (double*)nullptr);
+    hipLaunchKernelGGL(k_trimul_t64, dim3((unsigned)(Mp / 64), (unsigned)nt), dim3(256), GEMM64_SMEM_BYTES, stream,
+                       (const double*)Linv.d(), Np, nt, (const double*)VZ.d(), Mp, WZ.d(), Mp);
+  } else {
+    hipLaunchKernelGGL(k_trimul, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
+                       (const double*)Linv.d(), Np, nb, (const double*)kXZ.d(), Mp, VZ.d(), Mp, qpart.d(), Mp,
+                       (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, stream,
+                       (const double*)qpart.d(), Mp, nb, Mp, hyp.kvar + hyp.noise, 0, basez.d(), (double*)nullptr);
+    hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
+                       (const double*)Linv.d(), Np, nb, (const double*)VZ.d(), Mp, WZ.d(), Mp);
+  }
   LAUNCH_CHECK();
   if (host_z) z_seen_m = M;
 }

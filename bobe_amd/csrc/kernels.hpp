@@ -201,6 +201,49 @@ __global__ __launch_bounds__(256, 2) void k_trimul_t(const double* __restrict__ 
   store_tile(acc, W, ldw, (int64_t)ti * TILE, (int64_t)tc * TILE, 1.0, 0.0);
 }
 
+// ---- the same two products on 64 x 64 tiles, for right-hand sides with FEW columns (the M = 512 integration points of a
+// sweep: 4 x nb tiles of 128 x 128 leave half the chip idle for two launches of ~0.57 ms each at N = 4096; 8 x 2nb tiles
+// of 64 x 64 fill it).  V = Linv B with the column sums of squares per 64-row tile (qpart[2 nb][.]), W = Linv^T V.
+__global__ __launch_bounds__(256, 2) void k_trimul_v64(const double* __restrict__ Linv, int64_t ldi, int nt,
+                                                       const double* __restrict__ B, int64_t ldb, double* __restrict__ V,
+                                                       int64_t ldv, double* __restrict__ qpart, int64_t ldq) {
+  extern __shared__ double smem[];
+  const int tc = blockIdx.x;
+  const int ti = nt - 1 - (int)blockIdx.y;                      // long K first
+  v4d acc[2][2];
+  acc_zero(acc);
+  gemm_tile<KC, RC, 64, 64, BK64>(acc, Linv, ldi, (int64_t)ti * 64, B, ldb, (int64_t)tc * 64, 0, (int64_t)(ti + 1) * 64, smem);
+  store_tile<64, 64>(acc, V, ldv, (int64_t)ti * 64, (int64_t)tc * 64, 1.0, 0.0);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double* red = smem;  // [2][64]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) red[(wave >> 1) * 64 + (wave & 1) * 32 + 16 * j + lane] = s;
+  }
+  __syncthreads();
+  if (t < 64) qpart[(int64_t)ti * ldq + (int64_t)tc * 64 + t] = red[t] + red[64 + t];
+}
+
+__global__ __launch_bounds__(256, 2) void k_trimul_t64(const double* __restrict__ Linv, int64_t ldi, int nt,
+                                                       const double* __restrict__ V, int64_t ldv, double* __restrict__ W,
+                                                       int64_t ldw) {
+  extern __shared__ double smem[];
+  const int ti = blockIdx.y;                                    // (row tile 0 has the longest K and starts first)
+  const int tc = blockIdx.x;
+  v4d acc[2][2];
+  acc_zero(acc);
+  gemm_tile<RC, RC, 64, 64, BK64>(acc, Linv, ldi, (int64_t)ti * 64, V, ldv, (int64_t)tc * 64, (int64_t)ti * 64,
+                                  (int64_t)nt * 64, smem);
+  store_tile<64, 64>(acc, W, ldw, (int64_t)ti * 64, (int64_t)tc * 64, 1.0, 0.0);
+}
+
 // ---- WIPV / WIPStd scoring of every candidate (BOBE/gp.py:552-576, acquisition.py:438-465) -------
 // crossT[z*ldx + c] = sum_n WZ[n][z] kXC[n][c] (from k_trimul).  For candidate c and integration point z:
 //   cross = k(x_c, z) - crossT;  var+ = base_z - cross^2 / s_c  -> NaN / < 1e-12 -> 1e-12 -> * ystd2
