@@ -844,3 +844,16 @@ def test_wip_gradient_against_values_and_central_differences(kernel, d, m):
     assert np.allclose(wv0, bw[0][9:11], rtol=1e-11) and np.allclose(dv0, bw[2][9:11], rtol=1e-8, atol=1e-7 * scale_v)
     one = gp.wip_grad(cand[4], Z)                                          # a single candidate (what L-BFGS sends)
     assert np.array_equal(one[2][0], dv[4]) and one[0][0] == wv[4]      # a candidate does not depend on its batch
+
+
+def test_plain_c_host_program_over_the_abi(tmp_path):
+    """examples/c_abi_host.c — factor, value + gradient, posterior and the WIPV / WIPStd sweep from a C99 program that
+    binds include/bobe_gp.h directly; its own checks (central differences, interpolation, argmin vs scores) must pass."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_lib_cpu import _build_c_host
+    exe = _build_c_host(tmp_path)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "all checks passed" in p.stdout

@@ -177,3 +177,26 @@ def test_small_host_helpers():
     # utils/core.py:150-167: 1 sigma in 1-D is half a chi-square unit; grows with the dimension
     assert get_threshold_for_nsigma(1.0, 1) == pytest.approx(0.5, rel=1e-9)
     assert get_threshold_for_nsigma(2.0, 2) > get_threshold_for_nsigma(2.0, 1) > get_threshold_for_nsigma(1.0, 1)
+
+
+def _build_c_host(tmp_path):
+    """examples/c_abi_host.c: a host program in plain C99 over include/bobe_gp.h (no Python, no torch)"""
+    import subprocess
+    exe = str(tmp_path / "c_abi_host")
+    lib_dir = os.path.join(ROOT, "bobe_amd")
+    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_host.c"), "-o", exe, "-L", lib_dir, "-lbobe_gp", f"-Wl,-rpath,{lib_dir}", "-lm"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_host_links_against_the_library(tmp_path, lib):
+    """The drop-in boundary is a C ABI: the header must compile as strict C99 and a C program must link against
+    libbobe_gp.so without any C++ / HIP / Python on its side.  Without a GPU it reports that and exits 77 (no CPU path)."""
+    import subprocess
+    exe = _build_c_host(tmp_path)
+    if lib.bobe_device_count() >= 1:
+        pytest.skip("a GPU is present: tests/test_gpu_parity.py runs the program")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 77 and "no CPU compute path" in p.stderr
