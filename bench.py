@@ -362,8 +362,9 @@ def main():
                      "refactor_ms": vals[2], "sweep_ms": vals[3], "exchange_ms": vals[4], "candidates_total": s_total,
                      "candidates_per_gpu": s_hi - s_lo, "restarts_rank0": restart_share, "steps": args.steps,
                      "check": dict(last),
-                     "note": "max over ranks per phase; with --exchange rccl the sweep's all-gather is inside sweep_ms "
-                             "(bobe_mgpu_wip_sweep) and exchange_ms is bobe_mgpu_best_fit alone"}
+                     "note": "max over ranks per phase; exchange_ms = the two all-gathers INCLUDING the wait for the slowest rank "
+                             "(a rank that finished its fit / sweep early waits there); with --exchange rccl the sweep's "
+                             "all-gather is inside sweep_ms (bobe_mgpu_wip_sweep) and exchange_ms is bobe_mgpu_best_fit alone"}
         del swork
 
     def timed(fn, reps=2):
