@@ -517,7 +517,7 @@ const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill) {
   if (it != chol_plans.end()) return it->second;
   const int ncu = std::max(num_cus, 1);
   const int D = tu.fill_near, CH = tu.fill_chunk;
-  auto npanel = [&](int k) { const int rr = nb - 1 - k; return rr > 0 ? 2 * rr : 1; };
+  auto npanel = [&](int k) { return panel_workgroups(nb - 1 - k); };
   auto one_launch = [&](int k) { return !tu.chol_legacy && B * npanel(k) <= ncu; };
   auto tiles_of = [&](int c) { return 4 * (nb - c) - 1; };   // 64 x 64 tiles of block column c from its diagonal block down
   auto build = [&](int far, CholPlan* out) {
@@ -660,7 +660,8 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
     if (op.kind == 0) {                                       // (64 rows of the panel per workgroup)
       const int kk = op.k;
       const int rr = nb - 1 - kk;
-      const int np_ = rr > 0 ? 2 * rr : 1;
+      const int np_ = panel_workgroups(rr);
+      const int rows_below = rr * TILE;
       const int nv = (int)std::min<int64_t>(TILE, N - (int64_t)kk * TILE);
       if (!tu.chol_legacy && B * np_ <= std::max(num_cus, 1)) {
         first_aside = std::min(first_aside, kk);
@@ -669,16 +670,16 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
         if (op.tab_cnt > 0) {
           hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + op.tab_cnt / 2, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES,
                              stream, a, Np, bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr,
-                             jobs + op.tab_off, op.tab_cnt, 0, (double*)nullptr);
+                             jobs + op.tab_off, op.tab_cnt, 0, (double*)nullptr, rows_below);
         } else if (standin > 0) {
           filler_ws.ensure((size_t)B * (np_ + standin) * PANEL_THREADS * sizeof(double));
           hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + standin, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream,
                              a, Np, bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr,
-                             (const FillJob*)nullptr, 0, tu.filler_iters, filler_ws.d());
+                             (const FillJob*)nullptr, 0, tu.filler_iters, filler_ws.d(), rows_below);
         } else {
           hipLaunchKernelGGL(k_chol_panel<false>, dim3(np_, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv,
                              Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, (const FillJob*)nullptr, 0,
-                             0, (double*)nullptr);
+                             0, (double*)nullptr, rows_below);
         }
         prof_end(BOBE_PROF_POTF2);
       } else {
@@ -1430,7 +1431,7 @@ int bobe_gp_mll_batch(bobe_gp_t* g, int64_t B, const double* ls, const double* k
   g->use();
   const int d = g->d;
   int worst = BOBE_OK;
-  if (B >= 2 && g->N >= tuning().lockstep_min_n && g->prof_tag == 0) {
+  if (B >= 2 && g->N >= tuning().lockstep_min_n) {      // (kernel-class event timing works there too: one stream, no capture)
     // GPU-bound sizes: the evaluations advance in lock step through one batched launch sequence
     for (int64_t b0 = 0; b0 < B; b0 += BOBE_MAX_MLL_SLOTS) {
       const int nbat = (int)std::min<int64_t>(BOBE_MAX_MLL_SLOTS, B - b0);

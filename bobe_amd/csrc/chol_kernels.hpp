@@ -475,12 +475,22 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
 // wave 0's leaf, instead of after the factor: of the 144 MFMAs per wave (12 k cycles after a 52 k factor) only the last
 // sub-block's four stay exposed.
 constexpr int PANEL_THREADS = 512;
+#ifndef BOBE_PANEL_STRIPS
+#define BOBE_PANEL_STRIPS 4
+#endif
+// 16-row strips a panel workgroup solves (one per solver wave): 4 = waves 1, 2, 3, 5 (64 rows), 6 = waves 1, 2, 3, 5, 6, 7
+// (96 rows: a third fewer 150 KB workgroups per panel launch).  Which workgroup solves a strip does not change its bits.
+constexpr int PANEL_STRIPS = BOBE_PANEL_STRIPS;
+constexpr int PANEL_ROWS = 16 * PANEL_STRIPS;
+__host__ __device__ inline int panel_workgroups(int blocks_below) {
+  return blocks_below > 0 ? (blocks_below * TILE + PANEL_ROWS - 1) / PANEL_ROWS : 1;
+}
 template <bool STAMP>
 __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                  int64_t ldl, int k, int pw, int npanel, int* __restrict__ info,
                                                  int nvalid, double* __restrict__ Lkk_out,
-                                                 unsigned long long* __restrict__ stamps) {
-  const bool has_rows = npanel > 1;
+                                                 unsigned long long* __restrict__ stamps, int gridDim_rows_below) {
+  const bool has_rows = gridDim_rows_below > 0;
   extern __shared__ double S[];
   double* Dall = S + TILE * PLD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -496,9 +506,11 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
   // solver wave (1, 2, 3, 5 = strip 0..3): rows (k+1)*128 + 64*pw + 16*strip .. +15 of block column k, straight into
   // transposed-accumulator layout (lane (li, g), register r of tile p = A[row li][16p + g + 4r]); in flight during the
   // first factor steps
-  const int strip = wave < 4 ? wave - 1 : 3;
-  const bool solver = has_rows && ((wave >= 1 && wave <= 3) || wave == 5);
-  const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)pw * 64 + strip * 16;
+  const int strip = wave < 4 ? wave - 1 : wave - 2;                        // waves 1, 2, 3, 5, 6, 7 -> strips 0 .. 5
+  const int64_t rows_below = (int64_t)(gridDim_rows_below);
+  const bool solver = has_rows && wave != 0 && wave != 4 && strip < PANEL_STRIPS &&
+                      (int64_t)pw * PANEL_ROWS + strip * 16 < rows_below;      // (the last workgroup may own fewer strips)
+  const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)pw * PANEL_ROWS + strip * 16;
   double* Aw = A + row0 * lda + col0;
   v4d X[8];
   if (solver) {
@@ -623,7 +635,8 @@ __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict
                                                               double* __restrict__ diag, int64_t bsD,
                                                               unsigned long long* __restrict__ stamps = nullptr,
                                                               const FillJob* __restrict__ jobs = nullptr, int njobs = 0,
-                                                              int fill_iters = 0, double* __restrict__ fill_out = nullptr) {
+                                                              int fill_iters = 0, double* __restrict__ fill_out = nullptr,
+                                                              int rows_below = 0) {
   if (FILL && (int)blockIdx.x >= npanel) {
     if (fill_iters > 0) {
       v4d acc[8];
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict
   }
   const int slot = blockIdx.y;
   chol_panel_body5<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel, info + slot,
-                          nvalid, diag + slot * bsD + (int64_t)k * TILE * TILE, stamps);
+                          nvalid, diag + slot * bsD + (int64_t)k * TILE * TILE, stamps, rows_below);
 }
 
 // A[blk][blk] <- scratch block blk for blk = first + blockIdx.x (slot = blockIdx.y): the L_kk the panel launches left aside
