@@ -64,7 +64,7 @@ int main() {
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipMemcpy(A, K.data(), K.size() * 8, hipMemcpyHostToDevice));
       hipLaunchKernelGGL((k_chol_panel<true>), dim3(14, 1), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, 0, A, (int64_t)N, (int64_t)0, Linv, (int64_t)N,
-                         (int64_t)0, 0, 14, info, 128, dg, (int64_t)0, st);
+                         (int64_t)0, 0, 14, info, 128, dg, (int64_t)0, st, (const FillJob*)nullptr, 0, 0, (double*)nullptr, 7 * 128);
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost));
       unsigned long long ta = 0, tb = 0, tc = 0;
