@@ -141,10 +141,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep, fill, fill_near, fill_chunk, fill_slack, fill_phase; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep, fill, fill_near, fill_chunk, fill_slack, fill_phase, fill_inv, fill_inv_chunk; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0, 1, 2, 3, 16, 1024};
+    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0, 1, 2, 3, 16, 1024, 1, 4};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -163,6 +163,10 @@ const Tuning& tuning() {
     if (const char* e = std::getenv("BOBE_FILL_NEAR")) v.fill_near = std::max(1, std::atoi(e));   // last panels of a column: never deferred
     if (const char* e = std::getenv("BOBE_FILL_CHUNK")) v.fill_chunk = std::max(1, std::atoi(e)); // panels per filler visit of a tile
     if (const char* e = std::getenv("BOBE_FILL_PHASE")) v.fill_phase = std::atoi(e);   // fillers ride in panel launches with B rem^2 <= this
+    // tiles of the triangular inverse (its diagonal blocks and the T / R stages of its recursion) as fillers too: they have
+    // no deadline, so they take whatever CUs the panel launches leave; 0 = off.  Chunk: 64-column units of K per visit
+    if (const char* e = std::getenv("BOBE_FILL_INV")) v.fill_inv = std::atoi(e);
+    if (const char* e = std::getenv("BOBE_FILL_INV_CHUNK")) v.fill_inv_chunk = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("BOBE_FILL_SLACK")) v.fill_slack = std::max(1, std::atoi(e)); // deferred / caught-up work the plan accepts
     return v;
   }();
@@ -222,9 +226,19 @@ struct bobe_gp {
     DBuf d_jobs, d_colk0;
     int far_start = 0;    // first deferred block column (nb: none)
     int64_t deferred_units = 0, catchup_units = 0;
+    // what is left of the inverse after the factorisation when part of it rode in the panel launches: per recursion depth
+    // the problems whose T / R stage still has to run (TriProb lists with their own tile offsets), on the device
+    bool inverse_started = false;
+    struct Rest { int first_t, count_t, nblocks_t, first_r, count_r, nblocks_r, skip_t, skip_r; };
+    std::vector<Rest> rest;               // [depth]
+    std::vector<TriProb> rest_probs;
+    std::vector<unsigned char> rest_skip;  // per list: 1 = the tile ran inside the factorisation
+    DBuf d_rest, d_skip;
+    int64_t inv_units = 0, inv_units_total = 0;
   };
   std::map<uint64_t, CholPlan> chol_plans;
-  const CholPlan& chol_plan(int B, bool fill);
+  const CholPlan& chol_plan(int B, bool fill, bool inv = false);
+  const CholPlan* inverse_rest = nullptr;   // set by potrf() when its plan carried inverse work, consumed by the next trtri()
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
   std::vector<Depth> depths;
@@ -351,7 +365,7 @@ struct bobe_gp {
             int far_col = 0, int ncols = 0);
   // defer_diag: leave the L_kk scratch blocks where they are; the trtri() that follows puts them in place (one launch less)
   void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0, double* dg = nullptr,
-             bool defer_diag = false);
+             bool defer_diag = false, double* tmp = nullptr, int64_t bsT = 0);
   int aside_first = 1 << 30;       // set by potrf(defer_diag = true), consumed by the next trtri()
   const double* aside_dg = nullptr;
   void trtri(double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
@@ -510,24 +524,92 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
 // CUs the panel workgroups do not occupy - whole block columns at a time, `fill_chunk` panels per visit (a filler must
 // not outlast the panel, ~28 us), earliest deadline first.  far_start is the smallest column from which the fillers keep
 // up (what they leave behind is caught up by the update launch that makes the column current, with a longer K range).
-const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill) {
+const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill, bool inv) {
   const Tuning& tu = tuning();
-  const uint64_t key = ((uint64_t)nb << 32) | ((uint64_t)B << 8) | (fill ? 1u : 0u);
+  const uint64_t key = ((uint64_t)nb << 32) | ((uint64_t)B << 8) | (fill ? 1u : 0u) | (inv ? 2u : 0u);
   auto it = chol_plans.find(key);
   if (it != chol_plans.end()) return it->second;
   const int ncu = std::max(num_cus, 1);
-  const int D = tu.fill_near, CH = tu.fill_chunk;
+  const int D = tu.fill_near, CH = tu.fill_chunk, ICH = tu.fill_inv_chunk;
   auto npanel = [&](int k) { return panel_workgroups(nb - 1 - k); };
   auto one_launch = [&](int k) { return !tu.chol_legacy && B * npanel(k) <= ncu; };
   auto tiles_of = [&](int c) { return 4 * (nb - c) - 1; };   // 64 x 64 tiles of block column c from its diagonal block down
-  auto build = [&](int far, CholPlan* out) {
+
+  // ---- the inverse's recursion (build_probs) as a task graph: DIAG(b) per diagonal block, T(P) and R(P) per problem
+  struct Tile { int ti, tj, kbeg, kend, kcur; };
+  struct Stage {
+    int depth, prob, kind;        // kind 1 = T, 2 = R
+    int lo, mid, hi;
+    int dep_a, dep_b;             // stages (indices) that must be complete; -1 - b: DIAG of block b
+    int min_launch;               // panels that must have run: a filler of launch k reads what launches < k wrote
+    std::vector<Tile> tiles;
+    int left, done_launch;        // tiles not finished yet; launch that finished the stage (INT_MAX: not finished)
+  };
+  std::vector<Stage> stages;
+  std::vector<int> node_done_stage;   // per problem (flat index over depths): index of its R stage
+  std::vector<TriProb> flat;          // the problems in build_probs' order (depth-major)
+  std::vector<int> flat_depth;
+  if (inv) {
+    struct Item { int depth, lo, mid, hi; };
+    std::vector<Item> items;
+    struct Rec {
+      static void go(std::vector<Item>& v, int depth, int lo, int hi) {
+        if (hi - lo <= 1) return;
+        const int mid = lo + (hi - lo) / 2;
+        v.push_back({depth, lo, mid, hi});
+        go(v, depth + 1, lo, mid);
+        go(v, depth + 1, mid, hi);
+      }
+    };
+    Rec::go(items, 0, 0, nb);
+    int maxd = -1;
+    for (auto& i : items) maxd = std::max(maxd, i.depth);
+    for (int dd = 0; dd <= maxd; ++dd)
+      for (auto& i : items)
+        if (i.depth == dd) {
+          flat.push_back({i.lo, i.mid, i.hi, 0});
+          flat_depth.push_back(dd);
+        }
+    // the stage that completes the inverse of block range [lo, hi): R of that problem, or DIAG(lo) for a single block
+    auto range_done = [&](int lo, int hi) -> int {
+      if (hi - lo == 1) return -1 - lo;
+      for (size_t q = 0; q < flat.size(); ++q)
+        if (flat[q].lo == lo && flat[q].hi == hi) return 2 * (int)q + 1;
+      return INT_MIN;
+    };
+    for (size_t q = 0; q < flat.size(); ++q) {
+      const TriProb& P = flat[q];
+      const int rows = (P.hi - P.mid) * 2, w = (P.mid - P.lo) * 2;           // in 64 x 64 tiles
+      Stage T{flat_depth[q], (int)q, 1, P.lo, P.mid, P.hi, range_done(P.lo, P.mid), INT_MIN, P.mid, {}, 0, INT_MAX};
+      Stage R{flat_depth[q], (int)q, 2, P.lo, P.mid, P.hi, 2 * (int)q, range_done(P.mid, P.hi), P.hi, {}, 0, INT_MAX};
+      for (int tj = 0; tj < w; ++tj)
+        for (int ti = 0; ti < rows; ++ti) {
+          // T: Tmp[m0][n0] = sum_{k in [n0, mid)} L[m0][k] Linv[k][n0];  R: Linv[m0][n0] = -sum_{k in [mid, m0 + 64)} Linv[m0][k] Tmp[k][n0]
+          T.tiles.push_back({2 * P.mid + ti, 2 * P.lo + tj, 2 * P.lo + tj, 2 * P.mid, 2 * P.lo + tj});
+          R.tiles.push_back({2 * P.mid + ti, 2 * P.lo + tj, 2 * P.mid, 2 * P.mid + ti + 1, 2 * P.mid});
+        }
+      T.left = R.left = (int)T.tiles.size();
+      stages.push_back(T);      // index 2q
+      stages.push_back(R);      // index 2q + 1
+    }
+  }
+
+  typedef std::vector<std::vector<char>> TileFlags;       // [stage][tile]
+  auto build = [&](int far, const TileFlags* keep, CholPlan* out, TileFlags* finished, bool do_inv) {
     std::vector<int> applied(nb, 0);
-    int64_t deferred = 0, catchup = 0;
+    int64_t deferred = 0, catchup = 0, inv_units = 0;
+    std::vector<Stage> st = stages;                     // (fresh progress per simulation)
+    std::vector<int> diag_done(nb, INT_MAX);            // launch that inverted diagonal block b
+    auto dep_done = [&](int dep) -> int {               // launch after which a dependency is complete
+      if (dep == INT_MIN) return -1;
+      if (dep < 0) return diag_done[-1 - dep];
+      return st[dep].done_launch;
+    };
     auto panel = [&](int k) {
       CholOp op{0, k, k, out ? (int)out->jobs.size() : 0, 0, 0, 0, true, k, k};
       const int64_t remk = nb - 1 - k;
-      if (fill && far < nb && one_launch(k) && (int64_t)B * remk * remk <= tu.fill_phase) {
-        int cap = (ncu - tu.filler_keep - B * npanel(k)) / B;           // filler workgroups per slot, two tiles each
+      int cap = one_launch(k) ? (ncu - tu.filler_keep - B * npanel(k)) / B : 0;   // filler workgroups per slot, two jobs each
+      if (fill && far < nb && cap > 0 && (int64_t)B * remk * remk <= tu.fill_phase) {
         for (int c = std::max(far, k + 2); c < nb && cap > 0; ++c) {     // earliest deadline first
           const int pend = std::min(k, c - D);                           // panels < k are final; the last D are never deferred
           if (applied[c] >= pend) continue;
@@ -538,12 +620,83 @@ const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill) {
           deferred += (int64_t)tiles_of(c) * (k1 - applied[c]);
           if (out) {
             for (int tj = 2 * c; tj <= 2 * c + 1; ++tj)
-              for (int ti = tj; ti < 2 * nb; ++ti) out->jobs.push_back({ti, tj, applied[c], k1});
-            const FillJob last = out->jobs.back();                       // an odd count: a twin that is computed, not stored,
-            out->jobs.push_back({-last.ti - 1, last.tj, last.k0, last.k1});  // keeps the two groups of a workgroup in step
+              for (int ti = tj; ti < 2 * nb; ++ti) out->jobs.push_back({0, ti, tj, 2 * applied[c], 2 * k1, 0, 0, 0});
+            FillJob twin = out->jobs.back();                             // an odd count: a twin that is computed, not stored,
+            twin.flags |= FILL_TWIN;                                     // keeps the two groups of a workgroup in step
+            out->jobs.push_back(twin);
             op.tab_cnt += tiles_of(c) + 1;
           }
           applied[c] = k1;
+        }
+      }
+      if (do_inv && cap > 0) {
+        // diagonal blocks first (everything else waits for them), then the ready stages, deepest level first
+        for (int b = 0; b < k && b < nb && cap > 0; ++b) {
+          if (diag_done[b] != INT_MAX) continue;
+          diag_done[b] = k;
+          --cap;
+          inv_units += 8;
+          if (out) {
+            out->jobs.push_back({3, b, b, 0, 0, one_launch(b) ? FILL_ASIDE : 0, 0, 0});
+            out->jobs.push_back({4, 0, 0, 0, 0, 0, 0, 0});
+            op.tab_cnt += 2;
+          }
+        }
+        std::vector<int> order;
+        for (size_t i = 0; i < st.size(); ++i) {
+          Stage& S = st[i];
+          if (S.left == 0 || S.min_launch > k) continue;
+          if (dep_done(S.dep_a) >= k || dep_done(S.dep_b) >= k) continue;     // (INT_MAX: not done at all)
+          order.push_back((int)i);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return st[a].depth > st[b].depth; });
+        const int launches_left = nb - k;               // panel launches from this one on (an upper bound on a tile's visits)
+        for (int i : order) {
+          if (cap <= 0) break;
+          Stage& S = st[i];
+          // This launch's visit of the unfinished tiles: at most ICH 64-column units each.  A tile is worth starting only if
+          // it can still finish inside the factorisation (one visit per launch): least slack first; tiles of equal visit
+          // length share a workgroup.
+          struct Cand { int t, len, slack; };
+          std::vector<Cand> pend;
+          for (size_t t = 0; t < S.tiles.size(); ++t) {
+            const Tile& tl = S.tiles[t];
+            if (tl.kcur >= tl.kend || (keep && !(*keep)[i][t])) continue;
+            const int need = (tl.kend - tl.kcur + ICH - 1) / ICH;
+            if (need > launches_left) continue;
+            pend.push_back({(int)t, std::min(ICH, tl.kend - tl.kcur), launches_left - need});
+          }
+          std::stable_sort(pend.begin(), pend.end(), [](const Cand& a, const Cand& b) {
+            return a.slack != b.slack ? a.slack < b.slack : a.len > b.len;
+          });
+          std::vector<char> used(pend.size(), 0);
+          for (size_t p = 0; p < pend.size() && cap > 0; ++p) {
+            if (used[p]) continue;
+            used[p] = 1;
+            size_t q = p + 1;                             // a partner of the same visit length (the nearest in slack order)
+            while (q < pend.size() && (used[q] || pend[q].len != pend[p].len)) ++q;
+            const int n = q < pend.size() ? 2 : 1;
+            if (n == 2) used[q] = 1;
+            --cap;
+            FillJob last{};
+            for (int u = 0; u < n; ++u) {
+              Tile& tl = S.tiles[pend[u == 0 ? p : q].t];
+              const int len = pend[p].len;
+              const bool first = tl.kcur == tl.kbeg, fin = tl.kcur + len == tl.kend;
+              last = {S.kind, tl.ti, tl.tj, tl.kcur, tl.kcur + len,
+                      (first ? FILL_FIRST : 0) | (fin && S.kind == 2 ? FILL_NEGATE : 0), 0, 0};
+              if (out) out->jobs.push_back(last);
+              tl.kcur += len;
+              inv_units += len;
+              if (fin) --S.left;
+            }
+            if (n == 1 && out) {
+              last.flags |= FILL_TWIN;
+              out->jobs.push_back(last);
+            }
+            if (out) op.tab_cnt += 2;
+          }
+          if (S.left == 0) S.done_launch = k;
         }
       }
       if (out) out->ops.push_back(op);
@@ -589,26 +742,95 @@ const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill) {
         k += 1;
       }
     }
+    if (finished) {
+      finished->assign(st.size(), std::vector<char>());
+      for (size_t i = 0; i < st.size(); ++i) {
+        (*finished)[i].assign(st[i].tiles.size(), 0);
+        for (size_t t = 0; t < st[i].tiles.size(); ++t) (*finished)[i][t] = st[i].tiles[t].kcur >= st[i].tiles[t].kend;
+      }
+    }
     if (out) {
       out->far_start = far;
       out->deferred_units = deferred;
       out->catchup_units = catchup;
+      out->inv_units = inv_units;
     }
     return std::make_pair(deferred, catchup);
   };
   int far = nb;
   if (fill) {
     for (int f = 1; f < nb; ++f) {
-      const auto dc = build(f, nullptr);
+      const auto dc = build(f, nullptr, nullptr, nullptr, false);
       if (dc.first > 0 && dc.second * tu.fill_slack <= dc.first) { far = f; break; }
     }
   }
+  // A TILE is either finished inside the factorisation or left to the inverse's own launches as a whole (they start a tile
+  // from zero): simulate, keep the tiles that finished, simulate again with only those until nothing changes
+  TileFlags keep, fin;
+  if (inv) {
+    build(far, nullptr, nullptr, &fin, true);
+    for (int round = 0; round < 6; ++round) {
+      keep = fin;
+      build(far, &keep, nullptr, &fin, true);
+      bool same = true;
+      for (size_t i = 0; i < fin.size(); ++i)
+        for (size_t t = 0; t < fin[i].size(); ++t) {
+          fin[i][t] = fin[i][t] && keep[i][t];
+          same = same && fin[i][t] == keep[i][t];
+        }
+      if (same) break;
+    }
+    keep = fin;
+  }
   CholPlan& pl = chol_plans[key];
-  build(far, &pl);
+  TileFlags fin2;
+  build(far, inv ? &keep : nullptr, &pl, inv ? &fin2 : nullptr, inv);
+  if (inv) {
+    // What the inverse's own launches still have to do, per depth: the problems with an unfinished tile in their T (R)
+    // stage, and a mask of the tiles that are done ([tile column][tile row] per problem, at the list's tile offsets).
+    // (A kept tile that did not finish after all - it cannot - is simply not masked: it runs again from zero.)
+    int maxd = -1;
+    for (int dd : flat_depth) maxd = std::max(maxd, dd);
+    pl.rest.assign(maxd + 1, CholPlan::Rest{0, 0, 0, 0, 0, 0, 0, 0});
+    for (int dd = 0; dd <= maxd; ++dd) {
+      CholPlan::Rest& r = pl.rest[dd];
+      for (int pass = 1; pass <= 2; ++pass) {
+        (pass == 1 ? r.first_t : r.first_r) = (int)pl.rest_probs.size();
+        (pass == 1 ? r.skip_t : r.skip_r) = (int)pl.rest_skip.size();
+        int off = 0, cnt = 0;
+        for (size_t q = 0; q < flat.size(); ++q) {
+          if (flat_depth[q] != dd) continue;
+          const size_t si = 2 * q + (pass - 1);
+          bool all_done = true;
+          for (char c : fin2[si]) all_done = all_done && c;
+          if (all_done) continue;
+          pl.rest_probs.push_back({flat[q].lo, flat[q].mid, flat[q].hi, off});
+          // stages[si].tiles were pushed tile column by tile column, rows inside: the mask's order
+          for (char c : fin2[si]) pl.rest_skip.push_back((unsigned char)(c ? 1 : 0));
+          off += (flat[q].hi - flat[q].mid) * (flat[q].mid - flat[q].lo);
+          ++cnt;
+        }
+        (pass == 1 ? r.count_t : r.count_r) = cnt;
+        (pass == 1 ? r.nblocks_t : r.nblocks_r) = off;
+      }
+    }
+    for (const Stage& S : stages)
+      for (const Tile& t : S.tiles) pl.inv_units_total += t.kend - t.kbeg;
+    pl.inverse_started = pl.inv_units > 0;
+    if (pl.inverse_started && !pl.rest_probs.empty()) {
+      pl.d_rest.ensure(pl.rest_probs.size() * sizeof(TriProb));
+      HIPCHK(hipMemcpy(pl.d_rest.p, pl.rest_probs.data(), pl.rest_probs.size() * sizeof(TriProb), hipMemcpyHostToDevice));
+      pl.d_skip.ensure(pl.rest_skip.size());
+      HIPCHK(hipMemcpy(pl.d_skip.p, pl.rest_skip.data(), pl.rest_skip.size(), hipMemcpyHostToDevice));
+    }
+  }
   for (const FillJob& j : pl.jobs) {           // (the tables drive device addresses: check them on the host)
-    const int ti = j.ti >= 0 ? j.ti : -j.ti - 1;
-    if (ti < j.tj || ti >= 2 * nb || j.tj < 0 || j.k0 < 0 || j.k1 <= j.k0 || j.k1 * 2 > j.tj)
-      throw Err(BOBE_ERR_STATE, "internal error: filler job outside the trailing matrix");
+    bool ok = true;
+    if (j.kind == 0) ok = j.ti >= j.tj && j.ti < 2 * nb && j.tj >= 0 && j.k0 >= 0 && j.k1 > j.k0 && j.k1 <= j.tj - (j.tj & 1);
+    else if (j.kind == 1 || j.kind == 2) ok = j.ti > j.tj && j.ti < 2 * nb && j.tj >= 0 && j.k0 >= 0 && j.k1 > j.k0 && j.k1 <= 2 * nb;
+    else if (j.kind == 3) ok = j.ti >= 0 && j.ti < nb;
+    else ok = j.kind == 4;
+    if (!ok) throw Err(BOBE_ERR_STATE, "internal error: filler job outside the matrix");
   }
   if (!pl.jobs.empty()) {
     pl.d_jobs.ensure(pl.jobs.size() * sizeof(FillJob));
@@ -621,8 +843,10 @@ const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill) {
     HIPCHK(hipMemcpy(pl.d_colk0.p, pl.colk0.data(), pl.colk0.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   if (std::getenv("BOBE_TRACE"))
-    std::fprintf(stderr, "[bobe] chol plan nb=%d B=%d fill=%d: deferred columns from %d, %lld tile-panels in fillers (%zu jobs), %lld caught up\n",
-                 nb, B, (int)fill, pl.far_start, (long long)pl.deferred_units, pl.jobs.size(), (long long)pl.catchup_units);
+    std::fprintf(stderr, "[bobe] chol plan nb=%d B=%d fill=%d inv=%d: deferred columns from %d, %lld tile-panels in fillers, %lld caught up; "
+                 "inverse: %lld of %lld tile-units inside the factorisation (%zu jobs in all)\n",
+                 nb, B, (int)fill, (int)inv, pl.far_start, (long long)pl.deferred_units, (long long)pl.catchup_units,
+                 (long long)pl.inv_units, (long long)pl.inv_units_total, pl.jobs.size());
   return pl;
 }
 
@@ -640,7 +864,8 @@ const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill) {
 // not needed soon are DEFERRED and ride in those launches as filler workgroups (chol_plan, k_chol_panel<., true>) - not on
 // an evaluation slot's private stream, where the other slots' kernels want those CUs.
 // Every matrix element sees the same operation sequence in all forms (same bits).
-void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg, bool defer_diag) {
+void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg, bool defer_diag,
+                    double* tmp, int64_t bsT) {
   const Tuning& tu = tuning();
   if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches
   const int64_t bsD = (int64_t)nb * TILE * TILE;
@@ -653,7 +878,13 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
   // BOBE_FILL=2 forces them on everywhere, BOBE_FILL=0 off.
   const bool fill = tu.fill != 0 && !in_slot && !tu.chol_legacy && tu.filler_iters == 0 &&
                     (tu.fill == 2 || (B == 1 && nb >= 24 && nb <= 36));
-  const CholPlan& pl = chol_plan(B, fill);
+  // The inverse that follows has work without a deadline - its diagonal blocks and the T / R tiles of its recursion depend
+  // only on block rows that are final - so the same launches carry it as well (when the caller hands over the inverse's
+  // scratch matrix): what finishes inside the factorisation is skipped by trtri().  Same tiles, same K order: same bits.
+  const bool inv = tmp != nullptr && tu.fill_inv != 0 && !in_slot && !tu.chol_legacy && tu.filler_iters == 0 &&
+                   (tu.fill_inv == 2 || nb >= 16);
+  const CholPlan& pl = chol_plan(B, fill, inv);
+  inverse_rest = pl.inverse_started ? &pl : nullptr;
   const FillJob* jobs = static_cast<const FillJob*>(pl.d_jobs.p);
   const int* coltab = static_cast<const int*>(pl.d_colk0.p);
   for (const CholOp& op : pl.ops) {
@@ -670,7 +901,7 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
         if (op.tab_cnt > 0) {
           hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + op.tab_cnt / 2, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES,
                              stream, a, Np, bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr,
-                             jobs + op.tab_off, op.tab_cnt, 0, (double*)nullptr, rows_below);
+                             jobs + op.tab_off, op.tab_cnt, 0, (double*)nullptr, rows_below, tmp, Np, bsT);
         } else if (standin > 0) {
           filler_ws.ensure((size_t)B * (np_ + standin) * PANEL_THREADS * sizeof(double));
           hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + standin, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream,
@@ -733,24 +964,45 @@ void bobe_gp::trtri(double* a, double* linv, double* tmp, int B, int64_t bsA, in
   aside_first = 1 << 30;
   aside_dg = nullptr;
   prof_end(BOBE_PROF_TRTRI);
+  // (part of the recursion may have run inside the factorisation's panel launches: then only the stages it left)
+  const CholPlan* rest = inverse_rest;
+  inverse_rest = nullptr;
   for (int dd = (int)depths.size() - 1; dd >= 0; --dd) {
     const Depth& D = depths[dd];
-    const TriProb* pr = static_cast<const TriProb*>(probs.p) + D.first;
+    const TriProb* pr_t = static_cast<const TriProb*>(probs.p) + D.first;
+    const TriProb* pr_r = pr_t;
+    int cnt_t = D.count, cnt_r = D.count, nbl_t = D.nblocks, nbl_r = D.nblocks;
+    const unsigned char *sk_t = nullptr, *sk_r = nullptr;
+    if (rest) {
+      const CholPlan::Rest& r = rest->rest[dd];
+      pr_t = static_cast<const TriProb*>(rest->d_rest.p) + r.first_t;
+      pr_r = static_cast<const TriProb*>(rest->d_rest.p) + r.first_r;
+      cnt_t = r.count_t; cnt_r = r.count_r; nbl_t = r.nblocks_t; nbl_r = r.nblocks_r;
+      sk_t = static_cast<const unsigned char*>(rest->d_skip.p) + r.skip_t;
+      sk_r = static_cast<const unsigned char*>(rest->d_skip.p) + r.skip_r;
+    }
     prof_begin(BOBE_PROF_TRTRI);
     // (64x64 tiles while a level of ONE matrix has too few 128x128 tiles to fill the chip; a tile's K order is the
     // same either way.  Batches keep the per-matrix choice: four in lock step at N = 4096 take 7.0 ms per evaluation
     // round with 64x64 tiles at every level against 7.4 with 128x128 tiles at the top level)
     if (D.nblocks < tu.trtri64_below) {
-      const TileGrid tg = tile_grid(2 * D.nblocks);         // (tile pairs of complementary K: equal work)
-      hipLaunchKernelGGL(k_trtri_T<64>, dim3(tg.grid, B), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
-                         (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT, tg.per);
-      hipLaunchKernelGGL(k_trtri_R<64>, dim3(tg.grid, B), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
-                         (const double*)tmp, Np, pr, D.count, bsL, bsT, tg.per);
+      if (cnt_t > 0) {
+        const TileGrid tg = tile_grid(2 * nbl_t);             // (tile pairs of complementary K: equal work)
+        hipLaunchKernelGGL(k_trtri_T<64>, dim3(tg.grid, B), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
+                           (const double*)linv, Np, tmp, Np, pr_t, cnt_t, bsA, bsL, bsT, tg.per, sk_t);
+      }
+      if (cnt_r > 0) {
+        const TileGrid tg = tile_grid(2 * nbl_r);
+        hipLaunchKernelGGL(k_trtri_R<64>, dim3(tg.grid, B), dim3(256), GEMM64_SMEM_BYTES, stream, linv, Np,
+                           (const double*)tmp, Np, pr_r, cnt_r, bsL, bsT, tg.per, sk_r);
+      }
     } else {
-      hipLaunchKernelGGL(k_trtri_T<128>, dim3(D.nblocks, B), dim3(256), GEMM_SMEM_BYTES, stream, a, Np,
-                         (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT);
-      hipLaunchKernelGGL(k_trtri_R<128>, dim3(D.nblocks, B), dim3(256), GEMM_SMEM_BYTES, stream, linv, Np,
-                         (const double*)tmp, Np, pr, D.count, bsL, bsT);
+      if (cnt_t > 0)
+        hipLaunchKernelGGL(k_trtri_T<128>, dim3(nbl_t, B), dim3(256), GEMM_SMEM_BYTES, stream, a, Np,
+                           (const double*)linv, Np, tmp, Np, pr_t, cnt_t, bsA, bsL, bsT);
+      if (cnt_r > 0)
+        hipLaunchKernelGGL(k_trtri_R<128>, dim3(nbl_r, B), dim3(256), GEMM_SMEM_BYTES, stream, linv, Np,
+                           (const double*)tmp, Np, pr_r, cnt_r, bsL, bsT);
     }
     prof_end(BOBE_PROF_TRTRI);
   }
@@ -803,7 +1055,7 @@ void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, 
                           const Hyper* hdev) {
   scale(X.d(), N, Np, h, xst, Np, hdev, 1, 0, static_cast<int*>(info.p));
   assemble_kxx(h, xst, a, hdev);
-  potrf(a, linv, static_cast<int*>(info.p), 1, 0, 0, nullptr, true);
+  potrf(a, linv, static_cast<int*>(info.p), 1, 0, 0, nullptr, true, Tmp.d(), 0);
   trtri(a, linv, Tmp.d());
   solve_alpha(linv, wv, al, part.d());
 }
@@ -987,7 +1239,7 @@ void bobe_gp::mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad) {
   scale(X.d(), N, Np, hs[0], bw.XsT.d(), Np, hdev, B, xs);
   assemble_kxx(hs[0], bw.XsT.d(), bw.A.d(), hdev, B, xs, mat);
   HIPCHK(hipMemsetAsync(inf, 0x7f, (size_t)B * sizeof(int), stream));
-  potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat, bw.diag.d(), true);
+  potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat, bw.diag.d(), true, bw.Tmp.d(), mat);
   trtri(bw.A.d(), bw.Linv.d(), bw.Tmp.d(), B, mat, mat, mat);
   solve_alpha(bw.Linv.d(), bw.w.d(), bw.alpha.d(), bw.part.d(), B, mat, vec, prt);
   hipLaunchKernelGGL(k_mll_terms, dim3(B), dim3(256), 0, stream, (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np,
@@ -1302,6 +1554,8 @@ void bobe_gp_destroy(bobe_gp_t* g) {
   for (auto& kv : g->chol_plans) {
     kv.second.d_jobs.release();
     kv.second.d_colk0.release();
+    kv.second.d_rest.release();
+    kv.second.d_skip.release();
   }
   if (g->ev_batch) (void)hipEventDestroy(g->ev_batch);
   if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);

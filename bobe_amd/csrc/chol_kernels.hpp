@@ -299,25 +299,9 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t l
 // out: Linv[blk][blk] = L[blk][blk]^-1 (lower, zeros above).
 // diag / first_aside: the factorisation left the L_kk of blocks >= first_aside in its scratch blocks (k_chol_panel); they
 // are read from there and put in place on the way (what k_copy_diag does when no inverse follows the factorisation).
-__global__ __launch_bounds__(256) void k_trti_diag(double* __restrict__ L, int64_t lda,
-                                                   double* __restrict__ Linv, int64_t ldl, int64_t bsA = 0,
-                                                   int64_t bsL = 0, const double* __restrict__ diag = nullptr,
-                                                   int64_t bsD = 0, int first_aside = 1 << 30) {
-  extern __shared__ double S[];
+// (the block's L is in S[128][PLD]; Ib = the block of Linv holding the eight 16x16 diagonal inverses; called by 256 threads)
+__device__ __forceinline__ void trti_block(double* S, double* __restrict__ Ib, int64_t ldl) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int blk = blockIdx.x;
-  L += blockIdx.y * bsA;
-  Linv += blockIdx.y * bsL;
-  double* Lb = L + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
-  double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
-  if (diag && blk >= first_aside) {
-    block_load(S, diag + blockIdx.y * bsD + (int64_t)blk * TILE * TILE, TILE);
-    __syncthreads();
-    block_store_lower(S, Lb, lda);
-  } else {
-    block_load(S, Lb, lda);
-  }
-  __syncthreads();
   if (t < 128) {   // overwrite the diagonal 16x16 sub-blocks with their inverses
     const int bb = t >> 4, col = t & 15, o = 16 * bb;
 #pragma unroll
@@ -363,6 +347,27 @@ __global__ __launch_bounds__(256) void k_trti_diag(double* __restrict__ L, int64
     __syncthreads();
   }
   block_store_lower(S, Ib, ldl);
+}
+
+__global__ __launch_bounds__(256) void k_trti_diag(double* __restrict__ L, int64_t lda,
+                                                   double* __restrict__ Linv, int64_t ldl, int64_t bsA = 0,
+                                                   int64_t bsL = 0, const double* __restrict__ diag = nullptr,
+                                                   int64_t bsD = 0, int first_aside = 1 << 30) {
+  extern __shared__ double S[];
+  const int blk = blockIdx.x;
+  L += blockIdx.y * bsA;
+  Linv += blockIdx.y * bsL;
+  double* Lb = L + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
+  double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
+  if (diag && blk >= first_aside) {
+    block_load(S, diag + blockIdx.y * bsD + (int64_t)blk * TILE * TILE, TILE);
+    __syncthreads();
+    block_store_lower(S, Lb, lda);
+  } else {
+    block_load(S, Lb, lda);
+  }
+  __syncthreads();
+  trti_block(S, Ib, ldl);
 }
 
 // ---- panel: A[r][k-block] <- A[r][k-block] * L_kk^-T for rows r >= (k+1)*128 ------------------------
@@ -622,12 +627,26 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
 // (Measured with stand-in MFMA workgroups first, profiles/r03_filler_standin.txt: up to ~8 MFLOP per filler workgroup the
 // factorisation takes exactly as long as without them; beyond that the launch lasts as long as its slowest filler.)
 // BOBE_FILLER_ITERS > 0 (timing experiments): the fillers run that many rounds of eight MFMAs instead.
-struct FillJob { int ti, tj, k0, k1; };   // 64 x 64 tile (ti, tj) of the padded matrix; panels (128-blocks) [k0, k1)
+// A filler job.  K ranges are in units of 64 columns.
+//   kind 0  update tile:      A[ti][tj]    -= sum_k A[ti][k] A[tj][k]^T                      (k_syrk_trail's tile)
+//   kind 1  inverse, T stage: Tmp[ti][tj]  (+)= sum_k L[ti][k] Linv[k][tj]                    (k_trtri_T's tile)
+//   kind 2  inverse, R stage: Linv[ti][tj] (+)= sum_k Linv[ti][k] Tmp[k][tj], negated by the last chunk   (k_trtri_R's tile)
+//   kind 3  inverse of the diagonal 128-block ti (k_trti_diag's block; FILL_ASIDE: its L_kk is still in the scratch blocks)
+//   kind 4  nothing (the idle half of a pair)
+// A tile whose K range does not fit one visit is visited in several launches, the partial sum parked in its destination:
+// the accumulator chain is the one of a single pass (same bits).  The two jobs of a workgroup run the same number of
+// K-steps (workgroup-wide barriers): the plan pairs jobs of equal kind and length; FILL_TWIN completes an odd one (computed,
+// not stored).
+enum { FILL_TWIN = 1, FILL_FIRST = 2, FILL_NEGATE = 4, FILL_ASIDE = 8 };
+struct FillJob { int kind, ti, tj, k0, k1, flags, pad0, pad1; };
 #ifndef BOBE_FILL_BK
 #define BOBE_FILL_BK 32
 #endif
 constexpr int FILL_BK = BOBE_FILL_BK;
 constexpr int FILL_SMEM_DOUBLES = gemm_smem_doubles_exact<KC, KC, 64, 64, FILL_BK>();   // per group; two groups fit the panel's 150 KB
+constexpr int FILL_INV_BK = 16;                                                          // (KC x RC images at BK = 32 would not)
+static_assert(2 * FILL_SMEM_DOUBLES * 8 <= POTF2_SMEM_BYTES, "update fillers exceed the panel's LDS");
+static_assert(2 * gemm_smem_doubles_exact<KC, RC, 64, 64, FILL_INV_BK>() <= 2 * FILL_SMEM_DOUBLES, "inverse fillers use the same slices");
 template <bool STAMP = false, bool FILL = false>
 __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
                                                               double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
@@ -636,7 +655,8 @@ __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict
                                                               unsigned long long* __restrict__ stamps = nullptr,
                                                               const FillJob* __restrict__ jobs = nullptr, int njobs = 0,
                                                               int fill_iters = 0, double* __restrict__ fill_out = nullptr,
-                                                              int rows_below = 0) {
+                                                              int rows_below = 0, double* __restrict__ Tmp = nullptr,
+                                                              int64_t ldt = 0, int64_t bsT = 0) {
   if (FILL && (int)blockIdx.x >= npanel) {
     if (fill_iters > 0) {
       v4d acc[8];
@@ -658,16 +678,37 @@ __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict
     const int idx = 2 * ((int)blockIdx.x - npanel) + grp;
     if (idx >= njobs) return;                 // (never: the job lists have even length, a workgroup = one pair)
     const FillJob jb = jobs[idx];
-    // a block column has an odd number of tiles: its last pair is completed by a twin (ti stored as -ti-1) that is computed
-    // but not written back, so that both groups of the workgroup pass the same number of workgroup-wide barriers
-    const bool live = jb.ti >= 0;
-    const int64_t r0 = (int64_t)(live ? jb.ti : -jb.ti - 1) * 64, c0 = (int64_t)jb.tj * 64;
+    if (jb.kind == 4) return;                 // (a wave that has ended is not waited for by the other group's barriers)
     double* As = A + blockIdx.y * bsA;
+    double* Ls = Linv + blockIdx.y * bsL;
+    if (jb.kind == 3) {                       // the first group's 256 threads; its partner is a kind-4 job
+      double* Ib = Ls + ((int64_t)jb.ti * TILE) * ldl + (int64_t)jb.ti * TILE;
+      if (jb.flags & FILL_ASIDE) block_load(S, diag + blockIdx.y * bsD + (int64_t)jb.ti * TILE * TILE, TILE);
+      else block_load(S, As + ((int64_t)jb.ti * TILE) * lda + (int64_t)jb.ti * TILE, lda);
+      __syncthreads();
+      trti_block(S, Ib, ldl);
+      return;
+    }
+    const bool live = !(jb.flags & FILL_TWIN);
+    const int64_t r0 = (int64_t)jb.ti * 64, c0 = (int64_t)jb.tj * 64;
+    const int64_t kb = (int64_t)jb.k0 * 64, ke = (int64_t)jb.k1 * 64;
     v4d acc[2][2];
-    load_tile<64, 64>(acc, As, lda, r0, c0, tid);
-    gemm_tile<KC, KC, 64, 64, FILL_BK, true>(acc, As, lda, r0, As, lda, c0, (int64_t)jb.k0 * TILE, (int64_t)jb.k1 * TILE,
-                                        S + grp * FILL_SMEM_DOUBLES, tid);
-    if (live) store_tile<64, 64>(acc, As, lda, r0, c0, 1.0, 0.0, tid);
+    if (jb.kind == 0) {
+      load_tile<64, 64>(acc, As, lda, r0, c0, tid);
+      gemm_tile<KC, KC, 64, 64, FILL_BK, true>(acc, As, lda, r0, As, lda, c0, kb, ke, S + grp * FILL_SMEM_DOUBLES, tid);
+      if (live) store_tile<64, 64>(acc, As, lda, r0, c0, 1.0, 0.0, tid);
+      return;
+    }
+    double* Ts = Tmp + blockIdx.y * bsT;
+    double* dst = jb.kind == 1 ? Ts : Ls;
+    const int64_t ldd = jb.kind == 1 ? ldt : ldl;
+    if (jb.flags & FILL_FIRST) acc_zero(acc);
+    else load_tile<64, 64>(acc, dst, ldd, r0, c0, tid);
+    if (jb.kind == 1)
+      gemm_tile<KC, RC, 64, 64, FILL_INV_BK>(acc, As, lda, r0, Ls, ldl, c0, kb, ke, S + grp * FILL_SMEM_DOUBLES, tid);
+    else
+      gemm_tile<KC, RC, 64, 64, FILL_INV_BK>(acc, Ls, ldl, r0, Ts, ldt, c0, kb, ke, S + grp * FILL_SMEM_DOUBLES, tid);
+    if (live) store_tile<64, 64>(acc, dst, ldd, r0, c0, (jb.flags & FILL_NEGATE) ? -1.0 : 1.0, 0.0, tid);
     return;
   }
   const int slot = blockIdx.y;
@@ -771,7 +812,8 @@ __global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L
                                                     const double* __restrict__ Linv, int64_t ldi,
                                                     double* __restrict__ Tmp, int64_t ldt,
                                                     const TriProb* __restrict__ probs, int nprob, int64_t bsA = 0,
-                                                    int64_t bsL = 0, int64_t bsT = 0, int per = 0) {
+                                                    int64_t bsL = 0, int64_t bsT = 0, int per = 0,
+                                                    const unsigned char* __restrict__ skip = nullptr) {
   extern __shared__ double smem[];
   L += blockIdx.y * bsA;
   Linv += blockIdx.y * bsL;
@@ -788,6 +830,8 @@ __global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L
     } else {
       tj = e[u] / rows, ti = e[u] % rows;                  // column-major: small tj (long K) first
     }
+    // (a tile that already ran as a filler of the factorisation's panel launches: skip[problem's tile offset + tj * rows + ti])
+    if (skip && skip[(int64_t)p.off * (TILE / T) * (TILE / T) + tj * rows + ti]) continue;
     const int64_t m0 = (int64_t)p.mid * TILE + (int64_t)ti * T, n0 = (int64_t)p.lo * TILE + (int64_t)tj * T;
     v4d acc[T / 32][T / 32];
     acc_zero(acc);
@@ -800,7 +844,8 @@ template <int T>
 __global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, int64_t ldi,
                                                     const double* __restrict__ Tmp, int64_t ldt,
                                                     const TriProb* __restrict__ probs, int nprob, int64_t bsL = 0,
-                                                    int64_t bsT = 0, int per = 0) {
+                                                    int64_t bsT = 0, int per = 0,
+                                                    const unsigned char* __restrict__ skip = nullptr) {
   extern __shared__ double smem[];
   Linv += blockIdx.y * bsL;
   Tmp += blockIdx.y * bsT;
@@ -817,6 +862,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, i
     } else {
       ti = rows - 1 - e[u] / w, tj = e[u] % w;             // bottom rows (long K) first
     }
+    if (skip && skip[(int64_t)p.off * (TILE / T) * (TILE / T) + tj * rows + ti]) continue;
     const int64_t m0 = (int64_t)p.mid * TILE + (int64_t)ti * T, n0 = (int64_t)p.lo * TILE + (int64_t)tj * T;
     v4d acc[T / 32][T / 32];
     acc_zero(acc);

@@ -98,8 +98,11 @@ class GP:
         self.optimizer_method = optimizer
         self.mll_optimize = optimize_scipy if optimizer == "scipy" else optimize_optax          # gp.py:264-267
         self.optimizer_options = optimizer_options
-        self.concurrent_restarts = True        # fit(): the restarts run concurrently, one evaluation slot each
-        self.restart_slots = 4                 # evaluations in flight at once (more than 4 oversubscribes the queues)
+        self.concurrent_restarts = True        # fit(): the restarts run concurrently ...
+        self.restart_slots = 4                 # ... this many evaluations in flight at once (more oversubscribes the queues)
+        # ... each in its own thread on an evaluation slot ("slots"), or advancing in lock step through one batched
+        # launch sequence per round ("lockstep": bobe_gp_mll_batch); same trajectories and result either way
+        self.restart_mode = "slots"
 
         self.lengthscale_bounds = lengthscale_bounds
         self.kernel_variance_bounds = kernel_variance_bounds
@@ -302,9 +305,13 @@ class GP:
         x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
         optimizer_options = dict(self.optimizer_options)
         # restarts are independent L-BFGS-B runs: each gets a host thread and an evaluation slot of the library
-        extra = {"slot_value_and_grad": lambda x, slot: self.neg_mll_value_and_grad(x, slot=slot),
-                 "n_slots": self.restart_slots} \
-            if (self.concurrent_restarts and x0.shape[0] > 1 and self.mll_optimize is optimize_scipy) else {}
+        extra = {}
+        if self.concurrent_restarts and x0.shape[0] > 1 and self.mll_optimize is optimize_scipy:
+            if self.restart_mode == "lockstep":
+                extra = {"batch_value_and_grad": self.neg_mll_value_and_grad_batch}
+            else:
+                extra = {"slot_value_and_grad": lambda x, slot: self.neg_mll_value_and_grad(x, slot=slot),
+                         "n_slots": self.restart_slots}
         best_params_log, best_loss = self.mll_optimize(
             self.neg_mll_value_and_grad, num_params=self.num_hyperparams, bounds=self.hyperparam_bounds, x0=x0,
             maxiter=maxiter, n_restarts=x0.shape[0], optimizer_options=optimizer_options, **extra)

@@ -31,11 +31,12 @@ def test_every_launch_sequence_gives_the_same_bits():
 
 
 def test_deferred_updates_in_the_panel_shadows_do_not_move_a_bit():
-    """potrf() lets trailing-update tiles of far block columns ride in the panel launches as filler workgroups
-    (k_chol_panel<., true>, chol_plan in bobe_gp.hip).  Where a tile is computed must not change what it holds: the
-    factor, MLL, gradient, batch results and predictions with the fillers forced on everywhere (BOBE_FILL=2: lone and
-    lock-step, ragged and full sizes, both kernels) equal, bit for bit, those with every update in its own launch
-    (BOBE_FILL=0).  The switches are read once per process, hence the child interpreters."""
+    """potrf() lets trailing-update tiles of far block columns, and tiles of the inverse that follows (its diagonal blocks,
+    the T / R stages of its recursion), ride in the panel launches as filler workgroups (k_chol_panel<., true>, chol_plan
+    in bobe_gp.hip).  Where a tile is computed must not change what it holds: the factor, MLL, gradient, batch results and
+    predictions with both kinds of filler forced on everywhere (BOBE_FILL=2, BOBE_FILL_INV=2: lone and lock-step, ragged and
+    full sizes, both kernels) equal, bit for bit, those with every update and every inverse tile in its own launch (=0).
+    The switches are read once per process, hence the child interpreters."""
     import json
     import os
     import subprocess
@@ -44,7 +45,7 @@ def test_deferred_updates_in_the_panel_shadows_do_not_move_a_bit():
     sizes = "300:3:rbf,1500:8:matern,2500:5:rbf,3200:6:matern,4096:8:rbf,5000:4:rbf"
     digests = {}
     for mode in ("0", "2", "1"):
-        env = dict(os.environ, BOBE_FILL=mode, BITS_SIZES=sizes, BOBE_LOCKSTEP_MIN_N="1024")
+        env = dict(os.environ, BOBE_FILL=mode, BOBE_FILL_INV=mode, BITS_SIZES=sizes, BOBE_LOCKSTEP_MIN_N="1024")
         p = subprocess.run([sys.executable, os.path.join(root, "tools", "bits_snapshot.py"), "print"], env=env,
                            capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
