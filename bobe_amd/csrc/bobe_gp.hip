@@ -238,7 +238,6 @@ struct bobe_gp {
   };
   std::map<uint64_t, CholPlan> chol_plans;
   const CholPlan& chol_plan(int B, bool fill, bool inv = false);
-  const CholPlan* inverse_rest = nullptr;   // set by potrf() when its plan carried inverse work, consumed by the next trtri()
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
   std::vector<Depth> depths;
@@ -364,11 +363,14 @@ struct bobe_gp {
   void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0, const int* colk0 = nullptr,
             int far_col = 0, int ncols = 0);
   // defer_diag: leave the L_kk scratch blocks where they are; the trtri() that follows puts them in place (one launch less)
-  void potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0, double* dg = nullptr,
-             bool defer_diag = false, double* tmp = nullptr, int64_t bsT = 0);
+  // tmp: the inverse's scratch matrix - part of the inverse may then ride in the panel launches; the plan that says what is
+  // left of it is returned (nullptr: all of it) and goes to the trtri() that follows
+  const CholPlan* potrf(double* a, double* linv, int* info_dev, int B = 1, int64_t bsA = 0, int64_t bsL = 0,
+                        double* dg = nullptr, bool defer_diag = false, double* tmp = nullptr, int64_t bsT = 0);
   int aside_first = 1 << 30;       // set by potrf(defer_diag = true), consumed by the next trtri()
   const double* aside_dg = nullptr;
-  void trtri(double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
+  void trtri(double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0,
+             const CholPlan* rest = nullptr);
   int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
             const Hyper* hdev = nullptr, double* gp_out = nullptr, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
             int64_t bsX = 0, int64_t bsP = 0);
@@ -864,8 +866,8 @@ const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill, bool inv) {
 // not needed soon are DEFERRED and ride in those launches as filler workgroups (chol_plan, k_chol_panel<., true>) - not on
 // an evaluation slot's private stream, where the other slots' kernels want those CUs.
 // Every matrix element sees the same operation sequence in all forms (same bits).
-void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg, bool defer_diag,
-                    double* tmp, int64_t bsT) {
+const bobe_gp::CholPlan* bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg,
+                                        bool defer_diag, double* tmp, int64_t bsT) {
   const Tuning& tu = tuning();
   if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches
   const int64_t bsD = (int64_t)nb * TILE * TILE;
@@ -881,10 +883,10 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
   // The inverse that follows has work without a deadline - its diagonal blocks and the T / R tiles of its recursion depend
   // only on block rows that are final - so the same launches carry it as well (when the caller hands over the inverse's
   // scratch matrix): what finishes inside the factorisation is skipped by trtri().  Same tiles, same K order: same bits.
-  const bool inv = tmp != nullptr && tu.fill_inv != 0 && !in_slot && !tu.chol_legacy && tu.filler_iters == 0 &&
-                   (tu.fill_inv == 2 || nb >= 16);
+  static const bool fill_in_slots = std::getenv("BOBE_FILL_SLOTS") != nullptr;      // (experiment: not on a slot by default)
+  const bool inv = tmp != nullptr && tu.fill_inv != 0 && (!in_slot || (fill_in_slots && N > tu.graph_max_n)) && !tu.chol_legacy &&
+                   tu.filler_iters == 0 && (tu.fill_inv == 2 || (nb >= 16 && nb <= 48));   // (larger: update-bound, nothing to hide in)
   const CholPlan& pl = chol_plan(B, fill, inv);
-  inverse_rest = pl.inverse_started ? &pl : nullptr;
   const FillJob* jobs = static_cast<const FillJob*>(pl.d_jobs.p);
   const int* coltab = static_cast<const int*>(pl.d_colk0.p);
   for (const CholOp& op : pl.ops) {
@@ -953,10 +955,11 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
     }
   }
   LAUNCH_CHECK();
+  return pl.inverse_started ? &pl : nullptr;
 }
 
 // Linv = L^-1: diagonal 128-blocks in one batched launch, then recursive doubling (two GEMM launches per level)
-void bobe_gp::trtri(double* a, double* linv, double* tmp, int B, int64_t bsA, int64_t bsL, int64_t bsT) {
+void bobe_gp::trtri(double* a, double* linv, double* tmp, int B, int64_t bsA, int64_t bsL, int64_t bsT, const CholPlan* rest) {
   const Tuning& tu = tuning();
   prof_begin(BOBE_PROF_TRTRI);
   hipLaunchKernelGGL(k_trti_diag, dim3(nb, B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, bsA, bsL, aside_dg,
@@ -965,8 +968,6 @@ void bobe_gp::trtri(double* a, double* linv, double* tmp, int B, int64_t bsA, in
   aside_dg = nullptr;
   prof_end(BOBE_PROF_TRTRI);
   // (part of the recursion may have run inside the factorisation's panel launches: then only the stages it left)
-  const CholPlan* rest = inverse_rest;
-  inverse_rest = nullptr;
   for (int dd = (int)depths.size() - 1; dd >= 0; --dd) {
     const Depth& D = depths[dd];
     const TriProb* pr_t = static_cast<const TriProb*>(probs.p) + D.first;
@@ -1055,8 +1056,8 @@ void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, 
                           const Hyper* hdev) {
   scale(X.d(), N, Np, h, xst, Np, hdev, 1, 0, static_cast<int*>(info.p));
   assemble_kxx(h, xst, a, hdev);
-  potrf(a, linv, static_cast<int*>(info.p), 1, 0, 0, nullptr, true, Tmp.d(), 0);
-  trtri(a, linv, Tmp.d());
+  const CholPlan* rest = potrf(a, linv, static_cast<int*>(info.p), 1, 0, 0, nullptr, true, Tmp.d(), 0);
+  trtri(a, linv, Tmp.d(), 1, 0, 0, 0, rest);
   solve_alpha(linv, wv, al, part.d());
 }
 
@@ -1239,8 +1240,8 @@ void bobe_gp::mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad) {
   scale(X.d(), N, Np, hs[0], bw.XsT.d(), Np, hdev, B, xs);
   assemble_kxx(hs[0], bw.XsT.d(), bw.A.d(), hdev, B, xs, mat);
   HIPCHK(hipMemsetAsync(inf, 0x7f, (size_t)B * sizeof(int), stream));
-  potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat, bw.diag.d(), true, bw.Tmp.d(), mat);
-  trtri(bw.A.d(), bw.Linv.d(), bw.Tmp.d(), B, mat, mat, mat);
+  const CholPlan* rest = potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat, bw.diag.d(), true, bw.Tmp.d(), mat);
+  trtri(bw.A.d(), bw.Linv.d(), bw.Tmp.d(), B, mat, mat, mat, rest);
   solve_alpha(bw.Linv.d(), bw.w.d(), bw.alpha.d(), bw.part.d(), B, mat, vec, prt);
   hipLaunchKernelGGL(k_mll_terms, dim3(B), dim3(256), 0, stream, (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np,
                      bw.res.d(), vec, mat, (int64_t)128);
