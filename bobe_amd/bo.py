@@ -276,6 +276,10 @@ class BOBE:
 
         def check_logz(lz) -> bool:                              # bo.py:871-934 (the KL bookkeeping is results-manager work)
             nonlocal counter
+            if lz.get("truncated"):                              # the sampler was cut by its call budget: its evidence is a
+                log.warning("nested sampling hit its call budget; not testing convergence on a truncated run")
+                counter = 0                                      # lower bound, not an estimate (the reference's dynesty run
+                return False                                     # would stop the same way, silently)
             delta = (lz["upper"] - lz["lower"]) / 2.0
             if delta < logz_threshold:
                 counter += 1
