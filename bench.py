@@ -4,9 +4,9 @@
 One *cycle* (SURVEY.md 8d / BASELINE.md section 2) =
     20 x [K(X,X) assembly + Cholesky + alpha + log-marginal-likelihood + analytic gradient]
        at the fixed theta schedule: the fit's 4 restarts (GP.fit / optim.py:335-354, independent L-BFGS-B runs)
-       x 5 evaluations each.  --fit-mode slots: every restart in its own host thread on its own evaluation slot
-       (bobe_gp_mll_submit / bobe_gp_mll_wait, what GP.fit does); --fit-mode batch: lock-step rounds through
-       bobe_gp_mll_batch (one batched launch sequence per round); --fit-concurrency 1: one after the other.
+       x 5 evaluations each.  --fit-mode batch (default): lock-step rounds through bobe_gp_mll_batch (one batched launch
+       sequence per round: what GP.fit does); --fit-mode slots: every restart in its own host thread on its own
+       evaluation slot (bobe_gp_mll_submit / bobe_gp_mll_wait); --fit-concurrency 1: one after the other.
   + 1 x refactor at the last theta    (bobe_gp_factor)
   + 1 x sweep: posterior mean & variance of all C candidates, WIPV and WIPStd scores against the
         M = 512 integration points, argmin of both  (bobe_gp_wip_sweep)
@@ -65,8 +65,9 @@ def parse(argv=None):
     ap.add_argument("--no-shard-record", action="store_true", help="N > 1, weak mode: skip the strong config-4 sub-record")
     ap.add_argument("--profile-class", default="trimul", help="kernel class timed with HIP events for the roofline")
     ap.add_argument("--fit-concurrency", type=int, default=4, help="restarts of the fit in flight together (1 = sequential)")
-    ap.add_argument("--fit-mode", default="slots", choices=["slots", "batch"],
-                    help="slots: one thread + evaluation slot per restart, no barrier; batch: lock-step rounds")
+    ap.add_argument("--fit-mode", default="batch", choices=["slots", "batch"],
+                    help="batch: lock-step rounds through bobe_gp_mll_batch (what GP.fit does); slots: one thread + "
+                         "evaluation slot per restart, no barrier")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk of the sweep (0 = library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a single GPU")
@@ -398,16 +399,20 @@ def main():
             # GP.fit as the BO loop calls it for N >= 750 (bo.py:651-653): 4 restarts (pool.py:277-286 recipe), maxiter 200
             from bobe_amd.bo import gp_fit
             calls = [0]
-            orig = gp.mll_data
+            orig, orig_b = gp.mll_data, gp.mll_data_batch
 
             def counted(*a, **k):
                 calls[0] += 1
                 return orig(*a, **k)
-            gp.mll_data = counted
+
+            def counted_b(ls_, kv_, *a, **k):                  # (GP.fit advances its restarts in lock step: batched calls)
+                calls[0] += len(kv_)
+                return orig_b(ls_, kv_, *a, **k)
+            gp.mll_data, gp.mll_data_batch = counted, counted_b
             t4 = time.perf_counter()
             r_fit = gp_fit(gp, maxiters=200, n_restarts=4, rng=np.random.default_rng(7), distributed=False)
             t5 = time.perf_counter()
-            gp.mll_data = orig
+            gp.mll_data, gp.mll_data_batch = orig, orig_b
             refactor()                                   # back to the cycle's state
             lbfgs = {"restarts": 4, "maxiter": 200, "seconds": t5 - t4, "evaluations": calls[0],
                      "ms_per_evaluation": (t5 - t4) * 1e3 / max(calls[0], 1), "mll": float(r_fit["mll"])}

@@ -100,9 +100,11 @@ class GP:
         self.optimizer_options = optimizer_options
         self.concurrent_restarts = True        # fit(): the restarts run concurrently ...
         self.restart_slots = 4                 # ... this many evaluations in flight at once (more oversubscribes the queues)
-        # ... each in its own thread on an evaluation slot ("slots"), or advancing in lock step through one batched
-        # launch sequence per round ("lockstep": bobe_gp_mll_batch); same trajectories and result either way
-        self.restart_mode = "slots"
+        # ... advancing in lock step, one bobe_gp_mll_batch call per round, the L-BFGS-B routines stepped by one thread
+        # ("lockstep"), or each in its own thread on an evaluation slot ("slots").  Same trajectories and result either
+        # way; "auto" = lock step where SciPy's routine can be stepped (optim._rc_available), else slots: measured
+        # 33.7 vs 53.5 ms at N = 100, 39.5 vs 45.7 at 600, 124 vs 141 at 2048, 457 vs 461 at 4096 for a 4-restart fit
+        self.restart_mode = "auto"
 
         self.lengthscale_bounds = lengthscale_bounds
         self.kernel_variance_bounds = kernel_variance_bounds
@@ -307,7 +309,8 @@ class GP:
         # restarts are independent L-BFGS-B runs: each gets a host thread and an evaluation slot of the library
         extra = {}
         if self.concurrent_restarts and x0.shape[0] > 1 and self.mll_optimize is optimize_scipy:
-            if self.restart_mode == "lockstep":
+            from .optim import _rc_available
+            if self.restart_mode == "lockstep" or (self.restart_mode == "auto" and _rc_available()):
                 extra = {"batch_value_and_grad": self.neg_mll_value_and_grad_batch}
             else:
                 extra = {"slot_value_and_grad": lambda x, slot: self.neg_mll_value_and_grad(x, slot=slot),

@@ -75,7 +75,14 @@ class _LockStep:
 
 
 def _minimize_concurrently(batch_fun: Callable, starts: np.ndarray, has_grad: bool, **kw) -> List:
-    """``scipy.optimize.minimize`` from every row of ``starts``; returns the results (or the exception) per row."""
+    """``scipy.optimize.minimize`` from every row of ``starts``; returns the results (or the exception) per row.
+    L-BFGS-B with gradients is stepped by one thread (``_rc_minimize_all``) where that is available."""
+    known = {"maxcor", "ftol", "gtol", "maxfun", "maxiter", "maxls"}
+    if has_grad and kw.get("method", "L-BFGS-B") == "L-BFGS-B" and set(kw.get("options") or {}) <= known and _rc_available():
+        try:
+            return _rc_minimize_all(batch_fun, starts, kw.get("bounds"), dict(kw.get("options") or {}))
+        except Exception as e:  # pragma: no cover
+            log.warning(f"stepped L-BFGS-B driver failed with {e}; running the restarts in threads")
     ls = _LockStep(batch_fun, len(starts))
     out: List = [None] * len(starts)
 
@@ -94,6 +101,150 @@ def _minimize_concurrently(batch_fun: Callable, starts: np.ndarray, has_grad: bo
     for t in threads:
         t.join()
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# The same lock step without threads: SciPy's L-BFGS-B is a reverse-communication routine (``setulb`` hands control back
+# whenever it wants f and g), so R minimisations can be advanced by ONE thread — every routine is stepped until it asks
+# for a value, the pending points go to ``batch_fun`` in one call, the values are handed back.  No condition variables, no
+# GIL hand-offs between R threads: at the sizes of the BO loop (N = 100 ... 1200), where an evaluation is a ~100 us
+# graph replay, those cost more than the evaluation itself.  This is the loop of scipy.optimize._lbfgsb_py
+# ._minimize_lbfgsb (SciPy 1.15), statement for statement, per restart; it uses a private SciPy module, so it is verified
+# against ``minimize`` on a quadratic at first use and the thread driver above stays as the fallback.
+# --------------------------------------------------------------------------------------------------------------
+_RC_STATE = {"checked": False, "ok": False}
+
+
+class _RcRun:
+    """One L-BFGS-B minimisation stepped from outside (the body of ``_minimize_lbfgsb`` up to its ``func_and_grad`` call)."""
+
+    def __init__(self, lbfgsb, x0, bounds, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
+                 maxls=20, **unknown):
+        self.lb = lbfgsb
+        self.m, self.maxiter, self.maxfun, self.maxls = int(maxcor), int(maxiter), int(maxfun), int(maxls)
+        self.pgtol = gtol
+        self.factr = ftol / np.finfo(float).eps
+        x0 = np.asarray(x0, dtype=np.float64).ravel()
+        n = x0.shape[0]
+        self.nbd = np.zeros(n, np.int32)
+        self.low = np.zeros(n, np.float64)
+        self.up = np.zeros(n, np.float64)
+        if bounds is not None:
+            lo = np.array([(-np.inf if b[0] is None else b[0]) for b in bounds], dtype=np.float64)
+            hi = np.array([(np.inf if b[1] is None else b[1]) for b in bounds], dtype=np.float64)
+            if (lo > hi).any():
+                raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound.")
+            x0 = np.clip(x0, lo, hi)
+            bounds_map = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}
+            for i in range(n):
+                fl, fu = bool(np.isfinite(lo[i])), bool(np.isfinite(hi[i]))
+                if fl:
+                    self.low[i] = lo[i]
+                if fu:
+                    self.up[i] = hi[i]
+                self.nbd[i] = bounds_map[fl, fu]
+        m = self.m
+        self.x = np.array(x0, dtype=np.float64)
+        self.f = np.array(0.0, dtype=np.int32)
+        self.g = np.zeros((n,), dtype=np.int32)
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task = np.zeros(2, dtype=np.int32)
+        self.ln_task = np.zeros(2, dtype=np.int32)
+        self.lsave = np.zeros(4, dtype=np.int32)
+        self.isave = np.zeros(44, dtype=np.int32)
+        self.dsave = np.zeros(29, dtype=np.float64)
+        self.nit, self.nfev = 0, 0
+        self.finished = False
+        self.last_x, self.last_f, self.last_g = None, None, None     # ScalarFunction's one-point cache
+
+    def advance(self):
+        """Step until the routine wants f and g at a NEW point ``self.x`` (returns True) or has finished (False).  A
+        request at the point evaluated last (the routine restarts an iteration there after a failed line search) is
+        answered from the cache, as ScalarFunction.fun_and_grad does: no evaluation, not counted."""
+        while True:
+            self.g = self.g.astype(np.float64)
+            self.lb.setulb(self.m, self.x, self.low, self.up, self.nbd, self.f, self.g, self.factr, self.pgtol, self.wa,
+                           self.iwa, self.task, self.lsave, self.isave, self.dsave, self.maxls, self.ln_task)
+            if self.task[0] == 3:
+                if self.last_x is not None and np.array_equal(self.x, self.last_x):
+                    self.f, self.g = self.last_f, self.last_g
+                    continue
+                return True
+            if self.task[0] == 1:                       # new iteration
+                self.nit += 1
+                if self.nit >= self.maxiter:
+                    self.task[0], self.task[1] = 5, 504
+                elif self.nfev > self.maxfun:
+                    self.task[0], self.task[1] = 5, 502
+            else:
+                self.finished = True
+                return False
+
+    def give(self, f, g):
+        self.nfev += 1
+        self.f = f
+        self.g = np.asarray(g, dtype=np.float64)
+        self.last_x, self.last_f, self.last_g = np.array(self.x), self.f, self.g
+
+    def result(self):
+        from scipy.optimize import OptimizeResult
+        from scipy.optimize._lbfgsb_py import status_messages, task_messages
+        if self.task[0] == 4:
+            warnflag = 0
+        elif self.nfev > self.maxfun or self.nit >= self.maxiter:
+            warnflag = 1
+        else:
+            warnflag = 2
+        msg = status_messages[self.task[0]] + ": " + task_messages[self.task[1]]
+        return OptimizeResult(fun=self.f, jac=self.g, nfev=self.nfev, njev=self.nfev, nit=self.nit, status=warnflag,
+                              message=msg, x=self.x, success=(warnflag == 0))
+
+
+def _rc_minimize_all(batch_fun: Callable, starts, bounds, options) -> List:
+    from scipy.optimize import _lbfgsb
+    runs = [_RcRun(_lbfgsb, x0, bounds, **options) for x0 in starts]
+    waiting = [i for i, r in enumerate(runs) if r.advance()]
+    while waiting:
+        # (ScalarFunction hands the objective a copy of x and stores float(f): the values the routine sees are the same)
+        vals = batch_fun([np.array(runs[i].x) for i in waiting])
+        nxt = []
+        for i, (f, g) in zip(waiting, vals):
+            runs[i].give(float(f), g)
+            if runs[i].advance():
+                nxt.append(i)
+        waiting = nxt
+    return [r.result() for r in runs]
+
+
+def _rc_available() -> bool:
+    """The private routine is there, has the signature this file was written against, and the stepped loop reproduces
+    ``minimize`` exactly on a bounded quadratic (checked once per process)."""
+    if _RC_STATE["checked"]:
+        return _RC_STATE["ok"]
+    _RC_STATE["checked"] = True
+    try:
+        import scipy
+        if tuple(int(v) for v in scipy.__version__.split(".")[:2]) != (1, 15):
+            return False
+        A = np.array([[3.0, 0.4, 0.1], [0.4, 2.0, -0.3], [0.1, -0.3, 1.5]])
+        b = np.array([1.0, -2.0, 0.5])
+
+        def vg(x):
+            return float(0.5 * x @ A @ x - b @ x + 0.1 * np.sum(x ** 4)), A @ x - b + 0.4 * x ** 3
+        bounds = [(-0.5, 2.0), (-3.0, 0.2), (None, None)]
+        starts = np.array([[1.5, -2.5, 3.0], [-0.2, 0.1, -4.0]])
+        opts = {"ftol": 1e-9, "gtol": 1e-8, "maxiter": 50}
+        mine = _rc_minimize_all(lambda xs: [vg(x) for x in xs], starts, bounds, opts)
+        for x0, r in zip(starts, mine):
+            ref = minimize(vg, x0, jac=True, method="L-BFGS-B", bounds=bounds, options=dict(opts))
+            if not (np.array_equal(r.x, ref.x) and r.fun == ref.fun and r.nit == ref.nit and r.nfev == ref.nfev and
+                    r.message == ref.message and bool(r.success) == bool(ref.success)):
+                return False
+        _RC_STATE["ok"] = True
+    except Exception as e:  # pragma: no cover
+        log.debug(f"stepped L-BFGS-B driver unavailable ({e}); the thread driver is used")
+    return _RC_STATE["ok"]
 
 
 def _minimize_in_slots(slot_fun: Callable, starts: np.ndarray, has_grad: bool, n_slots: int, **kw) -> List:

@@ -166,6 +166,53 @@ def test_concurrent_restart_drivers_equal_the_sequential_loop():
     assert max(batch_sizes) == 7 and min(batch_sizes) >= 1   # rounds shrink as restarts finish
 
 
+def test_stepped_lbfgsb_driver_is_scipy_minimize_restart_for_restart():
+    """The lock-step driver steps SciPy's reverse-communication L-BFGS-B routine from one thread (optim._rc_minimize_all,
+    a restatement of scipy.optimize._lbfgsb_py._minimize_lbfgsb's loop on a private module): every restart must come
+    out exactly as ``minimize`` returns it - iterate, value, iteration and evaluation counts, message - with bounds that
+    bind, a maxiter that cuts some restarts short and an objective that goes NaN for one of them; and the thread driver
+    (the fallback when the private routine is missing or different) must agree too."""
+    from scipy.optimize import minimize
+    from bobe_amd import optim
+
+    def vg(x):
+        x = np.asarray(x)
+        f = float(np.sum(100 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2) + 0.01 * np.sum(np.cos(5 * x)))
+        g = np.zeros_like(x)
+        g[:-1] += -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        g += -0.05 * np.sin(5 * x)
+        if x[0] > 1.9:                                        # (like a kernel matrix that is not positive definite)
+            return float("nan"), np.full_like(x, np.nan)
+        return f, g
+
+    assert optim._rc_available()                              # this image's SciPy is the one the loop was written against
+    starts = np.random.default_rng(3).uniform(-2, 2, size=(6, 5))
+    starts[2, 0] = 1.95
+    bounds = [(-2.0, 2.0), (-0.5, 2.0), (None, 1.5), (-2.0, None), (None, None)]
+    for maxiter, tol in ((5, {"ftol": 1e-9, "gtol": 1e-7}), (200, {"ftol": 1e-9, "gtol": 1e-7}), (200, {"ftol": 1e-15, "gtol": 1e-12})):
+        # (the last setting drives the line search into failures: the routine then asks again at the point it has)
+        kw = dict(method="L-BFGS-B", bounds=bounds, options=dict(tol, maxiter=maxiter))
+        ref = [minimize(vg, x0, jac=True, **kw) for x0 in starts]
+        sizes = []
+
+        def batch(xs):
+            sizes.append(len(xs))
+            return [vg(x) for x in xs]
+        got = optim._minimize_concurrently(batch, starts, True, **kw)
+        assert max(sizes) == 6 and min(sizes) >= 1
+        saved = optim._RC_STATE["ok"]
+        optim._RC_STATE["ok"] = False                         # the thread driver
+        try:
+            thr = optim._minimize_concurrently(lambda xs: [vg(x) for x in xs], starts, True, **kw)
+        finally:
+            optim._RC_STATE["ok"] = saved
+        for r, a, b in zip(ref, got, thr):
+            for o in (a, b):
+                assert np.array_equal(o.x, r.x, equal_nan=True) and (o.fun == r.fun or (np.isnan(o.fun) and np.isnan(r.fun)))
+                assert o.nit == r.nit and o.nfev == r.nfev and o.message == r.message and bool(o.success) == bool(r.success)
+
+
 def test_small_host_helpers():
     from bobe_amd.dist_sweep import dist_info, shard_bounds
     from bobe_amd.samplers import get_hmc_settings, prior_transform
