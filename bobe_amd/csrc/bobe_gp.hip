@@ -1703,7 +1703,10 @@ int bobe_gp_mll_batch(bobe_gp_t* g, int64_t B, const double* ls, const double* k
     }
     return worst;
   }
-  const int width = std::max(1, std::min<int>(tuning().mll_slots, BOBE_MAX_MLL_SLOTS));
+  // (this path serves batches below lockstep_min_n points: kernels of a few workgroups each, where eight evaluations in
+  //  flight beat four - an 8-restart fit at N = 400 / 900: 59.5 / 93.7 against 66.5 / 102.3 ms; BOBE_MLL_SLOTS overrides)
+  static const bool slots_from_env = std::getenv("BOBE_MLL_SLOTS") != nullptr;
+  const int width = std::max(1, std::min<int>(slots_from_env ? tuning().mll_slots : BOBE_MAX_MLL_SLOTS, BOBE_MAX_MLL_SLOTS));
   for (int64_t b0 = 0; b0 < B; b0 += width) {
     const int nbat = (int)std::min<int64_t>(width, B - b0);
     static const bool trace = std::getenv("BOBE_TRACE") != nullptr;
