@@ -16,6 +16,7 @@ from typing import Any, Dict, Optional, Tuple
 import numpy as np
 from scipy.stats import qmc
 
+from . import _lib
 from .gp import GP
 from .optim import optimize_scipy
 from .utils import get_logger, get_numpy_rng
@@ -52,9 +53,7 @@ class AcquisitionFunction:
         x_batch.append(np.asarray(x_next))
         acq_vals.append(val)
         if n_batch > 1:
-            dummy_gp = GP(train_x=gp.train_x, train_y=gp.train_y * gp.y_std + gp.y_mean, noise=gp.noise,
-                          kernel=gp.kernel_name, lengthscales=gp.lengthscales, kernel_variance=gp.kernel_variance,
-                          device=gp.device)                                    # acquisition.py:175-180
+            dummy_gp = _believer_gp(gp)                                        # acquisition.py:175-180
             dummy_gp.update(x_next, dummy_gp.predict_mean_single(x_next))
             for _ in range(1, n_batch):
                 x_next, val = self.get_next_point(dummy_gp, acq_kwargs=acq_kwargs, maxiter=maxiter,
@@ -64,6 +63,30 @@ class AcquisitionFunction:
                 acq_vals.append(val)
                 dummy_gp.update(x_next, dummy_gp.predict_mean_single(x_next))
         return np.array(x_batch), np.array(acq_vals)
+
+
+def _believer_gp(gp: GP) -> GP:
+    """The plain GP the kriging believer works on (acquisition.py:175-180: same data, kernel and hyper-parameters as ``gp``,
+    default priors).  The reference constructs a new one per batch, i.e. standardises and factorises again; here ONE scratch
+    GP per surrogate is kept and brought to ``gp``'s state on the device (``bobe_gp_clone_state``: data, L, L^-1, alpha
+    copied, no factorisation).  Creating and destroying a handle costs ~40 hipMalloc / hipFree calls - 6 of the 16 ms of a
+    batch of five at N = 400 (tools/acq_host_profile.py)."""
+    if gp._pushed_hyper != gp._hyper_key():          # attributes changed by hand since the last factorisation: the reference's
+        return GP(train_x=gp.train_x, train_y=gp.train_y * gp.y_std + gp.y_mean, noise=gp.noise, kernel=gp.kernel_name,
+                  lengthscales=gp.lengthscales, kernel_variance=gp.kernel_variance, device=gp.device)   # dummy sees the new ones
+    d = getattr(gp, "_believer_scratch", None)
+    if d is None or d.ndim != gp.ndim or d.kernel_name != gp.kernel_name or d.device != gp.device:
+        d = GP(train_x=gp.train_x, train_y=gp.train_y * gp.y_std + gp.y_mean, noise=gp.noise, kernel=gp.kernel_name,
+               lengthscales=gp.lengthscales, kernel_variance=gp.kernel_variance, device=gp.device, _factor=False)
+        gp._believer_scratch = d
+    d.train_x, d.train_y = np.array(gp.train_x), np.array(gp.train_y)
+    d.y_mean, d.y_std = gp.y_mean, gp.y_std
+    d.lengthscales, d.kernel_variance, d.noise = np.array(gp.lengthscales), float(gp.kernel_variance), float(gp.noise)
+    _lib.check(d._lib.bobe_gp_clone_state(d._h, gp._h), "bobe_gp_clone_state")
+    d.not_pd = bool(gp.not_pd)
+    d._pushed_hyper = gp._pushed_hyper
+    d._chol_cache = d._alpha_cache = None
+    return d
 
 
 class EI(AcquisitionFunction):
