@@ -368,20 +368,24 @@ def main():
                              "all-gather is inside sweep_ms (bobe_mgpu_wip_sweep) and exchange_ms is bobe_mgpu_best_fit alone"}
         del swork
 
-    def timed(fn, reps=2):
+    def timed(fn, reps=5):
+        """median wall time (ms) of ``reps`` calls after one untimed call (a single slow call - a first-use allocation, a
+        host hiccup - would otherwise move a two-call mean by several per cent)"""
         fn()
         lib.bobe_gp_sync(h)
-        t1 = time.perf_counter()
+        ts = []
         for _ in range(reps):
+            t1 = time.perf_counter()
             fn()
-        lib.bobe_gp_sync(h)
-        return (time.perf_counter() - t1) * 1e3 / reps
+            lib.bobe_gp_sync(h)
+            ts.append((time.perf_counter() - t1) * 1e3)
+        return float(np.median(ts))
 
     secondary = rank == 0 and not args.no_secondary
     fit_ms, sub_ms, lbfgs, gpu_check = {}, {}, None, None
     if secondary:               # secondary measurements, outside the timed region: the three phases of a cycle on rank 0
         all_r = list(range(R_total))
-        fit_ms["sequential"] = timed(lambda: fit_evals(all_r, "sequential"), 1)
+        fit_ms["sequential"] = timed(lambda: fit_evals(all_r, "sequential"), 3)
         if R_total > 1:
             fit_ms[f"slots_{R_total}"] = timed(lambda: fit_evals(all_r, "slots"))
             fit_ms[f"lockstep_{R_total}"] = timed(lambda: fit_evals(all_r, "batch"))
