@@ -141,10 +141,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep, fill, fill_near, fill_chunk, fill_slack, fill_phase, fill_inv, fill_inv_chunk; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep, fill, fill_near, fill_chunk, fill_slack, fill_phase, fill_inv, fill_inv_chunk, sweep_overlap; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0, 1, 2, 3, 16, 1024, 1, 4};
+    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0, 1, 2, 3, 16, 1024, 1, 4, 0};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -167,6 +167,10 @@ const Tuning& tuning() {
     // no deadline, so they take whatever CUs the panel launches leave; 0 = off.  Chunk: 64-column units of K per visit
     if (const char* e = std::getenv("BOBE_FILL_INV")) v.fill_inv = std::atoi(e);
     if (const char* e = std::getenv("BOBE_FILL_INV_CHUNK")) v.fill_inv_chunk = std::max(1, std::atoi(e));
+    // sweep of two chunks or more: 1 = the assembly of chunk i+1 on a second stream, under the GEMM launch of chunk i.
+    // Off by default: with the posterior-mean products fused into the assembly there are 75 us per chunk left to hide, and
+    // the GEMM launch it runs under loses 120 us (58.3 -> 58.8 ms per cycle at the headline size)
+    if (const char* e = std::getenv("BOBE_SWEEP_OVERLAP")) v.sweep_overlap = std::atoi(e);
     if (const char* e = std::getenv("BOBE_FILL_SLACK")) v.fill_slack = std::max(1, std::atoi(e)); // deferred / caught-up work the plan accepts
     return v;
   }();
@@ -238,6 +242,9 @@ struct bobe_gp {
   };
   std::map<uint64_t, CholPlan> chol_plans;
   const CholPlan& chol_plan(int B, bool fill, bool inv = false);
+  // second K(X, chunk) buffer + mean partials + events of the sweep's assembly stream (sweep())
+  DBuf kXC2, part_aux;
+  hipEvent_t ev_sw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
       o_misc, kin_a, kin_b, kout;
   std::vector<Depth> depths;
@@ -356,8 +363,10 @@ struct bobe_gp {
   // reads its hyper-parameters from hdev[b]; B = 1 with zero strides is the plain call.
   void scale(const double* in, int64_t n, int64_t npad, const Hyper& h, double* out, int64_t ldo,
              const Hyper* hdev = nullptr, int B = 1, int64_t bsO = 0, int* info_reset = nullptr);
+  // wv / prt: also prt[row tile][column] = the tile's share of out^T wv (k_gemv_t_part's partial sums, same bits)
   void kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT, int64_t ldb,
-                           int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo);
+                           int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo,
+                           const double* wv = nullptr, double* prt = nullptr, int64_t ldp = 0);
   void assemble_kxx(const Hyper& h, const double* xst, double* a, const Hyper* hdev = nullptr, int B = 1,
                     int64_t bsX = 0, int64_t bsA = 0);
   void syrk(double* a, int k0, int k1, int first, int colmode, int B = 1, int64_t bsA = 0, const int* colk0 = nullptr,
@@ -472,9 +481,11 @@ void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, d
   } while (0)
 
 void bobe_gp::kernel_matrix_cross(const double* AT, int64_t lda, int64_t na, int64_t napad, const double* BT,
-                                  int64_t ldb, int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo) {
+                                  int64_t ldb, int64_t nbv, int64_t nbpad, const Hyper& h, double* out, int64_t ldo,
+                                  const double* wv, double* prt, int64_t ldp) {
   const dim3 grid((unsigned)(nbpad / TILE), (unsigned)(napad / TILE));
-  KM_DISPATCH(false, grid, AT, lda, na, BT, ldb, nbv, h, out, ldo, (const Hyper*)nullptr, (int64_t)0, (int64_t)0);
+  KM_DISPATCH(false, grid, AT, lda, na, BT, ldb, nbv, h, out, ldo, (const Hyper*)nullptr, (int64_t)0, (int64_t)0, wv, prt,
+              ldp);
   LAUNCH_CHECK();
 }
 
@@ -482,7 +493,8 @@ void bobe_gp::assemble_kxx(const Hyper& h, const double* xst, double* a, const H
                            int64_t bsA) {
   const dim3 grid((unsigned)(2 * nb * (nb + 1)), (unsigned)B);   // four workgroups per lower 128x128 tile
   prof_begin(BOBE_PROF_KXX);
-  KM_DISPATCH(true, grid, xst, Np, N, xst, Np, N, h, a, Np, hdev, bsX, bsA);
+  KM_DISPATCH(true, grid, xst, Np, N, xst, Np, N, h, a, Np, hdev, bsX, bsA, (const double*)nullptr, (double*)nullptr,
+              (int64_t)0);
   prof_end(BOBE_PROF_KXX);
   LAUNCH_CHECK();
 }
@@ -1360,25 +1372,63 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
     d_fant = is_device_ptr(fantasy_out) ? fantasy_out : (kout.ensure((size_t)C * M * sizeof(double)), kout.d());
   }
   const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+  // BOBE_SWEEP_OVERLAP=1 (experiment, off by default), two chunks or more: the VALU-bound front of a chunk (K(X, chunk)
+  // with the posterior-mean products) runs on a second stream under the MFMA-bound GEMM launch of the chunk before it; the
+  // GEMM launches themselves stay in order on the handle's stream.  K(X, chunk) is double-buffered; events: [0] inputs ready, [1] scoring done with CsT,
+  // [2 + b] buffer b assembled, [4 + b] buffer b consumed.  Same kernels on the same data: same bits.
+  const bool overlap = tuning().sweep_overlap != 0 && C > CH;
+  hipStream_t aux = nullptr;
+  double* kxc[2] = {kXC.d(), kXC.d()};
+  if (overlap) {
+    aux = slot_stream_set()[0];
+    for (hipEvent_t& e : ev_sw)
+      if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    kXC2.ensure((size_t)Np * CH * sizeof(double));
+    part_aux.ensure((size_t)nb * CH * sizeof(double));
+    kxc[1] = kXC2.d();
+    HIPCHK(hipEventRecord(ev_sw[0], stream));          // (after the candidates' upload and everything the factor needs)
+    HIPCHK(hipStreamWaitEvent(aux, ev_sw[0], 0));
+  }
+  struct StreamSwap {                                  // the launch helpers use the member `stream`
+    hipStream_t& a;
+    hipStream_t& b;
+    bool on;
+    StreamSwap(hipStream_t& a_, hipStream_t& b_, bool on_) : a(a_), b(b_), on(on_) { if (on) std::swap(a, b); }
+    ~StreamSwap() { if (on) std::swap(a, b); }
+  };
+  int64_t ci = 0;                                      // chunk counter (buffer parity)
   for (int64_t s0 = 0; s0 < C; s0 += SC) {
     const int64_t ns = (C - s0 < SC) ? (C - s0) : SC;
     const int64_t nsp = round_up(ns, TILE);
-    scale(cin + s0 * d, ns, nsp, hyp, CsT.d(), SC);
-    for (int64_t c0 = 0; c0 < ns; c0 += CH) {
+    {
+      StreamSwap sw(stream, aux, overlap);
+      if (overlap && s0 > 0) HIPCHK(hipStreamWaitEvent(stream, ev_sw[1], 0));   // the scorer read the previous CsT
+      scale(cin + s0 * d, ns, nsp, hyp, CsT.d(), SC);
+    }
+    for (int64_t c0 = 0; c0 < ns; c0 += CH, ++ci) {
       const int64_t nc = (ns - c0 < CH) ? (ns - c0) : CH;
       const int64_t ncp = round_up(nc, TILE);
-      kernel_matrix_cross(XsT.d(), Np, N, Np, CsT.d() + c0, SC, nc, ncp, hyp, kXC.d(), CH);
-      if (d_mean) {
-        hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(ncp / 64), (unsigned)nb), dim3(256), 0, stream,
-                           (const double*)kXC.d(), CH, 0, (const double*)alpha.d(), part.d(), CH);
-        hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
-                           (const double*)part.d(), CH, nb, 0, nc, d_mean + s0 + c0);
+      const int b = overlap ? (int)(ci & 1) : 0;
+      {
+        StreamSwap sw(stream, aux, overlap);
+        if (overlap && ci >= 2) HIPCHK(hipStreamWaitEvent(stream, ev_sw[4 + b], 0));
+        // (posterior mean: the assembly leaves K(X, chunk)^T alpha per row tile on the way, k_gemv_t_part's partial sums)
+        double* pm = overlap ? part_aux.d() : part.d();
+        kernel_matrix_cross(XsT.d(), Np, N, Np, CsT.d() + c0, SC, nc, ncp, hyp, kxc[b], CH,
+                            d_mean ? (const double*)alpha.d() : nullptr, d_mean ? pm : nullptr, CH);
+        if (d_mean) {
+          hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
+                             (const double*)pm, CH, nb, 0, nc, d_mean + s0 + c0);
+        }
+        if (overlap) HIPCHK(hipEventRecord(ev_sw[2 + b], stream));
       }
+      if (overlap) HIPCHK(hipStreamWaitEvent(stream, ev_sw[2 + b], 0));
       prof_begin(BOBE_PROF_TRIMUL);
       hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)(nb + nzt)), dim3(256), GEMM_SMEM_BYTES,
-                         stream, (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, (double*)nullptr,
+                         stream, (const double*)Linv.d(), Np, nb, (const double*)kxc[b], CH, (double*)nullptr,
                          (int64_t)0, qpart.d(), CH, (const double*)WZ.d(), Mp, nzt, do_wip ? pv.d() + c0 : nullptr, SC);
       prof_end(BOBE_PROF_TRIMUL);
+      if (overlap) HIPCHK(hipEventRecord(ev_sw[4 + b], stream));
       // s_c for the scorer, var for the caller
       hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                          (const double*)qpart.d(), CH, nb, nc, kself, policy, sc.d() + c0,
@@ -1404,6 +1454,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
       prof_end(BOBE_PROF_CROSS);
       LAUNCH_CHECK();
     }
+    if (overlap && s0 + SC < C) HIPCHK(hipEventRecord(ev_sw[1], stream));
   }
   o_misc.ensure(8 * sizeof(double));
   double* m_val = o_misc.d();                                        // [0],[1]
@@ -1517,7 +1568,8 @@ void bobe_gp_destroy(bobe_gp_t* g) {
   DBuf* bufs[] = {&g->X, &g->y, &g->XsT, &g->XsT2, &g->A, &g->Linv, &g->A2, &g->Linv2, &g->Tmp, &g->alpha, &g->w,
                   &g->alpha2, &g->w2, &g->part, &g->gpart, &g->res, &g->info, &g->probs, &g->flags, &g->diag, &g->in_stage, &g->z_stage,
                   &g->CsT, &g->ZsT, &g->kXC, &g->kXZ, &g->VZ, &g->WZ, &g->basez, &g->sc, &g->qpart, &g->pv, &g->ps,
-                  &g->o_mean, &g->o_var, &g->o_wipv, &g->o_wipstd, &g->o_misc, &g->kin_a, &g->kin_b, &g->kout, &g->wg_ws, &g->filler_ws};
+                  &g->o_mean, &g->o_var, &g->o_wipv, &g->o_wipstd, &g->o_misc, &g->kin_a, &g->kin_b, &g->kout, &g->wg_ws, &g->filler_ws,
+                  &g->kXC2, &g->part_aux};
   for (DBuf* b : bufs) b->release();
   for (auto& pr : g->prof_events) {
     (void)hipEventDestroy(pr.first);
@@ -1559,6 +1611,8 @@ void bobe_gp_destroy(bobe_gp_t* g) {
     kv.second.d_skip.release();
   }
   if (g->ev_batch) (void)hipEventDestroy(g->ev_batch);
+  for (hipEvent_t e : g->ev_sw)
+    if (e) (void)hipEventDestroy(e);
   if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -2060,10 +2114,9 @@ int bobe_gp_predict_grad(bobe_gp_t* g, const double* Xq, int64_t C, double* mean
   for (int64_t c0 = 0; c0 < C; c0 += CH) {
     const int64_t nc = std::min<int64_t>(CH, C - c0), ncp = round_up(nc, TILE);
     g->scale(cin + c0 * d, nc, ncp, g->hyp, g->CsT.d(), CH);
-    g->kernel_matrix_cross(g->XsT.d(), Np, g->N, Np, g->CsT.d(), CH, nc, ncp, g->hyp, g->kXC.d(), CH);
+    g->kernel_matrix_cross(g->XsT.d(), Np, g->N, Np, g->CsT.d(), CH, nc, ncp, g->hyp, g->kXC.d(), CH,
+                           d_mean ? (const double*)g->alpha.d() : nullptr, d_mean ? g->part.d() : nullptr, CH);
     if (d_mean) {
-      hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned)(ncp / 64), (unsigned)nb), dim3(256), 0, g->stream,
-                         (const double*)g->kXC.d(), CH, 0, (const double*)g->alpha.d(), g->part.d(), CH);
       hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, g->stream,
                          (const double*)g->part.d(), CH, nb, 0, nc, d_mean + c0);
     }

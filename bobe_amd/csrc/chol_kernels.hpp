@@ -123,6 +123,9 @@ __device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0
 // NW = waves of the workgroup that take part (4 for the 256-thread kernels, 8 in k_chol_panel): wave 0 owns the
 // serial leaf, the others share the deferred updates and the row solves (which tile a wave gets does not change any
 // tile's arithmetic).
+#ifndef BOBE_PANEL_LATE
+#define BOBE_PANEL_LATE 5
+#endif
 struct NoSideJob {
   __device__ __forceinline__ void operator()(int) const {}
 };
@@ -186,15 +189,22 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
       const int op = o - 16;
       const int nt = 8 - p;                 // tiles p..7
       const int ntiles = nt * (nt + 1) / 2 - 1;
-      constexpr int NU = NW - 1 - (SKIPW > 0 ? 1 : 0);            // updater waves
-      const int hw = wave - 1 - ((SKIPW > 0 && wave > SKIPW) ? 1 : 0);
-      for (int q = hw; q < ntiles; q += 2 * NU) {
-        int a0, b0, a1, b1;
-        tri_decode_small(q + 1, a0, b0);    // index 0 is (p, p): skipped
-        const bool two = (q + NU) < ntiles;
-        tri_decode_small(two ? q + NU + 1 : q + 1, a1, b1);
-        potf2_update2(S, op, p + a0, p + b0, p + a1, p + b1, two, lane);
-      }
+      constexpr int NUALL = NW - 1 - (SKIPW > 0 ? 1 : 0);         // updater waves
+      // Eight waves (k_chol_panel): from step LATE on the side job is the long pole (4 p + 4 dependent MFMAs per solver
+      // wave, two solver waves on one SIMD) and the deferred tiles are few: they go to waves 6 and 7, which have no side
+      // job, so that no wave does both under the leaf (phase A of steps 4..7: 5.2-5.6 k -> ~4 k cycles, the leaf's own)
+      constexpr int LATE = BOBE_PANEL_LATE;
+      const bool late = (NW == 8) && p >= LATE;
+      const int NU = late ? 2 : NUALL;
+      const int hw = late ? wave - 6 : wave - 1 - ((SKIPW > 0 && wave > SKIPW) ? 1 : 0);
+      if (hw >= 0)
+        for (int q = hw; q < ntiles; q += 2 * NU) {
+          int a0, b0, a1, b1;
+          tri_decode_small(q + 1, a0, b0);    // index 0 is (p, p): skipped
+          const bool two = (q + NU) < ntiles;
+          tri_decode_small(two ? q + NU + 1 : q + 1, a1, b1);
+          potf2_update2(S, op, p + a0, p + b0, p + a1, p + b1, two, lane);
+        }
       side(p - 1);
     }
     __syncthreads();
@@ -505,7 +515,32 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
   double* Ab = A + col0 * lda + col0;
   double* Ib = Linv + col0 * ldl + col0;
   BOBE_STAMP(0);
-  potf2_stage_in<8>(S, Dall, Ab, lda, nsteps);
+  // Stage-in under the first leaf: wave 0 fetches only what its first leaf reads - the 16 x 16 tile (0, 0) - and starts
+  // factoring; waves 1..7 (idle in phase A of step 0) bring in rows 16..127 meanwhile (lower part: rows 0..15 hold nothing
+  // else that is read).  The barrier that ends phase A of step 0 publishes the block (it used to cost ~10 k cycles before
+  // the first leaf could start).
+  if (wave == 0) {
+    const int r = lane >> 2, c = (lane & 3) * 4;
+    const v2d u0 = *reinterpret_cast<const v2d*>(Ab + (int64_t)r * lda + c);
+    const v2d u1 = *reinterpret_cast<const v2d*>(Ab + (int64_t)r * lda + c + 2);
+    *reinterpret_cast<v2d*>(S + r * PLD + c) = u0;
+    *reinterpret_cast<v2d*>(S + r * PLD + c + 2) = u1;
+  } else {
+    v2d v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = 16 + (wave - 1) + 7 * i;
+      const int c = (2 * lane <= r) ? 2 * lane : (r & ~1);
+      v[i] = *reinterpret_cast<const v2d*>(Ab + (int64_t)r * lda + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<v2d*>(S + (16 + (wave - 1) + 7 * i) * PLD + 2 * lane) = v[i];
+  }
+  if (nsteps < 8)
+    for (int e = t; e < (8 - nsteps) * 16 * 16; e += PANEL_THREADS) {
+      const int pp = nsteps + (e >> 8), rr = (e >> 4) & 15, cc = e & 15;
+      Dall[(pp * 16 + rr) * POTF2_DLD + cc] = (rr == cc) ? 1.0 : 0.0;
+    }
   __builtin_amdgcn_sched_barrier(0);
 
   // solver wave (1, 2, 3, 5 = strip 0..3): rows (k+1)*128 + 64*pw + 16*strip .. +15 of block column k, straight into
@@ -524,9 +559,7 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
 #pragma unroll
       for (int r = 0; r < 4; ++r) X[p][r] = Aw[(int64_t)li * lda + 16 * p + g + 4 * r];
   }
-  // (a raw barrier behind a wait for the LDS writes only: __syncthreads() would also wait for vmcnt(0), i.e. for the 32
-  // scattered loads of X just issued - 6 k cycles that are meant to pass under the first leaf)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // (no barrier here: phase A of step 0 touches only wave 0's own tile; the scattered loads of X pass under the first leaf)
   BOBE_STAMP(1);
   // sub-block p in two parts: accumulate<p> (x = A^T_p - sum_{q<p} L_kk[p][q] X^T_q: needs the factor's steps < p only)
   // and finish<p> (X^T_p = invD_p x: needs leaf p).  Every LDS operand of a part is read first (one latency for all).

@@ -89,12 +89,17 @@ __global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t
 // cache.  No LDS: the kernel is bound by the exp / pairwise-distance arithmetic and the coalesced 8-byte stores
 // (512 B per wave per row).
 // FULL: d == DCAP exactly (no per-dimension predication at all).
+// wv / part (cross tiles only): the tile's share of out^T wv on the way, part[ti*ldp + column] = sum over the tile's 128 rows
+// of out[row][column] wv[row] - the posterior-mean product K(X, C)^T alpha without reading K(X, C) back.  The thread
+// halves own rows 0..63 / 64..127 and sum them in the order of k_gemv_t_part (four runs of 32 rows, then
+// ((r0 + r1) + r2) + r3): the same bits as that kernel on the stored tile.
 template <int KERN, bool SQUARE, int DCAP, bool FULL>
 __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ AT, int64_t lda, int64_t na,
                                                        const double* __restrict__ BT, int64_t ldb, int64_t nb,
                                                        Hyper h, double* __restrict__ out, int64_t ldo,
                                                        const Hyper* __restrict__ hp = nullptr, int64_t bsX = 0,
-                                                       int64_t bsO = 0) {
+                                                       int64_t bsO = 0, const double* __restrict__ wv = nullptr,
+                                                       double* __restrict__ part = nullptr, int64_t ldp = 0) {
   if (hp) h = hp[SQUARE ? blockIdx.y : 0];
   int ti, tj;
   if (SQUARE) {
@@ -116,9 +121,13 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
   for (int j = 0; j < DCAP; ++j) xb[j] = (FULL || j < h.d) ? BT[j * ldb + gb] : 0.0;
   const int a0 = __builtin_amdgcn_readfirstlane(t >> 7);   // wave-uniform (a wave spans 64 consecutive columns)
   const double* arow = AT + (int64_t)ti * TILE;
-  const int abeg = SQUARE ? (int)(blockIdx.x & 3) * (TILE / 4) : 0, aend = SQUARE ? abeg + TILE / 4 : TILE;
+  // SQUARE: the halves interleave over the workgroup's 32 rows; cross tiles: half a0 owns rows 64 a0 .. 64 a0 + 63
+  const int abeg = SQUARE ? (int)(blockIdx.x & 3) * (TILE / 4) + a0 : a0 * (TILE / 2);
+  const int aend = SQUARE ? abeg - a0 + TILE / 4 : abeg + TILE / 2;
+  const int astep = SQUARE ? 2 : 1;
+  double s = 0.0, s_first = 0.0;
 #pragma unroll 4
-  for (int a = abeg + a0; a < aend; a += 2) {
+  for (int a = abeg; a < aend; a += astep) {
     const int64_t ga = (int64_t)ti * TILE + a;
     double r2 = 0.0;
     double xa[DCAP];   // unconditional (clamped) loads: all in flight at once, no branch per dimension
@@ -137,6 +146,22 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
       v = (SQUARE && ga == gb) ? 1.0 : 0.0;
     }
     out[ga * ldo + gb] = v;
+    if (!SQUARE && wv) {
+      if (a == abeg + TILE / 4) {      // (wave-uniform) second run of 32 rows
+        s_first = s;
+        s = 0.0;
+      }
+      s = __builtin_fma(v, wv[ga], s);
+    }
+  }
+  if (!SQUARE && wv) {
+    __shared__ double red[2][TILE];
+    if (a0 == 1) {
+      red[0][b] = s_first;
+      red[1][b] = s;
+    }
+    __syncthreads();
+    if (a0 == 0) part[(int64_t)ti * ldp + gb] = ((s_first + s) + red[0][b]) + red[1][b];
   }
 }
 

@@ -24,7 +24,7 @@ def _digests(extra_env):
 def test_every_launch_sequence_gives_the_same_bits():
     base = _digests({})
     assert len(base) >= 30
-    for variant in ({"BOBE_XCD_SHARES": "0"}, {"BOBE_CHOL_LEGACY": "1"}, {"BOBE_PAIR_MIN": "0"}):
+    for variant in ({"BOBE_XCD_SHARES": "0"}, {"BOBE_CHOL_LEGACY": "1"}, {"BOBE_PAIR_MIN": "0"}, {"BOBE_SWEEP_OVERLAP": "1"}):
         other = _digests(variant)
         differing = [k for k in base if base[k] != other[k]]
         assert not differing, (variant, differing)
@@ -50,6 +50,6 @@ def test_deferred_updates_in_the_panel_shadows_do_not_move_a_bit():
                            capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         digests[mode] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert digests["0"].keys() == digests["2"].keys() and len(digests["0"]) == 6 * 7
+    assert digests["0"].keys() == digests["2"].keys() and len(digests["0"]) == 6 * 7 + 2      # (+ the sweeps at N <= 2048)
     assert digests["2"] == digests["0"]
     assert digests["1"] == digests["0"]                       # the default (fillers only where they pay)
