@@ -300,7 +300,6 @@ struct bobe_gp {
     DBuf A, Linv, Tmp, XsT, w, alpha, part, gpart, res, info, hyp, diag;
     Hyper* h_hyp = nullptr;      // pinned [BOBE_MAX_MLL_SLOTS]
     double* h_res = nullptr;     // pinned [BOBE_MAX_MLL_SLOTS][128]
-    int* h_info = nullptr;       // pinned [BOBE_MAX_MLL_SLOTS]
   } bw;
   int64_t gpart_stride() const { return (int64_t)(2 * nb) * (2 * nb + 1) / 2 * (MAX_D + 1); }
   void ensure_batch(int B);
@@ -1224,7 +1223,6 @@ void bobe_gp::ensure_batch(int B) {
   if (!bw.h_hyp) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bw.h_hyp), BOBE_MAX_MLL_SLOTS * sizeof(Hyper), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bw.h_res), BOBE_MAX_MLL_SLOTS * 128 * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bw.h_info), BOBE_MAX_MLL_SLOTS * sizeof(int), hipHostMallocDefault));
   }
   const size_t mat = (size_t)Np * Np * sizeof(double), vec = (size_t)Np * sizeof(double);
   const size_t nB = (size_t)B;
@@ -1241,7 +1239,7 @@ void bobe_gp::ensure_batch(int B) {
 }
 
 // B value(+gradient) evaluations in lock step: the pipeline of mll_enqueue_body with every launch widened by the
-// slot dimension.  Results land in the pinned bw.h_res[b*128 + ...] / bw.h_info[b] (layout of mll_enqueue_body).
+// slot dimension.  Results land in the pinned bw.h_res[b*128 + ...] (layout of mll_enqueue_body, the info word at [100]).
 void bobe_gp::mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad) {
   ensure_batch(B);
   const int64_t mat = Np * Np, vec = Np, xs = (int64_t)d * Np, prt = (int64_t)nb * Np, gps = gpart_stride();
@@ -1249,24 +1247,25 @@ void bobe_gp::mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad) {
   HIPCHK(hipMemcpyAsync(bw.hyp.p, bw.h_hyp, (size_t)B * sizeof(Hyper), hipMemcpyHostToDevice, stream));
   const Hyper* hdev = static_cast<const Hyper*>(bw.hyp.p);
   int* inf = static_cast<int*>(bw.info.p);
-  scale(X.d(), N, Np, hs[0], bw.XsT.d(), Np, hdev, B, xs);
+  scale(X.d(), N, Np, hs[0], bw.XsT.d(), Np, hdev, B, xs, inf);      // (also arms the B info words)
   assemble_kxx(hs[0], bw.XsT.d(), bw.A.d(), hdev, B, xs, mat);
-  HIPCHK(hipMemsetAsync(inf, 0x7f, (size_t)B * sizeof(int), stream));
   const CholPlan* rest = potrf(bw.A.d(), bw.Linv.d(), inf, B, mat, mat, bw.diag.d(), true, bw.Tmp.d(), mat);
   trtri(bw.A.d(), bw.Linv.d(), bw.Tmp.d(), B, mat, mat, mat, rest);
   solve_alpha(bw.Linv.d(), bw.w.d(), bw.alpha.d(), bw.part.d(), B, mat, vec, prt);
-  hipLaunchKernelGGL(k_mll_terms, dim3(B), dim3(256), 0, stream, (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np,
-                     bw.res.d(), vec, mat, (int64_t)128);
+  // (the info word of slot b rides in res[b * 128 + 100]: one copy brings everything to the host)
   if (want_grad) {
     const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
     const int ntiles = lauum(hs[0], bw.Linv.d(), bw.alpha.d(), bw.XsT.d(), nullptr, dcap, hdev, bw.gpart.d(), B, mat, vec,
                              xs, gps);
-    hipLaunchKernelGGL(k_grad_reduce, dim3(d + 1, B), dim3(64), 0, stream, (const double*)bw.gpart.d(), ntiles, dcap + 1, d,
-                       dcap, bw.res.d() + 2, gps, (int64_t)128);
+    hipLaunchKernelGGL(k_mll_grad_reduce, dim3(d + 2, B), dim3(256), 0, stream, (const double*)bw.gpart.d(), ntiles, dcap + 1,
+                       d, dcap, bw.res.d(), (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np, (const int*)inf, gps,
+                       (int64_t)128, vec, mat);
+  } else {
+    hipLaunchKernelGGL(k_mll_terms, dim3(B), dim3(256), 0, stream, (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np,
+                       bw.res.d(), vec, mat, (int64_t)128, (const int*)inf);
   }
   LAUNCH_CHECK();
   HIPCHK(hipMemcpyAsync(bw.h_res, bw.res.p, (size_t)B * 128 * sizeof(double), hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipMemcpyAsync(bw.h_info, inf, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
 }
 
 int bobe_gp::mll_lockstep_collect(int B, double* mll, double* grad, int* status) {
@@ -1276,11 +1275,13 @@ int bobe_gp::mll_lockstep_collect(int B, double* mll, double* grad, int* status)
     const double* hr = bw.h_res + (size_t)b * 128;
     double* gb = grad ? grad + (size_t)b * (d + 1) : nullptr;
     int st = BOBE_OK;
-    if (bw.h_info[b] != 0x7f7f7f7f) {
+    int inf_b;
+    std::memcpy(&inf_b, hr + 100, sizeof(int));
+    if (inf_b != 0x7f7f7f7f) {
       mll[b] = std::nan("");
       if (gb)
         for (int j = 0; j <= d; ++j) gb[j] = std::nan("");
-      g_err = "kernel matrix not positive definite at column " + std::to_string(bw.h_info[b] - 1);
+      g_err = "kernel matrix not positive definite at column " + std::to_string(inf_b - 1);
       st = BOBE_NOT_PD;
       worst = st;
     } else {
@@ -1602,7 +1603,6 @@ void bobe_gp_destroy(bobe_gp_t* g) {
     for (DBuf* b : bb) b->release();
     if (g->bw.h_hyp) (void)hipHostFree(g->bw.h_hyp);
     if (g->bw.h_res) (void)hipHostFree(g->bw.h_res);
-    if (g->bw.h_info) (void)hipHostFree(g->bw.h_info);
   }
   for (auto& kv : g->chol_plans) {
     kv.second.d_jobs.release();

@@ -421,31 +421,22 @@ __global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w,
   mll_terms_body((int)blockIdx.x, w, L, ld, np, res, bsW, bsL, bsR, info);      // batched: blockIdx.x = slot
 }
 
-// res[j] = 0.5 * sum_tiles partial[tile*stride + src(j)]: one wave per component, lane-strided partial
-// sums combined by a fixed butterfly (deterministic).  grid = d+1 blocks of 64 threads.
-__global__ __launch_bounds__(64) void k_grad_reduce(const double* __restrict__ partial, int ntiles, int stride, int d,
-                                                    int dcap, double* __restrict__ res, int64_t bsP = 0,
-                                                    int64_t bsR = 0) {
-  partial += blockIdx.y * bsP;   // batched: blockIdx.y = slot
-  res += blockIdx.y * bsR;
-  const int j = blockIdx.x;
-  const int src = (j == d) ? dcap : j;
-  double s = 0.0;
-  for (int q = threadIdx.x; q < ntiles; q += 64) s += partial[(int64_t)q * stride + src];
-  s = wave_sum(s);
-  if (threadIdx.x == 0) res[j] = 0.5 * s;
-}
-// the two reductions that end an evaluation in ONE launch (single matrix): workgroups 0..d are k_grad_reduce's (their
-// first wave, same order of summation), workgroup d+1 is k_mll_terms
+// The two reductions that end an evaluation in ONE launch.  Workgroups 0..d: res[2 + j] = 0.5 * sum over the tiles of
+// partial[tile * stride + src(j)], one wave per component, lane-strided partial sums combined by a fixed butterfly
+// (deterministic).  Workgroup d+1 is k_mll_terms.  blockIdx.y = slot of a lock-step batch (strides in doubles).
 __global__ __launch_bounds__(256) void k_mll_grad_reduce(const double* __restrict__ partial, int ntiles, int stride, int d,
                                                          int dcap, double* __restrict__ res,
                                                          const double* __restrict__ w, const double* __restrict__ L,
-                                                         int64_t ld, int64_t np, const int* __restrict__ info) {
+                                                         int64_t ld, int64_t np, const int* __restrict__ info,
+                                                         int64_t bsP = 0, int64_t bsR = 0, int64_t bsW = 0, int64_t bsL = 0) {
+  const int slot = blockIdx.y;
   if ((int)blockIdx.x == d + 1) {
-    mll_terms_body(0, w, L, ld, np, res, 0, 0, 0, info);
+    mll_terms_body(slot, w, L, ld, np, res, bsW, bsL, bsR, info);
     return;
   }
   if (threadIdx.x >= 64) return;
+  partial += slot * bsP;
+  res += slot * bsR;
   const int j = blockIdx.x;
   const int src = (j == d) ? dcap : j;
   double s = 0.0;

@@ -22,21 +22,21 @@ if sys.argv[1] == "run":
         gp.mll_data_batch(ls, np.ones(B)) if B > 1 else gp.mll_data(ls[0], 1.0)
 else:
     rows = list(csv.DictReader(open(sys.argv[2])))
-    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void bobe::", "").replace("bobe::", ""))
-                for r in rows)
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void bobe::", "").replace("bobe::", ""),
+                 r.get("Stream_Id", "?")) for r in rows)
     last = max(i for i, e in enumerate(ev) if "k_scale_coords" in e[2] or "k_kernel_matrix" in e[2] and "k_scale_coords" not in ev[i - 1][2])
     seg = ev[last:]
     if sys.argv[1] == "timeline":
         t0, prev_end = seg[0][0], seg[0][0]
-        print("   start_us   dur_us   gap_us  kernel")
-        for s_, e_, n in seg:
-            print(f"{(s_ - t0) / 1e3:11.1f} {(e_ - s_) / 1e3:8.2f} {(s_ - prev_end) / 1e3:8.2f}  {n}")
+        print("   start_us   dur_us   gap_us  stream  kernel      (gap: since the end of every earlier launch)")
+        for s_, e_, n, st in seg:
+            print(f"{(s_ - t0) / 1e3:11.1f} {(e_ - s_) / 1e3:8.2f} {(s_ - prev_end) / 1e3:8.2f}  {st:>6}  {n}")
             prev_end = max(prev_end, e_)
-        busy = sum(e_ - s_ for s_, e_, _ in seg) / 1e3
+        busy = sum(e_ - s_ for s_, e_, _, _ in seg) / 1e3
         print(f"span {(seg[-1][1] - t0) / 1e3:.1f} us, kernel time {busy:.1f} us, gaps {(seg[-1][1] - t0) / 1e3 - busy:.1f} us")
         sys.exit(0)
     tot, cnt = collections.defaultdict(float), collections.Counter()
-    for s, e, n in seg:
+    for s, e, n, _ in seg:
         tot[n] += (e - s) / 1e3
         cnt[n] += 1
     span = (seg[-1][1] - seg[0][0]) / 1e3
