@@ -106,8 +106,10 @@ void configure_kernels_once() {
   allow_big_lds(k_potf2<false, false>, POTF2_SMEM_BYTES);
   allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
   allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
-  allow_big_lds(k_chol_panel<false>, POTF2_SMEM_BYTES);
-  allow_big_lds((k_chol_panel<false, true>), POTF2_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<false, false, 3>), POTF2_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<false, false, 4>), POTF2_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<false, true, 3>), POTF2_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<false, true, 4>), POTF2_SMEM_BYTES);
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_syrk_trail<64, SYRK64_BK>, SYRK64_SMEM);
@@ -141,10 +143,10 @@ struct Depth { int first, count, nblocks; };
 
 // tile-size switches (128-tile counts below which the 64x64-tile variant of a kernel is launched);
 // overridable through the environment for tuning runs
-struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep, fill, fill_near, fill_chunk, fill_slack, fill_phase, fill_inv, fill_inv_chunk, sweep_overlap; };
+struct Tuning { int syrk32_below, trtri64_below, lauum64_below, chol_legacy, pair_min, mll_slots, own_queues, graph_max_n, lockstep_min_n, xcd_shares, filler_iters, filler_keep, fill, fill_near, fill_chunk, fill_slack, fill_phase, fill_inv, fill_inv_chunk, sweep_overlap, panel_strips; };
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0, 1, 2, 3, 16, 1024, 1, 4, 0};
+    Tuning v{512, 600, 1200, 0, 300, 4, 1, 2048, 1024, 1, 0, 0, 1, 2, 3, 16, 1024, 1, 4, 0, 0};
     if (const char* e = std::getenv("BOBE_SYRK32_BELOW")) v.syrk32_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_TRTRI64")) v.trtri64_below = std::atoi(e);
     if (const char* e = std::getenv("BOBE_LAUUM64")) v.lauum64_below = std::atoi(e);
@@ -171,6 +173,8 @@ const Tuning& tuning() {
     // Off by default: with the posterior-mean products fused into the assembly there are 75 us per chunk left to hide, and
     // the GEMM launch it runs under loses 120 us (58.3 -> 58.8 ms per cycle at the headline size)
     if (const char* e = std::getenv("BOBE_SWEEP_OVERLAP")) v.sweep_overlap = std::atoi(e);
+    // 16-row strips per panel workgroup: 0 = three wherever the launch fits the chip, else four; 3 / 4 force (A/B runs)
+    if (const char* e = std::getenv("BOBE_PANEL_STRIPS")) v.panel_strips = std::atoi(e);
     if (const char* e = std::getenv("BOBE_FILL_SLACK")) v.fill_slack = std::max(1, std::atoi(e)); // deferred / caught-up work the plan accepts
     return v;
   }();
@@ -242,6 +246,12 @@ struct bobe_gp {
   };
   std::map<uint64_t, CholPlan> chol_plans;
   const CholPlan& chol_plan(int B, bool fill, bool inv = false);
+  // strips per workgroup of the panel launch with `rr` blocks below the diagonal block (chol_kernels.hpp, panel_workgroups)
+  int panel_strips(int B, int rr) const {
+    const int ps = tuning().panel_strips;
+    if (ps == 3 || ps == 4) return ps;
+    return B * panel_workgroups(rr, 3) <= std::max(num_cus, 1) ? 3 : 4;
+  }
   // second K(X, chunk) buffer + mean partials + events of the sweep's assembly stream (sweep())
   DBuf kXC2, part_aux;
   hipEvent_t ev_sw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -544,7 +554,7 @@ const bobe_gp::CholPlan& bobe_gp::chol_plan(int B, bool fill, bool inv) {
   if (it != chol_plans.end()) return it->second;
   const int ncu = std::max(num_cus, 1);
   const int D = tu.fill_near, CH = tu.fill_chunk, ICH = tu.fill_inv_chunk;
-  auto npanel = [&](int k) { return panel_workgroups(nb - 1 - k); };
+  auto npanel = [&](int k) { return panel_workgroups(nb - 1 - k, panel_strips(B, nb - 1 - k)); };
   auto one_launch = [&](int k) { return !tu.chol_legacy && B * npanel(k) <= ncu; };
   auto tiles_of = [&](int c) { return 4 * (nb - c) - 1; };   // 64 x 64 tiles of block column c from its diagonal block down
 
@@ -904,27 +914,34 @@ const bobe_gp::CholPlan* bobe_gp::potrf(double* a, double* linv, int* info_dev, 
     if (op.kind == 0) {                                       // (64 rows of the panel per workgroup)
       const int kk = op.k;
       const int rr = nb - 1 - kk;
-      const int np_ = panel_workgroups(rr);
+      const int strips = panel_strips(B, rr);
+      const int np_ = panel_workgroups(rr, strips);
       const int rows_below = rr * TILE;
       const int nv = (int)std::min<int64_t>(TILE, N - (int64_t)kk * TILE);
       if (!tu.chol_legacy && B * np_ <= std::max(num_cus, 1)) {
         first_aside = std::min(first_aside, kk);
         prof_begin(BOBE_PROF_POTF2);
         const int standin = tu.filler_iters > 0 ? std::max(0, (num_cus - tu.filler_keep - B * np_) / B) : 0;
+#define PANEL_LAUNCH(FILLV, GRIDX, ...)                                                                                        \
+  do {                                                                                                                         \
+    if (strips == 3)                                                                                                           \
+      hipLaunchKernelGGL((k_chol_panel<false, FILLV, 3>), dim3(GRIDX, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, \
+                         bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, __VA_ARGS__);       \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((k_chol_panel<false, FILLV, 4>), dim3(GRIDX, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, \
+                         bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, __VA_ARGS__);       \
+  } while (0)
         if (op.tab_cnt > 0) {
-          hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + op.tab_cnt / 2, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES,
-                             stream, a, Np, bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr,
-                             jobs + op.tab_off, op.tab_cnt, 0, (double*)nullptr, rows_below, tmp, Np, bsT);
+          PANEL_LAUNCH(true, np_ + op.tab_cnt / 2, jobs + op.tab_off, op.tab_cnt, 0, (double*)nullptr, rows_below, tmp, Np, bsT);
         } else if (standin > 0) {
           filler_ws.ensure((size_t)B * (np_ + standin) * PANEL_THREADS * sizeof(double));
-          hipLaunchKernelGGL((k_chol_panel<false, true>), dim3(np_ + standin, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream,
-                             a, Np, bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr,
-                             (const FillJob*)nullptr, 0, tu.filler_iters, filler_ws.d(), rows_below);
+          PANEL_LAUNCH(true, np_ + standin, (const FillJob*)nullptr, 0, tu.filler_iters, filler_ws.d(), rows_below, (double*)nullptr,
+                       (int64_t)0, (int64_t)0);
         } else {
-          hipLaunchKernelGGL(k_chol_panel<false>, dim3(np_, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, bsA, linv,
-                             Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, (const FillJob*)nullptr, 0,
-                             0, (double*)nullptr, rows_below);
+          PANEL_LAUNCH(false, np_, (const FillJob*)nullptr, 0, 0, (double*)nullptr, rows_below, (double*)nullptr, (int64_t)0,
+                       (int64_t)0);
         }
+#undef PANEL_LAUNCH
         prof_end(BOBE_PROF_POTF2);
       } else {
         prof_begin(BOBE_PROF_POTF2);

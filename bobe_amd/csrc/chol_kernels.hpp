@@ -67,6 +67,13 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   return y;
 }
 
+// per-wave stamps of phase A (diagnostic builds): stamps[64 + 32 * wave + slot]
+#define BOBE_WSTAMP(slot)                                                                                   \
+  do {                                                                                                      \
+    if (STAMP && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0)                              \
+      stamps[64 + 32 * (threadIdx.x >> 6) + (slot)] = __builtin_amdgcn_s_memtime();                         \
+  } while (0)
+
 // ---- diagonal block -------------------------------------------------------------------------------
 // FACTOR: Cholesky of A[blk][blk] in place (lower, zeros above).  Always: the inverses of the eight
 // 16x16 diagonal sub-blocks go to the same positions of Linv[blk][blk] (rest of that block untouched).
@@ -116,6 +123,91 @@ __device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0
   }
 }
 
+// The in-block update of n <= 6 consecutive tiles of the row-major list (positions t, t+1, ... of the triangle of tiles
+// p..7) in ONE pass: all accumulators, then the four K-steps with n independent MFMA chains, then the stores - the pipe
+// sees n x 4 MFMAs back to back instead of pairs between LDS round trips.  Per tile the operands and the order of its
+// four MFMAs are potf2_update2's.
+template <int K>
+__device__ __forceinline__ void potf2_update_run(double* S, int o, int p, int a, int b, int lane) {
+  // (a, b, p, o are wave-uniform: the tile offsets stay in scalar registers, a lane adds them to its two fixed bases - the
+  // accumulator layout (row (lane >> 4) + 4 r, column lane & 15) and the operand layout (row lane & 15, column 4 ks +
+  // (lane >> 4)) - and every access of a tile is that address plus a compile-time offset)
+  double* accb = S + (lane >> 4) * PLD + (lane & 15);
+  const double* opb = S + (lane & 15) * PLD + (lane >> 4) + o;
+  double* pc[K];
+  const double *pa[K], *pb[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int ti = p + a, tj = p + b;
+    pc[k] = accb + ti * (16 * PLD) + tj * 16;
+    pa[k] = opb + ti * (16 * PLD);
+    pb[k] = opb + tj * (16 * PLD);
+    if (++b > a) {
+      ++a;
+      b = 0;
+    }
+  }
+  // every LDS operand of the pass is requested before the first MFMA (one latency for all of them)
+  v4d acc[K];
+  double av[K][4], bv[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[k][r] = pc[k][r * 4 * PLD];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      av[k][ks] = pa[k][4 * ks];
+      bv[k][ks] = pb[k][4 * ks];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[k][ks], bv[k][ks], acc[k], 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pc[k][r * 4 * PLD] = acc[k][r];
+}
+
+// k_chol_panel's deferred tiles per helper wave and step.  Helpers in the order waves 1, 2, 3, 5, 6, 7; waves 1 and 5 share a
+// SIMD and both carry a row-solve side job (4 p + 4 dependent MFMAs in phase A of step p), waves 2 / 6 and 3 / 7 pair a
+// solver with a wave that has none.  A 16 x 16 x 4 fp64 MFMA holds a SIMD's pipe for 64 cycles and the leaf gives phase A
+// ~4 k: the counts below level tiles x 4 + side-job MFMAs over the three SIMDs (per-wave stamps, tools/ubench.hip: with an
+// even split the solver SIMD ran 5.5-6.8 k cycles in steps 1-4).  Which wave updates a tile does not change its arithmetic.
+constexpr unsigned pack4(int a, int b, int c, int d, int e, int f) {
+  return (unsigned)a | ((unsigned)b << 4) | ((unsigned)c << 8) | ((unsigned)d << 12) | ((unsigned)e << 16) | ((unsigned)f << 20);
+}
+__device__ __forceinline__ void panel_tile_range(int strips, int p, int h, int& start, int& cnt) {
+  unsigned c;
+  if (strips == 3) {                                  // waves 1, 2, 3 solve, waves 5, 6, 7 update: one of each per SIMD
+    switch (p) {
+      case 1: c = pack4(3, 3, 3, 6, 6, 6); break;     // 27 tiles (the side job is still short: the solvers take some)
+      case 2: c = pack4(2, 2, 2, 5, 5, 4); break;     // 20
+      case 3: c = pack4(1, 1, 1, 4, 4, 3); break;     // 14
+      case 4: c = pack4(0, 0, 0, 3, 3, 3); break;     //  9
+      case 5: c = pack4(0, 0, 0, 2, 2, 1); break;     //  5
+      case 6: c = pack4(0, 0, 0, 1, 1, 0); break;     //  2
+      default: c = 0u; break;
+    }
+  } else {
+    switch (p) {
+      case 1: c = pack4(4, 4, 4, 3, 6, 6); break;
+      case 2: c = pack4(2, 3, 3, 2, 5, 5); break;
+      case 3: c = pack4(1, 2, 2, 1, 4, 4); break;
+      case 4: c = pack4(0, 1, 1, 0, 4, 3); break;
+      case 5: c = pack4(0, 0, 0, 0, 3, 2); break;
+      case 6: c = pack4(0, 0, 0, 0, 1, 1); break;
+      default: c = 0u; break;
+    }
+  }
+  start = 0;
+  for (int i = 0; i < 6; ++i)
+    if (i < h) start += (int)((c >> (4 * i)) & 15u);
+  cnt = (int)((c >> (4 * h)) & 15u);
+}
+
 // The factor loop proper, on a block already staged in LDS (S: [128][PLD], lower part valid; Dall: [8][16][POTF2_DLD]).
 // Called by the first 256 threads of a workgroup (waves 0..3); colbase = global index of the block's first column
 // (for *info).  Leaves L (lower; the diagonal 16x16 tiles zero-filled above the diagonal) in S and the inverses of
@@ -123,9 +215,6 @@ __device__ __forceinline__ void potf2_update2(double* S, int o, int ti0, int tj0
 // NW = waves of the workgroup that take part (4 for the 256-thread kernels, 8 in k_chol_panel): wave 0 owns the
 // serial leaf, the others share the deferred updates and the row solves (which tile a wave gets does not change any
 // tile's arithmetic).
-#ifndef BOBE_PANEL_LATE
-#define BOBE_PANEL_LATE 5
-#endif
 struct NoSideJob {
   __device__ __forceinline__ void operator()(int) const {}
 };
@@ -134,7 +223,7 @@ struct NoSideJob {
 // its rows below the block there, under the leaf of wave 0, instead of after the factor.
 // SKIPW > 0: that wave takes no phase-A work (with more than four waves, wave SKIPW = 4 shares the leaf wave's SIMD, and
 // MFMAs issued there slow the leaf down by half: measured 4.4-4.9 k -> 5.7-6.4 k cycles per step).
-template <bool STAMP, int NW = 4, class SIDE = NoSideJob, int SKIPW = -1>
+template <bool STAMP, int NW = 4, class SIDE = NoSideJob, int SKIPW = -1, int STRIPS = 4>
 __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int nsteps, int colbase, int* __restrict__ info,
                                                  unsigned long long* __restrict__ stamps, SIDE side = SIDE()) {
   const int t = threadIdx.x;
@@ -145,6 +234,7 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
     double* Dv = Dall + p * 16 * POTF2_DLD;
     BOBE_STAMP(2 + 3 * p);
     if (wave == 0) {
+      BOBE_WSTAMP(3 * p);
       // ---- phase A, wave 0: 16x16 Cholesky + inverse (upper half-wave idle: EXEC[63:32] = 0) ----
       if (lane < 32) {
       const int li = lane & 15;
@@ -183,21 +273,42 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
       }
       if (bad && lane == 0) atomicMin(info, colbase + o + 1);
       }
+      BOBE_WSTAMP(3 * p + 2);
     } else if (p > 0 && wave != SKIPW) {
+      BOBE_WSTAMP(3 * p);
       // ---- phase A, waves 1..3: deferred updates of step p-1: every tile (ti, tj), p <= tj <= ti <= 7,
       //      except the diagonal tile (p, p), which wave 0 updated right after the previous phase B ----
       const int op = o - 16;
       const int nt = 8 - p;                 // tiles p..7
       const int ntiles = nt * (nt + 1) / 2 - 1;
-      constexpr int NUALL = NW - 1 - (SKIPW > 0 ? 1 : 0);         // updater waves
-      // Eight waves (k_chol_panel): from step LATE on the side job is the long pole (4 p + 4 dependent MFMAs per solver
-      // wave, two solver waves on one SIMD) and the deferred tiles are few: they go to waves 6 and 7, which have no side
-      // job, so that no wave does both under the leaf (phase A of steps 4..7: 5.2-5.6 k -> ~4 k cycles, the leaf's own)
-      constexpr int LATE = BOBE_PANEL_LATE;
-      const bool late = (NW == 8) && p >= LATE;
-      const int NU = late ? 2 : NUALL;
-      const int hw = late ? wave - 6 : wave - 1 - ((SKIPW > 0 && wave > SKIPW) ? 1 : 0);
-      if (hw >= 0)
+      if (NW == 8) {
+        // (eight waves: a contiguous run of the tile list per helper, sized by panel_tile_range)
+        int q0, nq;
+        const int wu = __builtin_amdgcn_readfirstlane(wave);       // (scalar: the run's tile offsets never touch a VGPR)
+        panel_tile_range(STRIPS, p, wu < 4 ? wu - 1 : wu - 2, q0, nq);
+        int a0 = 0, b0 = 0;
+        if (nq > 0) tri_decode_small(q0 + 1, a0, b0);               // index 0 is (p, p): skipped
+
+        while (nq > 0) {
+          const int m = nq > 6 ? (nq + 1) / 2 : nq;                 // (a long run in two passes of similar size)
+          switch (m) {
+            case 1: potf2_update_run<1>(S, op, p, a0, b0, lane); break;
+            case 2: potf2_update_run<2>(S, op, p, a0, b0, lane); break;
+            case 3: potf2_update_run<3>(S, op, p, a0, b0, lane); break;
+            case 4: potf2_update_run<4>(S, op, p, a0, b0, lane); break;
+            case 5: potf2_update_run<5>(S, op, p, a0, b0, lane); break;
+            default: potf2_update_run<6>(S, op, p, a0, b0, lane); break;
+          }
+          for (int i = 0; i < m; ++i)
+            if (++b0 > a0) {
+              ++a0;
+              b0 = 0;
+            }
+          nq -= m;
+        }
+      } else {
+        constexpr int NU = NW - 1 - (SKIPW > 0 ? 1 : 0);            // updater waves
+        const int hw = wave - 1 - ((SKIPW > 0 && wave > SKIPW) ? 1 : 0);
         for (int q = hw; q < ntiles; q += 2 * NU) {
           int a0, b0, a1, b1;
           tri_decode_small(q + 1, a0, b0);    // index 0 is (p, p): skipped
@@ -205,7 +316,10 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
           tri_decode_small(two ? q + NU + 1 : q + 1, a1, b1);
           potf2_update2(S, op, p + a0, p + b0, p + a1, p + b1, two, lane);
         }
+      }
+      BOBE_WSTAMP(3 * p + 1);
       side(p - 1);
+      BOBE_WSTAMP(3 * p + 2);
     }
     __syncthreads();
     BOBE_STAMP(3 + 3 * p);
@@ -483,24 +597,22 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
 // N = 4096, 0.63 vs 0.66 ms at 2048; removed.  Its update half ran at 33-36 TFLOP/s against 48 for four 256-thread
 // workgroups per CU, tools/ubench_upd.hip.)
 // The panel as its own launch: EIGHT waves.  Wave 0 is the factor's leaf wave; wave 4 (same SIMD) does nothing while the
-// leaf runs; waves 1, 2, 3, 5, 6, 7 are the helpers of the factor (deferred tile updates), and 1, 2, 3, 5 each own 16 of
-// the workgroup's 64 rows below the block.  The
+// leaf runs; waves 1, 2, 3, 5, 6, 7 are the helpers of the factor (deferred tile updates, shared out by panel_tile_range),
+// and 1, 2, 3 (and 5 with four strips) each own 16 of the workgroup's 48 (64) rows below the block.  The
 // solve of those rows by sub-block p (X^T_p = invD_p (A^T_p - sum_{q<p} L_kk[p][q] X^T_q), the MFMA sequence of
 // k_trsm_panel, same bits) only needs what factor step p produced, so the helpers run it in phase A of step p+1, under
 // wave 0's leaf, instead of after the factor: of the 144 MFMAs per wave (12 k cycles after a 52 k factor) only the last
 // sub-block's four stay exposed.
 constexpr int PANEL_THREADS = 512;
-#ifndef BOBE_PANEL_STRIPS
-#define BOBE_PANEL_STRIPS 4
-#endif
-// 16-row strips a panel workgroup solves (one per solver wave): 4 = waves 1, 2, 3, 5 (64 rows), 6 = waves 1, 2, 3, 5, 6, 7
-// (96 rows: a third fewer 150 KB workgroups per panel launch).  Which workgroup solves a strip does not change its bits.
-constexpr int PANEL_STRIPS = BOBE_PANEL_STRIPS;
-constexpr int PANEL_ROWS = 16 * PANEL_STRIPS;
-__host__ __device__ inline int panel_workgroups(int blocks_below) {
-  return blocks_below > 0 ? (blocks_below * TILE + PANEL_ROWS - 1) / PANEL_ROWS : 1;
+// 16-row strips a panel workgroup solves, one per solver wave.  STRIPS = 3 (48 rows, waves 1, 2, 3): every helper SIMD has
+// one solver and one wave that only updates tiles - phase A of every step from 4 on is then the leaf's own 4.2 k cycles,
+// against 4.6-5.7 k with STRIPS = 4 (64 rows, waves 1, 2, 3, 5: two solvers' dependent MFMA chains on one SIMD).  A third
+// more workgroups: the host takes 3 strips wherever the launch still fits the chip, else 4 (tools/ubench.hip stamps: panel
+// 64.3 k -> 60.2 k cycles).  Which workgroup solves a strip does not change its bits.
+__host__ __device__ inline int panel_workgroups(int blocks_below, int strips) {
+  return blocks_below > 0 ? (blocks_below * TILE + 16 * strips - 1) / (16 * strips) : 1;
 }
-template <bool STAMP>
+template <bool STAMP, int STRIPS>
 __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                  int64_t ldl, int k, int pw, int npanel, int* __restrict__ info,
                                                  int nvalid, double* __restrict__ Lkk_out,
@@ -548,7 +660,8 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
   // first factor steps
   const int strip = wave < 4 ? wave - 1 : wave - 2;                        // waves 1, 2, 3, 5, 6, 7 -> strips 0 .. 5
   const int64_t rows_below = (int64_t)(gridDim_rows_below);
-  const bool solver = has_rows && wave != 0 && wave != 4 && strip < PANEL_STRIPS &&
+  constexpr int PANEL_ROWS = 16 * STRIPS;
+  const bool solver = has_rows && wave != 0 && wave != 4 && strip < STRIPS &&
                       (int64_t)pw * PANEL_ROWS + strip * 16 < rows_below;      // (the last workgroup may own fewer strips)
   const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)pw * PANEL_ROWS + strip * 16;
   double* Aw = A + row0 * lda + col0;
@@ -609,7 +722,7 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
     }
   };
 #undef BOBE_SIDE_CASE
-  potf2_factor_lds<STAMP, 8, decltype(side), 4>(S, Dall, nsteps, (int)col0, info, stamps, side);
+  potf2_factor_lds<STAMP, 8, decltype(side), 4, STRIPS>(S, Dall, nsteps, (int)col0, info, stamps, side);
   BOBE_STAMP(26);
   // L_kk and the 16x16 inverses leave LDS once per slot: every workgroup of the launch holds the same factor, so
   // workgroup pw writes the rows pw, pw + npanel, ... of L_kk (zeros above the diagonal) and pw = 0 the inverses
@@ -680,7 +793,7 @@ constexpr int FILL_SMEM_DOUBLES = gemm_smem_doubles_exact<KC, KC, 64, 64, FILL_B
 constexpr int FILL_INV_BK = 16;                                                          // (KC x RC images at BK = 32 would not)
 static_assert(2 * FILL_SMEM_DOUBLES * 8 <= POTF2_SMEM_BYTES, "update fillers exceed the panel's LDS");
 static_assert(2 * gemm_smem_doubles_exact<KC, RC, 64, 64, FILL_INV_BK>() <= 2 * FILL_SMEM_DOUBLES, "inverse fillers use the same slices");
-template <bool STAMP = false, bool FILL = false>
+template <bool STAMP = false, bool FILL = false, int STRIPS = 4>
 __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
                                                               double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
                                                               int npanel, int* __restrict__ info, int nvalid,
@@ -745,7 +858,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict
     return;
   }
   const int slot = blockIdx.y;
-  chol_panel_body5<STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel, info + slot,
+  chol_panel_body5<STAMP, STRIPS>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel, info + slot,
                           nvalid, diag + slot * bsD + (int64_t)k * TILE * TILE, stamps, rows_below);
 }
 

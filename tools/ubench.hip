@@ -6,6 +6,9 @@
 #include <vector>
 #include "../bobe_amd/csrc/kernels.hpp"
 using namespace bobe;
+#ifndef UB_STRIPS
+#define UB_STRIPS 3      // 16-row strips per panel workgroup (3 or 4)
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 int main() {
@@ -22,7 +25,8 @@ int main() {
   int* info;
   CK(hipMalloc(&A, K.size() * 8));
   CK(hipMalloc(&Linv, K.size() * 8));
-  CK(hipMalloc(&st, 64 * 8));
+  CK(hipMalloc(&st, 320 * 8));
+  CK(hipMemset(st, 0, 320 * 8));
   CK(hipMalloc(&info, 4));
   CK(hipMemcpy(A, K.data(), K.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemset(Linv, 0, K.size() * 8));
@@ -30,7 +34,7 @@ int main() {
   CK(hipFuncSetAttribute((const void*)k_potf2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_SMEM_BYTES));
   CK(hipFuncSetAttribute((const void*)k_potf2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_SMEM_BYTES));
   CK(hipFuncSetAttribute((const void*)k_trsm_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_SMEM_BYTES));
-  unsigned long long h[64];
+  unsigned long long h[320];
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemcpy(A, K.data(), K.size() * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL((k_potf2<true, true>), dim3(1), dim3(256), POTF2_SMEM_BYTES, 0, A, (int64_t)N, Linv, (int64_t)N, 0, info, st);
@@ -58,15 +62,25 @@ int main() {
   for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_potf2<true, true>), dim3(1), dim3(256), POTF2_SMEM_BYTES, 0, A, (int64_t)N, Linv, (int64_t)N, 1, info, st);
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
   {
-    CK(hipFuncSetAttribute((const void*)k_chol_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_SMEM_BYTES));
+    CK(hipFuncSetAttribute((const void*)k_chol_panel<true, false, UB_STRIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_SMEM_BYTES));
     double* dg;
     CK(hipMalloc(&dg, (size_t)8 * 128 * 128 * 8));
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipMemcpy(A, K.data(), K.size() * 8, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL((k_chol_panel<true>), dim3(14, 1), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, 0, A, (int64_t)N, (int64_t)0, Linv, (int64_t)N,
-                         (int64_t)0, 0, 14, info, 128, dg, (int64_t)0, st, (const FillJob*)nullptr, 0, 0, (double*)nullptr, 7 * 128);
+      hipLaunchKernelGGL((k_chol_panel<true, false, UB_STRIPS>), dim3(panel_workgroups(7, UB_STRIPS), 1), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, 0, A, (int64_t)N, (int64_t)0, Linv, (int64_t)N,
+                         (int64_t)0, 0, panel_workgroups(7, UB_STRIPS), info, 128, dg, (int64_t)0, st, (const FillJob*)nullptr, 0, 0, (double*)nullptr, 7 * 128);
       CK(hipDeviceSynchronize());
-      CK(hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(h, st, 320 * 8, hipMemcpyDeviceToHost));
+      if (rep == 2)          // per wave and step: start of phase A (after the loop-top stamp of wave 0), deferred tiles, side job
+        for (int p = 1; p < 8; ++p) {
+          printf("  waves p%d (start+, tiles, side):", p);
+          for (int w = 0; w < 8; ++w) {
+            const unsigned long long* q = h + 64 + 32 * w + 3 * p;
+            if (w == 0) printf(" | w0 leaf %llu", q[2] - q[0]);
+            else if (q[0]) printf(" | w%d +%lld %llu(%llu) %llu", w, (long long)(q[0] - h[2 + 3 * p]), q[1] - q[0], h[64 + 32 * w + 24 + p] ? h[64 + 32 * w + 24 + p] - q[0] : 0ull, q[2] - q[1]);
+          }
+          printf("\n");
+        }
       unsigned long long ta = 0, tb = 0, tc = 0;
       for (int p = 0; p < 8; ++p) {
         ta += h[3 + 3 * p] - h[2 + 3 * p];
