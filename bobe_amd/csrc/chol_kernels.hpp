@@ -665,12 +665,18 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
                       (int64_t)pw * PANEL_ROWS + strip * 16 < rows_below;      // (the last workgroup may own fewer strips)
   const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)pw * PANEL_ROWS + strip * 16;
   double* Aw = A + row0 * lda + col0;
+  // Only the first two sub-blocks now; sub-block p + 2 is requested at the end of the side job of step p + 1, a leaf before it is
+  // needed (all 32 scattered loads per lane at once kept the stage-in waiting: phase A of step 0 7.9 k cycles with three
+  // solver waves, 9.6-10.3 k with four)
   v4d X[8];
+  auto fetch = [&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[p][r] = Aw[(int64_t)li * lda + 16 * p + g + 4 * r];
+  };
   if (solver) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X[p][r] = Aw[(int64_t)li * lda + 16 * p + g + 4 * r];
+    fetch(std::integral_constant<int, 0>());
+    fetch(std::integral_constant<int, 1>());
   }
   // (no barrier here: phase A of step 0 touches only wave 0's own tile; the scattered loads of X pass under the first leaf)
   BOBE_STAMP(1);
@@ -703,10 +709,11 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
   };
   // phase A of factor step pd + 1: finish sub-block pd, then the whole accumulation of sub-block pd + 1
   // (X is indexed with constants only: it must stay in registers)
-#define BOBE_SIDE_CASE(PD)                                    \
-  case PD:                                                    \
-    finish(std::integral_constant<int, PD>());                \
-    accumulate(std::integral_constant<int, PD + 1>());        \
+#define BOBE_SIDE_CASE(PD)                                                   \
+  case PD:                                                                   \
+    finish(std::integral_constant<int, PD>());                               \
+    accumulate(std::integral_constant<int, PD + 1>());                       \
+    if (PD + 2 < 8) fetch(std::integral_constant<int, (PD + 2) & 7>());      \
     break
   auto side = [&](int pd) {
     if (!solver) return;
