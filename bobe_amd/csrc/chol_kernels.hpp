@@ -655,7 +655,7 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
     }
   __builtin_amdgcn_sched_barrier(0);
 
-  // solver wave (1, 2, 3, 5 = strip 0..3): rows (k+1)*128 + 64*pw + 16*strip .. +15 of block column k, straight into
+  // solver wave (1, 2, 3, 5 = strip 0..3): rows (k+1)*128 + 16*STRIPS*pw + 16*strip .. +15 of block column k, straight into
   // transposed-accumulator layout (lane (li, g), register r of tile p = A[row li][16p + g + 4r]); in flight during the
   // first factor steps
   const int strip = wave < 4 ? wave - 1 : wave - 2;                        // waves 1, 2, 3, 5, 6, 7 -> strips 0 .. 5
@@ -665,9 +665,9 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
                       (int64_t)pw * PANEL_ROWS + strip * 16 < rows_below;      // (the last workgroup may own fewer strips)
   const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)pw * PANEL_ROWS + strip * 16;
   double* Aw = A + row0 * lda + col0;
-  // Only the first two sub-blocks now; sub-block p + 2 is requested at the end of the side job of step p + 1, a leaf before it is
-  // needed (all 32 scattered loads per lane at once kept the stage-in waiting: phase A of step 0 7.9 k cycles with three
-  // solver waves, 9.6-10.3 k with four)
+  // Only the first two sub-blocks now; sub-block p + 2 is requested at the end of the side job of step p + 1, a leaf
+  // before it is needed (all 32 scattered loads per lane at once kept the stage-in waiting: phase A of step 0 7.9 k
+  // cycles with three solver waves, 9.6-10.3 k with four)
   v4d X[8];
   auto fetch = [&](auto pc) {
     constexpr int p = decltype(pc)::value;
