@@ -56,11 +56,15 @@ template <int LA, int LB, int TM, int TN, int BK>
 constexpr int gemm_smem_doubles_exact() {
   return 2 * (Img<LA, TM, BK>::doubles + Img<LB, TN, BK>::doubles);
 }
-constexpr int BK128 = 16;   // 128x128 tiles: 73,728 B of LDS -> two workgroups per CU
-#ifndef BOBE_BK64
-#define BOBE_BK64 32
+#ifndef BOBE_BK128
+#define BOBE_BK128 16
 #endif
-constexpr int BK64 = BOBE_BK64;   // 64x64 tiles: deeper K-steps hide the global-load latency
+constexpr int BK128 = BOBE_BK128;   // 128x128 tiles: 73,728 B of LDS at BK = 16 -> two workgroups per CU
+#ifndef BOBE_BK64
+#define BOBE_BK64 16
+#endif
+constexpr int BK64 = BOBE_BK64;   // 64x64 tiles: 40,960 B of LDS -> FOUR workgroups per CU.  (Round 3: BK = 32 - 80 KB, two per CU -
+                                  // made the inverse and K^-1 launches 5-8 % slower: fit 32.8 -> 31.8 ms; BK = 8: 32.5 ms)
 constexpr int GEMM_SMEM_DOUBLES = gemm_smem_doubles<128, 128, BK128>();
 constexpr int GEMM_SMEM_BYTES = GEMM_SMEM_DOUBLES * 8;
 constexpr int GEMM64_SMEM_BYTES = gemm_smem_doubles<64, 64, BK64>() * 8;
