@@ -1,5 +1,5 @@
-"""The factorisation has several launch sequences (one-launch panel or k_potf2 + k_trsm_panel; XCD tile shares or the
-row-major tile order; alone, on a slot, in a lock-step batch).  They must all produce the same bits: the library reads
+"""The factorisation has several launch sequences (one-launch panel - with three or four row strips per workgroup - or
+k_potf2 + k_trsm_panel; XCD tile shares or the row-major tile order; alone, on a slot, in a lock-step batch).  They must all produce the same bits: the library reads
 its tuning environment once per process, so each variant runs tools/bits_snapshot.py in its own process and the digests
 of L, the MLL value, its gradient, the batched values and the predictions are compared."""
 import json
@@ -24,7 +24,8 @@ def _digests(extra_env):
 def test_every_launch_sequence_gives_the_same_bits():
     base = _digests({})
     assert len(base) >= 30
-    for variant in ({"BOBE_XCD_SHARES": "0"}, {"BOBE_CHOL_LEGACY": "1"}, {"BOBE_PAIR_MIN": "0"}, {"BOBE_SWEEP_OVERLAP": "1"}):
+    for variant in ({"BOBE_XCD_SHARES": "0"}, {"BOBE_CHOL_LEGACY": "1"}, {"BOBE_PAIR_MIN": "0"}, {"BOBE_SWEEP_OVERLAP": "1"},
+                    {"BOBE_PANEL_STRIPS": "4"}):
         other = _digests(variant)
         differing = [k for k in base if base[k] != other[k]]
         assert not differing, (variant, differing)
