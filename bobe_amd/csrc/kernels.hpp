@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Li
     return;
   }
   const int ti = nb - 1 - ((int)blockIdx.y - nzt);
-  gemm_tile<KC, RC>(acc, Linv, ldi, (int64_t)ti * TILE, B, ldb, (int64_t)tc * TILE, 0, (int64_t)(ti + 1) * TILE, smem);
+  // (the K range of a row tile ends with its diagonal block of the lower-triangular Linv: the zeros above the diagonal are
+  // skipped, 1.2 % of the launch)
+  gemm_tile<KC, RC, TILE, TILE, BK128, false, WgSync, true>(acc, Linv, ldi, (int64_t)ti * TILE, B, ldb, (int64_t)tc * TILE, 0,
+                                                            (int64_t)(ti + 1) * TILE, smem);
   if (V) store_tile(acc, V, ldv, (int64_t)ti * TILE, (int64_t)tc * TILE, 1.0, 0.0);
   if (qpart) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
