@@ -191,18 +191,27 @@ class BOBE:
             log.warning(f"Run state {resume_file}_run.json unusable ({e}): resuming with the GP file alone")
 
     def _checkpoint(self, state: dict, mc: Optional[dict]) -> None:
-        """``<save_path>_gp.npz`` (bo.py:239) and, beside it, the run state a resumed run continues from."""
+        """``<save_path>_gp.npz`` (bo.py:239) and, beside it, the run state a resumed run continues from.  Every file is
+        written under a temporary name and moved into place (``os.replace``), the run state LAST: a kill at any moment
+        leaves the previous generation readable, and a run state never names a GP file that is newer or half written
+        (``_handle_resume`` checks ``gp_training_set_size``)."""
         os.makedirs(self.save_dir, exist_ok=True)
-        self.gp.save(self.save_path + "_gp")
+        tmp_gp = self.save_path + "_gp.tmp"                              # (np.savez appends .npz)
+        self.gp.save(tmp_gp)
         st = dict(state, rng_state=self.np_rng.bit_generator.state, gp_training_set_size=int(self.gp.npoints),
                   n_points_since_last_fit=int(self.n_points_since_last_fit), timing=dict(self.timing),
                   has_mc=mc is not None)
+        tmp_mc = None
         if mc is not None:                                              # (arrays and scalars; acquisition uses 'x' only)
-            np.savez(self.save_path + "_mc.npz", **{k: np.asarray(v) for k, v in mc.items()
-                                                    if isinstance(v, (np.ndarray, float, int, str, np.generic))})
+            tmp_mc = self.save_path + "_mc.tmp.npz"
+            np.savez(tmp_mc, **{k: np.asarray(v) for k, v in mc.items()
+                                if isinstance(v, (np.ndarray, float, int, str, np.generic))})
         tmp = self.save_path + "_run.json.tmp"
         with open(tmp, "w") as fh:
             json.dump(st, fh)
+        os.replace(tmp_gp + ".npz", self.save_path + "_gp.npz")
+        if tmp_mc is not None:
+            os.replace(tmp_mc, self.save_path + "_mc.npz")
         os.replace(tmp, self.save_path + "_run.json")                  # (never a half-written state file)
 
     def _evaluate(self, pts: np.ndarray) -> np.ndarray:
@@ -414,7 +423,8 @@ class BOBE:
             samples = {"x": scale_from_unit(np.asarray(x_u), self.param_bounds), "weights": np.asarray(weights),
                        "logl": np.asarray(logl)}
         if self.save and is_wip and do_final_ns:                             # (the final fit changed the hyper-parameters)
-            self.gp.save(self.save_path + "_gp")
+            self.gp.save(self.save_path + "_gp.tmp")
+            os.replace(self.save_path + "_gp.tmp.npz", self.save_path + "_gp.npz")
         y = self.gp.train_y * self.gp.y_std + self.gp.y_mean
         ibest = int(np.argmax(y))
         best_x = scale_from_unit(self.gp.train_x[ibest], self.param_bounds)

@@ -4,9 +4,12 @@ All GP arithmetic is inherited (``super()`` calls into libbobe_gp.so, as in the 
 this class adds what the reference adds: a second, larger data set for a feasibility classifier, the GP
 trained only on points within ``gp_threshold`` of the best value (clf_gp.py:86-93, 238-244), and the gating of
 the predictions — mean -> ``minus_inf`` and variance -> 1e-12 where the classifier says "infeasible"
-(clf_gp.py:173-205).  Only the SVM classifier is provided (scikit-learn ``SVC`` + the RBF decision function of
-clf.py:188-213, evaluated batched in NumPy); the Flax MLP / ellipsoid classifiers are optional extras of the
-reference and are not built.
+(clf_gp.py:173-205).  Only the SVM classifier is provided: scikit-learn's ``SVC`` is TRAINED on the host, as in the
+reference (clf.py:36-69); its RBF decision function (clf.py:188-213) and the gate are evaluated ON THE DEVICE
+(``bobe_gp_set_gate``: inside ``bobe_gp_predict`` / ``_predict_grad`` / ``_acq_ei`` and the HMC kernels).  This file
+holds no classifier arithmetic: it hands the trained parameters to the library and replaces the library's mark for a
+gated mean (-inf) by ``minus_inf``.  The Flax MLP / ellipsoid classifiers are optional extras of the reference and are
+not built.
 """
 from __future__ import annotations
 
@@ -21,7 +24,9 @@ log = get_logger("clf_gp")
 
 
 def train_svm_classifier(X, Y, settings=None):
-    """clf.py:36-69: SVC(kernel='rbf', gamma='scale', C=1e7); returns (params, metrics, predict_fn)."""
+    """clf.py:36-69: SVC(kernel='rbf', gamma='scale', C=1e7); returns (params, metrics, None) - the prediction
+    function of the reference's triple is the library's gate here (``GPwithClassifier._sync_gate``,
+    ``get_svm_predict_proba_fn``)."""
     from sklearn.svm import SVC
     settings = settings or {}
     C = settings.get("C", 1e7)
@@ -31,20 +36,62 @@ def train_svm_classifier(X, Y, settings=None):
               "intercept": float(clf.intercept_[0]), "gamma_eff": float(clf._gamma)}
     metrics = {"n_support_vectors": len(params["support_vectors"]), "gamma": f"{params['gamma_eff']:.2e}",
                "C": f"{C:.2e}", "intercept": f"{params['intercept']:.2e}"}
-    return params, metrics, get_svm_predict_proba_fn(params)
+    return params, metrics, None
 
 
-def get_svm_predict_proba_fn(params) -> Callable[[np.ndarray], np.ndarray]:
-    """clf.py:71-78, 188-213: decision = sum_i dual_i exp(-gamma |x - sv_i|^2) + b ; proba = 1[decision >= 0]."""
-    sv, dc = np.asarray(params["support_vectors"]), np.asarray(params["dual_coef"])
-    b, gamma = float(params["intercept"]), float(params["gamma_eff"])
+def get_svm_predict_proba_fn(params, device: int = 0) -> Callable[[np.ndarray], np.ndarray]:
+    """clf.py:71-78: the probability function of stored SVM parameters (``svm_predict_proba``, clf.py:210-213) — evaluated
+    by the library (``bobe_gp_gate_eval`` on a data-less handle that carries only the gate)."""
+    return _DeviceSVM(params, device).proba
 
-    def predict(x):
-        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
-        d2 = np.sum(x * x, axis=1)[:, None] - 2.0 * x @ sv.T + np.sum(sv * sv, axis=1)[None, :]
-        decision = np.exp(-gamma * np.maximum(d2, 0.0)) @ dc + b
-        return np.where(decision >= 0, 1.0, 0.0)
-    return predict
+
+class _DeviceSVM:
+    """A library handle holding nothing but a classifier gate: decision values / probabilities of stored parameters."""
+
+    def __init__(self, params, device: int = 0):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self._ndim = int(np.asarray(params["support_vectors"]).shape[1])
+        self._h = C.c_void_p(0)
+        _lib.check(self._lib.bobe_gp_create(C.byref(self._h), int(device), 0, self._ndim), "bobe_gp_create")
+        install_gate(self._lib, self._h, params, 0.5, 0.0)
+
+    def __del__(self):
+        try:
+            if self._h.value:
+                self._lib.bobe_gp_destroy(self._h)
+        except Exception:
+            pass
+
+    def decision(self, x):
+        return gate_eval(self._lib, self._h, x, self._ndim)[0]
+
+    def proba(self, x):
+        return gate_eval(self._lib, self._h, x, self._ndim)[1]
+
+
+def install_gate(lib, handle, params, probability_threshold: float, minus_inf: float) -> None:
+    """Hand the trained SVM to the library (``bobe_gp_set_gate``); ``params=None`` clears the gate."""
+    from . import _lib
+    if params is None:
+        _lib.check(lib.bobe_gp_set_gate(handle, None, 0, None, 0.0, 0.0, float(probability_threshold), float(minus_inf)),
+                   "bobe_gp_set_gate")
+        return
+    sv = _lib.as_f64(np.atleast_2d(np.asarray(params["support_vectors"])))
+    dual = _lib.as_f64(np.asarray(params["dual_coef"])).reshape(-1)
+    _lib.check(lib.bobe_gp_set_gate(handle, _lib.ptr(sv), sv.shape[0], _lib.ptr(dual), float(params["intercept"]),
+                                    float(params["gamma_eff"]), float(probability_threshold), float(minus_inf)),
+               "bobe_gp_set_gate")
+
+
+def gate_eval(lib, handle, x, ndim: int):
+    """(decision, feasible) of the points ``x`` from the gate held by ``handle`` (``bobe_gp_gate_eval``)."""
+    from . import _lib
+    x = _lib.as_f64(np.atleast_2d(np.asarray(x, dtype=np.float64)).reshape(-1, ndim))
+    dec, ok = np.empty(x.shape[0]), np.empty(x.shape[0])
+    _lib.check(lib.bobe_gp_gate_eval(handle, _lib.ptr(x), x.shape[0], _lib.ptr(dec), _lib.ptr(ok)), "bobe_gp_gate_eval")
+    return dec, ok
 
 
 class GPwithClassifier(GP):
@@ -72,14 +119,46 @@ class GPwithClassifier(GP):
                          lengthscale_prior=lengthscale_prior if lengthscale_prior is not None else "DSLP",
                          kernel_variance_prior=kernel_variance_prior, tausq=tausq, tausq_bounds=tausq_bounds,
                          param_names=param_names, device=device)
-        self.use_clf = self.clf_data_size >= self.clf_use_size
+        self._gate_installed = False
         self._clf_predict_func: Optional[Callable] = None
+        self.use_clf = self.clf_data_size >= self.clf_use_size
         if self.use_clf and train_clf_on_init:
             self.train_classifier()
 
     @property
     def clf_data_size(self) -> int:
         return self.train_x_clf.shape[0]
+
+    # ``use_clf`` and the trained parameters decide whether the library gates this GP's predictions: every change of
+    # either goes through ``_sync_gate`` (the attribute can be set from outside, as in the reference)
+    @property
+    def use_clf(self) -> bool:
+        return self._use_clf
+
+    @use_clf.setter
+    def use_clf(self, value) -> None:
+        self._use_clf = bool(value)
+        self._sync_gate()
+
+    def _sync_gate(self) -> None:
+        """The library gates iff the reference would (clf_gp.py:175-176): ``use_clf`` and a trained classifier."""
+        want = bool(getattr(self, "_use_clf", False)) and getattr(self, "clf_params", None) is not None
+        if not hasattr(self, "_h") or not self._h.value:
+            return                                          # (before GP.__init__ created the handle)
+        if want:
+            install_gate(self._lib, self._h, self.clf_params, self.probability_threshold, self.minus_inf)
+            self._clf_predict_func = self._device_proba
+        elif self._gate_installed:
+            install_gate(self._lib, self._h, None, self.probability_threshold, self.minus_inf)
+        self._gate_installed = want
+
+    def _device_proba(self, x):
+        """``svm_predict_proba`` (clf.py:210-213) of the trained classifier, on the device."""
+        return gate_eval(self._lib, self._h, x, self.ndim)[1]
+
+    def clf_decision(self, x):
+        """``svm_predict`` (clf.py:188-208): the decision values of the trained classifier, on the device."""
+        return gate_eval(self._lib, self._h, x, self.ndim)[0]
 
     def train_classifier(self):
         """clf_gp.py:128-171."""
@@ -91,41 +170,45 @@ class GPwithClassifier(GP):
         if np.all(labels == labels[0]):               # one class only: do not use the classifier for the moment
             self.use_clf = False
             return
-        self.clf_params, self.clf_metrics, self._clf_predict_func = train_svm_classifier(
-            self.train_x_clf, labels, self.clf_settings)
+        self.clf_params, self.clf_metrics, _ = train_svm_classifier(self.train_x_clf, labels, self.clf_settings)
+        self._sync_gate()
 
-    def _feasible(self, x) -> Optional[np.ndarray]:
-        if not self.use_clf or self._clf_predict_func is None:
-            return None
-        return self._clf_predict_func(x) >= self.probability_threshold
+    def _gated(self) -> bool:
+        return self._gate_installed
 
-    # ---- gated predictions (clf_gp.py:173-205) ----
+    # ---- gated predictions (clf_gp.py:173-205): the library marks a gated mean with -inf and returns 1e-12 as its
+    # variance; the mark becomes ``minus_inf`` in the units of the method at hand
     def predict_mean_batched(self, x):
         m = super().predict_mean_batched(x)
-        ok = self._feasible(x)
-        return m if ok is None else np.where(ok, m, self.minus_inf)
+        return np.where(np.isneginf(m), self.minus_inf, m) if self._gated() else m
 
     def predict_mean_single(self, x):
         return self.predict_mean_batched(x)[0]
 
     def predict_var_batched(self, x):
-        v = super().predict_var_batched(x)
-        ok = self._feasible(x)
-        return v if ok is None else np.where(ok, v, safe_noise_floor)
+        if not self._gated():
+            return super().predict_var_batched(x)
+        # (the gate replaces the variance AFTER the y_std^2 scaling, clf_gp.py:186-189: the mean is asked for as well,
+        # it carries the gate's mark)
+        m, v = self._predict(x, True, True, 0)
+        return np.where(np.isneginf(m), safe_noise_floor, self.y_std ** 2 * v)
 
     def predict_var_single(self, x):
         return self.predict_var_batched(x)[0]
 
     def predict_batched(self, x):
         m, v = super().predict_batched(x)
-        ok = self._feasible(x)
-        if ok is None:
-            return m, v
-        return np.where(ok, m, self.minus_inf), np.where(ok, v, safe_noise_floor)
+        return (np.where(np.isneginf(m), self.minus_inf, m), v) if self._gated() else (m, v)
 
     def predict_single(self, x):
         m, v = self.predict_batched(x)
         return m[0], v[0:1]
+
+    def predict_grad(self, x, mean_only=False):
+        """``GP.predict_grad`` under the gate: a gated point has mean ``minus_inf`` (standardised units, like
+        ``predict_single``), variance 1e-12 and zero gradients."""
+        m, v, dm, dv = super().predict_grad(x, mean_only=mean_only)
+        return (np.where(np.isneginf(m), self.minus_inf, m), v, dm, dv) if self._gated() else (m, v, dm, dv)
 
     def update(self, new_x, new_y):
         """clf_gp.py:214-246: extend the classifier set, re-derive the GP subset, refactor."""
@@ -178,11 +261,9 @@ class GPwithClassifier(GP):
                 lengthscale_prior=plain(state.get("lengthscale_prior_spec")), tausq=plain(state.get("tausq", 1.0)),
                 tausq_bounds=list(np.asarray(state.get("tausq_bounds", [1e-4, 1e4])).tolist()),
                 train_clf_on_init=False, device=device)
-        g.use_clf = bool(plain(state["use_clf"]))
         g.clf_params = plain(state.get("clf_params"))
         g.clf_metrics = plain(state.get("clf_metrics", {})) or {}
-        if g.clf_params is not None:
-            g._clf_predict_func = get_svm_predict_proba_fn(g.clf_params)
+        g.use_clf = bool(plain(state["use_clf"]))              # (the setter hands the restored parameters to the library)
         return g
 
     def state_dict(self, with_factor: bool = True):

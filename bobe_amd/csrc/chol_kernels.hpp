@@ -1,18 +1,19 @@
-// Blocked Cholesky, triangular inverse and K^-1/gradient kernels (gfx950).  Included by kernels.hpp.
+// Blocked Cholesky, triangular inverse and K^-1/gradient kernels (gfx950).  Included by gp_factor.hip only.
 //
 // Right-looking blocked Cholesky with NB = 128, batched over slots:
 //   k_chol_panel   panel k of every factorisation of the batch in ONE launch: every workgroup factors the diagonal
 //                  block (k,k) in LDS (each one redundantly: no hand-off) and solves its 64 rows of block column k
 //                  under the factor's leaves
 //   k_syrk_trail   A22 -= L21 L21^T on lower tiles (one K = 256 pass per two panels where the update dominates)
-//   k_potf2 / k_trsm_panel   the two halves of a panel as separate launches (restore path, diagnostics,
-//                  BOBE_CHOL_LEGACY=1)
+//   k_potf2 / k_trsm_panel   the two halves of a panel as separate launches (restore path; batches or matrices whose
+//                  panel workgroups do not all fit on the chip at once)
 // Every kernel takes the slot of a batch from its last grid dimension and offsets its matrices by a slot stride.
 // Triangular inverse (needed by alpha, predictions and the gradient):
 //   k_trti_diag    all diagonal 128x128 blocks at once (one workgroup each)
 //   k_trtri_T/R    recursive doubling over 128-blocks, two GEMM launches per level
 //   k_lauum_grad   K^-1 = Linv^T Linv tile by tile, fused with the d+1 gradient reductions
 #pragma once
+#include "kernels_common.hpp"
 
 namespace bobe {
 
@@ -779,27 +780,10 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
 // k_syrk_trail - the same arithmetic per element as the separate update launch, only earlier and for free.
 // (Measured with stand-in MFMA workgroups first, profiles/r03_filler_standin.txt: up to ~8 MFLOP per filler workgroup the
 // factorisation takes exactly as long as without them; beyond that the launch lasts as long as its slowest filler.)
-// BOBE_FILLER_ITERS > 0 (timing experiments): the fillers run that many rounds of eight MFMAs instead.
-// A filler job.  K ranges are in units of 64 columns.
-//   kind 0  update tile:      A[ti][tj]    -= sum_k A[ti][k] A[tj][k]^T                      (k_syrk_trail's tile)
-//   kind 1  inverse, T stage: Tmp[ti][tj]  (+)= sum_k L[ti][k] Linv[k][tj]                    (k_trtri_T's tile)
-//   kind 2  inverse, R stage: Linv[ti][tj] (+)= sum_k Linv[ti][k] Tmp[k][tj], negated by the last chunk   (k_trtri_R's tile)
-//   kind 3  inverse of the diagonal 128-block ti (k_trti_diag's block; FILL_ASIDE: its L_kk is still in the scratch blocks)
-//   kind 4  nothing (the idle half of a pair)
-// A tile whose K range does not fit one visit is visited in several launches, the partial sum parked in its destination:
-// the accumulator chain is the one of a single pass (same bits).  The two jobs of a workgroup run the same number of
-// K-steps (workgroup-wide barriers): the plan pairs jobs of equal kind and length; FILL_TWIN completes an odd one (computed,
-// not stored).
-enum { FILL_TWIN = 1, FILL_FIRST = 2, FILL_NEGATE = 4, FILL_ASIDE = 8 };
-struct FillJob { int kind, ti, tj, k0, k1, flags, pad0, pad1; };
-#ifndef BOBE_FILL_BK
-#define BOBE_FILL_BK 32
-#endif
-constexpr int FILL_BK = BOBE_FILL_BK;
+// (FillJob: gp_types.hpp)
+constexpr int FILL_BK = 32;
 constexpr int FILL_SMEM_DOUBLES = gemm_smem_doubles_exact<KC, KC, 64, 64, FILL_BK>();   // per group; two groups fit the panel's 150 KB
-constexpr int FILL_INV_BK = 16;                                                          // (KC x RC images at BK = 32 would not)
 static_assert(2 * FILL_SMEM_DOUBLES * 8 <= POTF2_SMEM_BYTES, "update fillers exceed the panel's LDS");
-static_assert(2 * gemm_smem_doubles_exact<KC, RC, 64, 64, FILL_INV_BK>() <= 2 * FILL_SMEM_DOUBLES, "inverse fillers use the same slices");
 template <bool STAMP = false, bool FILL = false, int STRIPS = 4>
 __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
                                                               double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
@@ -807,61 +791,21 @@ __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict
                                                               double* __restrict__ diag, int64_t bsD,
                                                               unsigned long long* __restrict__ stamps = nullptr,
                                                               const FillJob* __restrict__ jobs = nullptr, int njobs = 0,
-                                                              int fill_iters = 0, double* __restrict__ fill_out = nullptr,
-                                                              int rows_below = 0, double* __restrict__ Tmp = nullptr,
-                                                              int64_t ldt = 0, int64_t bsT = 0) {
+                                                              int rows_below = 0) {
   if (FILL && (int)blockIdx.x >= npanel) {
-    if (fill_iters > 0) {
-      v4d acc[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-      const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-      for (int it = 0; it < fill_iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-      }
-      double sres = 0.0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) sres += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-      if (fill_out) fill_out[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * PANEL_THREADS + threadIdx.x] = sres;
-      return;
-    }
     extern __shared__ double S[];
     const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const int idx = 2 * ((int)blockIdx.x - npanel) + grp;
     if (idx >= njobs) return;                 // (never: the job lists have even length, a workgroup = one pair)
     const FillJob jb = jobs[idx];
-    if (jb.kind == 4) return;                 // (a wave that has ended is not waited for by the other group's barriers)
     double* As = A + blockIdx.y * bsA;
-    double* Ls = Linv + blockIdx.y * bsL;
-    if (jb.kind == 3) {                       // the first group's 256 threads; its partner is a kind-4 job
-      double* Ib = Ls + ((int64_t)jb.ti * TILE) * ldl + (int64_t)jb.ti * TILE;
-      if (jb.flags & FILL_ASIDE) block_load(S, diag + blockIdx.y * bsD + (int64_t)jb.ti * TILE * TILE, TILE);
-      else block_load(S, As + ((int64_t)jb.ti * TILE) * lda + (int64_t)jb.ti * TILE, lda);
-      __syncthreads();
-      trti_block(S, Ib, ldl);
-      return;
-    }
     const bool live = !(jb.flags & FILL_TWIN);
     const int64_t r0 = (int64_t)jb.ti * 64, c0 = (int64_t)jb.tj * 64;
     const int64_t kb = (int64_t)jb.k0 * 64, ke = (int64_t)jb.k1 * 64;
     v4d acc[2][2];
-    if (jb.kind == 0) {
-      load_tile<64, 64>(acc, As, lda, r0, c0, tid);
-      gemm_tile<KC, KC, 64, 64, FILL_BK, true>(acc, As, lda, r0, As, lda, c0, kb, ke, S + grp * FILL_SMEM_DOUBLES, tid);
-      if (live) store_tile<64, 64>(acc, As, lda, r0, c0, 1.0, 0.0, tid);
-      return;
-    }
-    double* Ts = Tmp + blockIdx.y * bsT;
-    double* dst = jb.kind == 1 ? Ts : Ls;
-    const int64_t ldd = jb.kind == 1 ? ldt : ldl;
-    if (jb.flags & FILL_FIRST) acc_zero(acc);
-    else load_tile<64, 64>(acc, dst, ldd, r0, c0, tid);
-    if (jb.kind == 1)
-      gemm_tile<KC, RC, 64, 64, FILL_INV_BK>(acc, As, lda, r0, Ls, ldl, c0, kb, ke, S + grp * FILL_SMEM_DOUBLES, tid);
-    else
-      gemm_tile<KC, RC, 64, 64, FILL_INV_BK>(acc, Ls, ldl, r0, Ts, ldt, c0, kb, ke, S + grp * FILL_SMEM_DOUBLES, tid);
-    if (live) store_tile<64, 64>(acc, dst, ldd, r0, c0, (jb.flags & FILL_NEGATE) ? -1.0 : 1.0, 0.0, tid);
+    load_tile<64, 64>(acc, As, lda, r0, c0, tid);
+    gemm_tile<KC, KC, 64, 64, FILL_BK, true>(acc, As, lda, r0, As, lda, c0, kb, ke, S + grp * FILL_SMEM_DOUBLES, tid);
+    if (live) store_tile<64, 64>(acc, As, lda, r0, c0, 1.0, 0.0, tid);
     return;
   }
   const int slot = blockIdx.y;
@@ -932,11 +876,7 @@ __global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ A, int6
 }
 
 // ---- recursive triangular inverse ------------------------------------------------------------------
-// problem {lo, mid, hi} in 128-block units: with inv[lo:mid) and inv[mid:hi) known,
-//   Tm = L[mid:hi, lo:mid) * inv[lo:mid)            (k_trtri_T, written to Tmp)
-//   inv[mid:hi, lo:mid) = -inv[mid:hi) * Tm          (k_trtri_R)
-// `off` counts T x T tiles: a problem owns (hi-mid)(mid-lo)(128/T)^2 consecutive blocks.
-struct TriProb { int lo, mid, hi, off; };
+// problems {lo, mid, hi}: TriProb in gp_types.hpp
 
 // Locate the problem of workgroup `bid`.  T = 128: one tile per workgroup.  T = 64: a workgroup owns the
 // two tiles e and nt-1-e of its problem's heavy-first enumeration, whose K lengths are complementary,
@@ -965,8 +905,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L
                                                     const double* __restrict__ Linv, int64_t ldi,
                                                     double* __restrict__ Tmp, int64_t ldt,
                                                     const TriProb* __restrict__ probs, int nprob, int64_t bsA = 0,
-                                                    int64_t bsL = 0, int64_t bsT = 0, int per = 0,
-                                                    const unsigned char* __restrict__ skip = nullptr) {
+                                                    int64_t bsL = 0, int64_t bsT = 0, int per = 0) {
   extern __shared__ double smem[];
   L += blockIdx.y * bsA;
   Linv += blockIdx.y * bsL;
@@ -983,8 +922,6 @@ __global__ __launch_bounds__(256, 2) void k_trtri_T(const double* __restrict__ L
     } else {
       tj = e[u] / rows, ti = e[u] % rows;                  // column-major: small tj (long K) first
     }
-    // (a tile that already ran as a filler of the factorisation's panel launches: skip[problem's tile offset + tj * rows + ti])
-    if (skip && skip[(int64_t)p.off * (TILE / T) * (TILE / T) + tj * rows + ti]) continue;
     const int64_t m0 = (int64_t)p.mid * TILE + (int64_t)ti * T, n0 = (int64_t)p.lo * TILE + (int64_t)tj * T;
     v4d acc[T / 32][T / 32];
     acc_zero(acc);
@@ -997,8 +934,7 @@ template <int T>
 __global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, int64_t ldi,
                                                     const double* __restrict__ Tmp, int64_t ldt,
                                                     const TriProb* __restrict__ probs, int nprob, int64_t bsL = 0,
-                                                    int64_t bsT = 0, int per = 0,
-                                                    const unsigned char* __restrict__ skip = nullptr) {
+                                                    int64_t bsT = 0, int per = 0) {
   extern __shared__ double smem[];
   Linv += blockIdx.y * bsL;
   Tmp += blockIdx.y * bsT;
@@ -1015,7 +951,6 @@ __global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, i
     } else {
       ti = rows - 1 - e[u] / w, tj = e[u] % w;             // bottom rows (long K) first
     }
-    if (skip && skip[(int64_t)p.off * (TILE / T) * (TILE / T) + tj * rows + ti]) continue;
     const int64_t m0 = (int64_t)p.mid * TILE + (int64_t)ti * T, n0 = (int64_t)p.lo * TILE + (int64_t)tj * T;
     v4d acc[T / 32][T / 32];
     acc_zero(acc);

@@ -1,172 +1,7 @@
-// HIP kernels of the BOBE GP hot path for gfx950.  See DESIGN.md for the data layout.
-//
-// Conventions
-//   * Np = N rounded up to 128.  The padded kernel matrix is [[K,0],[0,I]], so its Cholesky
-//     factor is [[L,0],[0,I]], its inverse factor [[L^-1,0],[0,I]], and padded y / alpha are 0.
-//     Kernels that evaluate k(x_a, x_b) mask padded points by index.
-//   * coordinates are stored SoA and pre-divided by the lengthscales: XsT[j*ld + i] = x_ij / ls_j
-//     (reference op order: dist_sq(xa/ls, xb/ls), BOBE/gp.py:149, 161).
+// Kernels of the acquisition sweep and of the posterior / score gradients (gfx950).  Included by gp_sweep.hip only.
 #pragma once
-#include "gemm_f64.hpp"
+#include "kernels_common.hpp"
 
-namespace bobe {
-
-constexpr int MAX_D = 32;
-constexpr double SQRT5 = 2.23606797749978969641;
-constexpr double NOISE_FLOOR = 1e-12;   // BOBE/gp.py:16
-
-struct Hyper {
-  double ls[MAX_D];
-  double kvar;
-  double noise;
-  int d;
-  int kern;  // 0 rbf, 1 matern-5/2
-};
-
-// ---- kernel functions (BOBE/gp.py:124-168) ---------------------------------------------
-template <int KERN>
-__device__ __forceinline__ double kern_eval(double r2, double kvar) {
-  if (KERN == 0) {
-    return kvar * exp(-0.5 * r2);
-  } else {
-    const double dd = sqrt(r2 < 1e-30 ? 1e-30 : r2);
-    const double e = exp(-SQRT5 * dd);
-    const double poly = 1.0 + dd * (SQRT5 + (dd * 5.0) / 3.0);
-    return kvar * poly * e;
-  }
-}
-
-// d k / d log ls_j = grad_factor * D_j, with D_j the squared scaled difference in dim j
-template <int KERN>
-__device__ __forceinline__ double kern_grad_factor(double r2, double kvar, double kval) {
-  if (KERN == 0) {
-    return kval;
-  } else {
-    if (r2 < 1e-30) return 0.0;
-    const double dd = sqrt(r2);
-    return kvar * (5.0 / 3.0) * (1.0 + SQRT5 * dd) * exp(-SQRT5 * dd);
-  }
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  union { double d; int i[2]; } u;
-  u.d = v;
-  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
-  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
-  return u.d;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// ---- coordinate scaling: out[j*ldo + i] = in[i*d + j] / ls[j]  (0 for i >= n) ------------
-// (hp, when given, overrides h with the device-resident hyper-parameters: a captured graph replays with new values)
-// Batched launches: blockIdx.y = slot picks hp[slot] and offsets `out` by bsO doubles per slot.
-__global__ void k_scale_coords(const double* __restrict__ in, int64_t n, int64_t npad, Hyper h,
-                               double* __restrict__ out, int64_t ldo, const Hyper* __restrict__ hp = nullptr,
-                               int64_t bsO = 0, int* __restrict__ info_reset = nullptr) {
-  if (hp) h = hp[blockIdx.y];
-  out += blockIdx.y * bsO;
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  // (first kernel of an evaluation: it also arms the factorisation's info word - one memset launch less)
-  if (info_reset && i == 0) info_reset[blockIdx.y] = 0x7f7f7f7f;
-  if (i >= npad) return;
-  // (constant indices into h.ls: a runtime index would send the by-value struct through scratch memory)
-#pragma unroll
-  for (int j = 0; j < MAX_D; ++j)
-    if (j < h.d) out[j * ldo + i] = (i < n) ? in[i * h.d + j] / h.ls[j] : 0.0;
-}
-
-// ---- kernel-matrix assembly ---------------------------------------------------------------
-// out[a*ldo + b] = k(A_a, B_b) for a < na, b < nb; padding is 0, or identity when SQUARE.
-// SQUARE: blockIdx.x enumerates lower tiles (ti >= tj) and noise is added on the diagonal.
-// else  : blockIdx.x = tile column, blockIdx.y = tile row.
-// A thread owns one column b of the 128x128 tile (its d scaled coordinates stay in registers) and walks 64
-// rows; a wave's lanes share the row, so the row's coordinates are wave-uniform and come through the scalar
-// cache.  No LDS: the kernel is bound by the exp / pairwise-distance arithmetic and the coalesced 8-byte stores
-// (512 B per wave per row).
-// FULL: d == DCAP exactly (no per-dimension predication at all).
-// wv / part (cross tiles only): the tile's share of out^T wv on the way, part[ti*ldp + column] = sum over the tile's 128 rows
-// of out[row][column] wv[row] - the posterior-mean product K(X, C)^T alpha without reading K(X, C) back.  The thread
-// halves own rows 0..63 / 64..127 and sum them in the order of k_gemv_t_part (four runs of 32 rows, then
-// ((r0 + r1) + r2) + r3): the same bits as that kernel on the stored tile.
-template <int KERN, bool SQUARE, int DCAP, bool FULL>
-__global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ AT, int64_t lda, int64_t na,
-                                                       const double* __restrict__ BT, int64_t ldb, int64_t nb,
-                                                       Hyper h, double* __restrict__ out, int64_t ldo,
-                                                       const Hyper* __restrict__ hp = nullptr, int64_t bsX = 0,
-                                                       int64_t bsO = 0, const double* __restrict__ wv = nullptr,
-                                                       double* __restrict__ part = nullptr, int64_t ldp = 0) {
-  if (hp) h = hp[SQUARE ? blockIdx.y : 0];
-  int ti, tj;
-  if (SQUARE) {
-    // batched assembly of K(X,X): blockIdx.y = slot (its own scaled coordinates, hyper-parameters and output)
-    AT += blockIdx.y * bsX;
-    BT += blockIdx.y * bsX;
-    out += blockIdx.y * bsO;
-    // four workgroups per lower tile (32 rows each): n(n+1)/2 tiles alone are barely two per CU at N = 4096
-    tri_decode(blockIdx.x >> 2, ti, tj);
-  } else {
-    ti = blockIdx.y;
-    tj = blockIdx.x;
-  }
-  const int t = threadIdx.x;
-  const int b = t & 127;
-  const int64_t gb = (int64_t)tj * TILE + b;
-  double xb[DCAP];
-#pragma unroll
-  for (int j = 0; j < DCAP; ++j) xb[j] = (FULL || j < h.d) ? BT[j * ldb + gb] : 0.0;
-  const int a0 = __builtin_amdgcn_readfirstlane(t >> 7);   // wave-uniform (a wave spans 64 consecutive columns)
-  const double* arow = AT + (int64_t)ti * TILE;
-  // SQUARE: the halves interleave over the workgroup's 32 rows; cross tiles: half a0 owns rows 64 a0 .. 64 a0 + 63
-  const int abeg = SQUARE ? (int)(blockIdx.x & 3) * (TILE / 4) + a0 : a0 * (TILE / 2);
-  const int aend = SQUARE ? abeg - a0 + TILE / 4 : abeg + TILE / 2;
-  const int astep = SQUARE ? 2 : 1;
-  double s = 0.0, s_first = 0.0;
-#pragma unroll 4
-  for (int a = abeg; a < aend; a += astep) {
-    const int64_t ga = (int64_t)ti * TILE + a;
-    double r2 = 0.0;
-    double xa[DCAP];   // unconditional (clamped) loads: all in flight at once, no branch per dimension
-#pragma unroll
-    for (int j = 0; j < DCAP; ++j) xa[j] = arow[(int64_t)((FULL || j < h.d) ? j : 0) * lda + a];
-#pragma unroll
-    for (int j = 0; j < DCAP; ++j) {
-      const double df = (FULL || j < h.d) ? xa[j] - xb[j] : 0.0;
-      r2 = __builtin_fma(df, df, r2);
-    }
-    double v;
-    if (ga < na && gb < nb) {
-      v = kern_eval<KERN>(r2, h.kvar);
-      if (SQUARE && ga == gb) v += h.noise;
-    } else {
-      v = (SQUARE && ga == gb) ? 1.0 : 0.0;
-    }
-    out[ga * ldo + gb] = v;
-    if (!SQUARE && wv) {
-      if (a == abeg + TILE / 4) {      // (wave-uniform) second run of 32 rows
-        s_first = s;
-        s = 0.0;
-      }
-      s = __builtin_fma(v, wv[ga], s);
-    }
-  }
-  if (!SQUARE && wv) {
-    __shared__ double red[2][TILE];
-    if (a0 == 1) {
-      red[0][b] = s_first;
-      red[1][b] = s;
-    }
-    __syncthreads();
-    if (a0 == 0) part[(int64_t)ti * ldp + gb] = ((s_first + s) + red[0][b]) + red[1][b];
-  }
-}
-
-}  // namespace bobe
-#include "chol_kernels.hpp"
 namespace bobe {
 
 // ---- the sweep's one big GEMM launch ------------------------------------------------------------
@@ -337,116 +172,6 @@ __global__ __launch_bounds__(256) void k_wip_score(const double* __restrict__ cr
   }
 }
 
-// ---- matrix-vector products ---------------------------------------------------------------------
-// w[i] = sum_{k <= i} M[i][k] y[k]   (one wave per row, fixed summation order)
-__global__ __launch_bounds__(256) void k_gemv_lower(const double* __restrict__ M, int64_t ld, int64_t np,
-                                                    const double* __restrict__ y, double* __restrict__ w,
-                                                    int64_t bsM = 0, int64_t bsW = 0, int64_t bsY = 0) {
-  M += blockIdx.y * bsM;      // batched: blockIdx.y = slot (y is shared by the slots unless bsY is given)
-  w += blockIdx.y * bsW;
-  y += blockIdx.y * bsY;
-  const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= np) return;
-  double s = 0.0;
-  for (int64_t k = lane; k <= i; k += 64) s += M[i * ld + k] * y[k];
-  s = wave_sum(s);
-  if (lane == 0) w[i] = s;
-}
-
-// part[rb*ldp + c] = sum_{k in row block rb (128 rows)} M[k][c] w[k], only row blocks rb >= rb_min(c)
-// where rb_min = (lower ? c/128 : 0).  grid.x = column strips of 64, grid.y = row blocks.
-__global__ __launch_bounds__(256) void k_gemv_t_part(const double* __restrict__ M, int64_t ld, int lower,
-                                                     const double* __restrict__ w, double* __restrict__ part,
-                                                     int64_t ldp, int64_t bsM = 0, int64_t bsW = 0, int64_t bsP = 0) {
-  M += blockIdx.z * bsM;      // batched: blockIdx.z = slot
-  w += blockIdx.z * bsW;
-  part += blockIdx.z * bsP;
-  __shared__ double red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
-  const int rb = blockIdx.y;
-  double s = 0.0;
-  if (!lower || rb >= (int)(blockIdx.x * 64 / TILE)) {
-    const int64_t k0 = (int64_t)rb * TILE + ry * 32;
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) s += M[(k0 + k) * ld + c] * w[k0 + k];
-  }
-  red[ry][cx] = s;
-  __syncthreads();
-  if (ry == 0) part[(int64_t)rb * ldp + c] = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
-}
-
-// out[c] = sum_{rb=rb0(c)}^{nrb-1} part[rb*ldp + c]   (fixed order)
-__global__ void k_colsum_parts(const double* __restrict__ part, int64_t ldp, int nrb, int lower, int64_t ncols,
-                               double* __restrict__ out, int64_t bsP = 0, int64_t bsO = 0) {
-  part += blockIdx.y * bsP;   // batched: blockIdx.y = slot
-  out += blockIdx.y * bsO;
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
-  double s = 0.0;
-  for (int rb = lower ? (int)(c / TILE) : 0; rb < nrb; ++rb) s += part[(int64_t)rb * ldp + c];
-  out[c] = s;
-}
-
-// ---- scalar reductions ------------------------------------------------------------------------------
-// res[0] = sum_i w_i^2 ; res[1] = sum_i log L_ii        (single workgroup, fixed order)
-__device__ __forceinline__ void mll_terms_body(int slot, const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
-                                                   int64_t np, double* __restrict__ res, int64_t bsW,
-                                                   int64_t bsL, int64_t bsR, const int* __restrict__ info) {
-  w += slot * bsW;      // batched: blockIdx.x = slot
-  L += slot * bsL;
-  res += slot * bsR;
-  // (the factorisation's info word rides along in res[100], so that one copy brings everything to the host)
-  if (info && threadIdx.x == 0) reinterpret_cast<int*>(res + 100)[0] = info[slot];
-  __shared__ double r0[4], r1[4];
-  double a = 0.0, b = 0.0;
-  for (int64_t i = threadIdx.x; i < np; i += 256) {
-    a += w[i] * w[i];
-    b += log(L[i * ld + i]);
-  }
-  a = wave_sum(a);
-  b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) {
-    r0[threadIdx.x >> 6] = a;
-    r1[threadIdx.x >> 6] = b;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    res[0] = ((r0[0] + r0[1]) + r0[2]) + r0[3];
-    res[1] = ((r1[0] + r1[1]) + r1[2]) + r1[3];
-  }
-}
-__global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
-                                                   int64_t np, double* __restrict__ res, int64_t bsW = 0,
-                                                   int64_t bsL = 0, int64_t bsR = 0,
-                                                   const int* __restrict__ info = nullptr) {
-  mll_terms_body((int)blockIdx.x, w, L, ld, np, res, bsW, bsL, bsR, info);      // batched: blockIdx.x = slot
-}
-
-// The two reductions that end an evaluation in ONE launch.  Workgroups 0..d: res[2 + j] = 0.5 * sum over the tiles of
-// partial[tile * stride + src(j)], one wave per component, lane-strided partial sums combined by a fixed butterfly
-// (deterministic).  Workgroup d+1 is k_mll_terms.  blockIdx.y = slot of a lock-step batch (strides in doubles).
-__global__ __launch_bounds__(256) void k_mll_grad_reduce(const double* __restrict__ partial, int ntiles, int stride, int d,
-                                                         int dcap, double* __restrict__ res,
-                                                         const double* __restrict__ w, const double* __restrict__ L,
-                                                         int64_t ld, int64_t np, const int* __restrict__ info,
-                                                         int64_t bsP = 0, int64_t bsR = 0, int64_t bsW = 0, int64_t bsL = 0) {
-  const int slot = blockIdx.y;
-  if ((int)blockIdx.x == d + 1) {
-    mll_terms_body(slot, w, L, ld, np, res, bsW, bsL, bsR, info);
-    return;
-  }
-  if (threadIdx.x >= 64) return;
-  partial += slot * bsP;
-  res += slot * bsR;
-  const int j = blockIdx.x;
-  const int src = (j == d) ? dcap : j;
-  double s = 0.0;
-  for (int q = threadIdx.x; q < ntiles; q += 64) s += partial[(int64_t)q * stride + src];
-  s = wave_sum(s);
-  if (threadIdx.x == 0) res[2 + j] = 0.5 * s;
-}
 
 // ---- sweep finalisers -------------------------------------------------------------------------------
 // q = sum of row-tile partials; s = kself - q.  var policy: 0 -> clip(s, floor) keeps NaN (gp.py:465),
@@ -516,31 +241,6 @@ __global__ __launch_bounds__(1024) void k_argmin(const double* __restrict__ v, i
   }
 }
 
-// ---- misc ------------------------------------------------------------------------------------------
-__global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
-// dst[i*ldd + j] = (lower_only && j > i) ? 0 : src[i*lds + j]  for i < rows, j < cols
-__global__ void k_copy2d(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd, int64_t rows,
-                         int64_t cols, int lower_only) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i = blockIdx.y;
-  if (i < rows && j < cols) dst[i * ldd + j] = (lower_only && j > i) ? 0.0 : src[i * lds + j];
-}
-
-// pad-aware load of a caller-provided N x N lower factor into the padded [[L,0],[0,I]] layout
-__global__ void k_load_padded_lower(const double* __restrict__ src, int64_t n, double* __restrict__ dst, int64_t ld,
-                                    int64_t np) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i = blockIdx.y;
-  if (i >= np || j >= np) return;
-  double v;
-  if (i < n && j < n) v = (j <= i) ? src[i * n + j] : 0.0;
-  else v = (i == j) ? 1.0 : 0.0;
-  dst[i * ld + j] = v;
-}
 
 // ---- rank-b append (bobe_gp_append; the reference's fast_update_cholesky, gp.py:181-197, b rows at a time) ------
 // G[i*b + j] = sum_{k < n} V[k*ldv + i] * V[k*ldv + j]   (b <= 64; one workgroup per (i, j), fixed summation order)
@@ -584,24 +284,7 @@ __global__ void k_append_rows(double* __restrict__ L, double* __restrict__ Linv,
   }
 }
 
-// EI / LogEI pointwise scorers (BOBE/acquisition.py:21-75, 226-253, 318-330); mu, var standardised
-__device__ __forceinline__ double norm_pdf(double u) { return exp(-0.5 * u * u) * 0.39894228040143267794; }
-__device__ __forceinline__ double norm_cdf(double u) { return 0.5 * erfc(-u * 0.70710678118654752440); }
-__device__ __forceinline__ double ei_helper(double u) { return norm_pdf(u) + u * norm_cdf(u); }
-__device__ __forceinline__ double log1mexp_tfp(double x) {
-  x = fabs(x);
-  return (x < 0.69314718055994530942) ? log(-expm1(-x)) : log1p(-exp(-x));
-}
-__device__ __forceinline__ double log_ei_helper(double u) {
-  const double bound = -1.0, neg_inv_sqrt_eps = -1e6;
-  if (u > bound) return log(ei_helper(u));
-  const double u_lower = u;
-  const double u_eps = (u_lower < neg_inv_sqrt_eps) ? neg_inv_sqrt_eps : u_lower;
-  const double w = log(fabs(u_eps) * erfcx(-0.70710678118654752440 * u_eps)) + 0.22579135264472743236;
-  const double log_phi_u = -0.5 * (u * u + 1.83787706640934548356);
-  const double second = (u > neg_inv_sqrt_eps) ? log1mexp_tfp(w) : -2.0 * log(fabs(u_lower));
-  return log_phi_u + second;
-}
+
 // ---- input gradients of the posterior mean and variance (for gradient-based consumers) ---------------
 // dmean[c][j] = sum_n alpha_n dk(x_n, x_c)/dx_cj ;  dvar[c][j] = -2 sum_n u_nc dk(x_n, x_c)/dx_cj, u = K^-1 k_c
 // with dk/dx_cj = G(r2) (s_nj - s_cj) / ls_j  (s = x / ls; G = k for RBF, the Matern-5/2 factor otherwise).
@@ -685,314 +368,6 @@ __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__
   }
 }
 
-// ---- Hamiltonian Monte Carlo on the surrogate: L leapfrog steps of every chain in ONE launch ---------------------
-// Consumer of the posterior mean (the reference's NUTS differentiates predict_mean_batched through JAX, one call per
-// step and chain, samplers.py:268-288).  One workgroup = one chain.  Target on u = logit(x), x in the unit cube:
-//   logp(u) = (mean(x) * ystd + ymean) / temp + sum_j [log x_j + log(1 - x_j)]          (Jacobian of the logit map)
-//   g(u)    = dmean/dx * ystd / temp * x (1 - x) + (1 - 2x)
-// with mean(x) = sum_n alpha_n k(x_n, x), dmean/dx_j = sum_n alpha_n G(r2) (s_nj - s_j) / ls_j (k_predict_grad's
-// mean-only arithmetic).  In:  U, Pm = p0 + eps/2 * g(U)  (P x d).  Per step: u += eps * inv_mass * p; evaluate;
-// p += (eps | eps/2 on the last step) * g.  Out: U, Pm (final), logp, grad, mean (physical units), X.
-// Fixed reduction order (4 waves x lanes, then a fixed tree): a chain's trajectory does not depend on the batch.
-template <int KERN, int DCAP>
-__global__ __launch_bounds__(256) void k_hmc_leapfrog(const double* __restrict__ XsT, int64_t ldx, int64_t n,
-                                                      const double* __restrict__ alpha, Hyper h,
-                                                      double* __restrict__ U, double* __restrict__ Pm,
-                                                      const double* __restrict__ inv_mass, double eps, int L,
-                                                      double ystd, double ymean, double temp,
-                                                      double* __restrict__ logp, double* __restrict__ grad,
-                                                      double* __restrict__ mean_out, double* __restrict__ Xout) {
-  __shared__ double u[DCAP], pm[DCAP], x[DCAP], xs[DCAP], g[DCAP], red[4][DCAP + 1], lp_s, mean_s;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t c = blockIdx.x;
-  const int d = h.d;
-  if (t < d) {
-    u[t] = U[c * d + t];
-    pm[t] = Pm[c * d + t];
-  }
-  __syncthreads();
-  for (int s = 0; s < L; ++s) {
-    if (t < d) {
-      const double un = u[t] + eps * inv_mass[t] * pm[t];
-      u[t] = un;
-      double xv = 1.0 / (1.0 + exp(-un));
-      xv = xv < 1e-12 ? 1e-12 : (xv > 1.0 - 1e-12 ? 1.0 - 1e-12 : xv);
-      x[t] = xv;
-      xs[t] = xv / h.ls[t];
-    }
-    __syncthreads();
-    double ms = 0.0, gm[DCAP];
-#pragma unroll
-    for (int j = 0; j < DCAP; ++j) gm[j] = 0.0;
-    for (int64_t i = t; i < n; i += 256) {
-      double df[DCAP];
-      double r2 = 0.0;
-#pragma unroll
-      for (int j = 0; j < DCAP; ++j) {
-        df[j] = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
-        r2 += df[j] * df[j];
-      }
-      const double kv = kern_eval<KERN>(r2, h.kvar);
-      const double a = alpha[i];
-      const double ag = a * kern_grad_factor<KERN>(r2, h.kvar, kv);
-      ms += a * kv;
-#pragma unroll
-      for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
-    }
-    ms = wave_sum(ms);
-    if (lane == 0) red[wave][DCAP] = ms;
-#pragma unroll
-    for (int j = 0; j < DCAP; ++j) {
-      if (j < d) {
-        const double v = wave_sum(gm[j]);
-        if (lane == 0) red[wave][j] = v;
-      }
-    }
-    __syncthreads();
-    if (t < d) {
-      const double dm = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) / h.ls[t];
-      const double xv = x[t];
-      const double gv = dm * ystd / temp * (xv * (1.0 - xv)) + (1.0 - 2.0 * xv);
-      g[t] = gv;
-      pm[t] += ((s < L - 1) ? eps : 0.5 * eps) * gv;
-    }
-    if (t == 0) {
-      const double m = (((red[0][DCAP] + red[1][DCAP]) + red[2][DCAP]) + red[3][DCAP]) * ystd + ymean;
-      double jac = 0.0;
-      for (int j = 0; j < d; ++j) jac += log(x[j]) + log1p(-x[j]);
-      mean_s = m;
-      lp_s = m / temp + jac;
-    }
-    __syncthreads();
-  }
-  if (t < d) {
-    U[c * d + t] = u[t];
-    Pm[c * d + t] = pm[t];
-    grad[c * d + t] = g[t];
-    Xout[c * d + t] = x[t];
-  }
-  if (t == 0) {
-    logp[c] = lp_s;
-    mean_out[c] = mean_s;
-  }
-}
-
-// ---- whole HMC chains on the device ---------------------------------------------------------------------------
-// `niter` trajectories of every chain in ONE launch (one workgroup = one chain): momentum draw, 4-12 leapfrog steps (the
-// arithmetic of k_hmc_leapfrog), Metropolis test, and - while warming up - the chain's own dual-averaging step-size
-// update (Hoffman & Gelman 2014, what NumPyro's warm-up does per chain).  The host only cuts the run at the
-// mass-matrix windows.  Random numbers are a counter hash (splitmix64 finaliser) of (seed, chain, iteration, index):
-// a chain's path depends on nothing but its own seed, whatever the batch or the launch boundaries.
-//   S     [P][3d+2]  chain state in/out: u (d), g = dlogp/du (d), x (d), logp, mean (physical units)
-//   adapt [P][5]     eps, mu, hbar, log_eps_bar, m (dual averaging; only eps is read when do_adapt == 0)
-//   hist  [niter - hist_from][P][d]   u after iterations >= hist_from of this launch        (may be null)
-//   keep  [niter / thin][P][d+1]      x and mean after every thin-th iteration of this launch (may be null)
-//   dbg   [P][d+3]   last iteration's p0 (d), L, uniform, acceptance probability             (may be null)
-__device__ __forceinline__ unsigned long long hmc_mix64(unsigned long long z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ double hmc_u01(unsigned long long bits) {          // in (0, 1)
-  return ((double)(bits >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-}
-
-template <int KERN, int DCAP>
-__global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT, int64_t ldx, int64_t n,
-                                                 const double* __restrict__ alpha, Hyper h, int64_t P,
-                                                 double* __restrict__ S, double* __restrict__ adapt,
-                                                 const double* __restrict__ inv_mass, unsigned long long seed,
-                                                 int64_t it0, int niter, int do_adapt, double ystd, double ymean,
-                                                 double temp, int hist_from, double* __restrict__ hist, int thin,
-                                                 double* __restrict__ keep, double* __restrict__ dbg) {
-  __shared__ double u[DCAP], pm[DCAP], x[DCAP], xs[DCAP], g[DCAP], red[4][DCAP + 1], lp_s, mean_s;
-  __shared__ double u0[DCAP], g0[DCAP], x0[DCAP], p0[DCAP], im[DCAP], lp0, mean0, eps_s;
-  __shared__ int L_s, acc_s;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t c = blockIdx.x;
-  const int d = h.d, sw = 3 * d + 2;
-  double* Sc = S + c * sw;
-  double* ad = adapt + c * 5;
-  if (t < d) {
-    u0[t] = Sc[t];
-    g0[t] = Sc[d + t];
-    x0[t] = Sc[2 * d + t];
-    im[t] = inv_mass[t];
-  }
-  if (t == 0) {
-    lp0 = Sc[3 * d];
-    mean0 = Sc[3 * d + 1];
-    eps_s = ad[0];
-  }
-  const unsigned long long ckey = hmc_mix64(seed ^ hmc_mix64((unsigned long long)c));
-  // Up to RMAX training points per thread are loaded ONCE per launch (a launch is hundreds of leapfrog steps, each of
-  // which would otherwise wait for the same global loads again); points past n carry alpha = 0.
-  constexpr int RMAX = 64 / DCAP;
-  const bool cached = n <= (int64_t)256 * RMAX;
-  const int nrow = (int)((n + 255) / 256);
-  double cx[RMAX][DCAP], ca[RMAX];
-  if (cached) {
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      const int64_t i = t + 256 * r;
-      ca[r] = (i < n) ? alpha[i] : 0.0;
-#pragma unroll
-      for (int j = 0; j < DCAP; ++j) cx[r][j] = (j < d && i < n) ? XsT[j * ldx + i] : 0.0;
-    }
-  }
-  __syncthreads();
-  for (int it = 0; it < niter; ++it) {
-    const unsigned long long ikey = ckey + ((unsigned long long)(it0 + it) << 12);
-    const double eps = eps_s;
-    if (t < d) {                                               // momentum ~ N(0, M), M = diag(1 / inv_mass)
-      const double a = hmc_u01(hmc_mix64(ikey + 2 * t)), b = hmc_u01(hmc_mix64(ikey + 2 * t + 1));
-      const double z = sqrt(-2.0 * log(a)) * cos(6.283185307179586 * b);
-      const double pv = z / sqrt(im[t]);
-      p0[t] = pv;
-      pm[t] = pv + 0.5 * eps * g0[t];
-      u[t] = u0[t];
-    }
-    if (t == 0) L_s = 4 + (int)(hmc_mix64(ikey + 4000) % 9ull);
-    __syncthreads();
-    const int L = L_s;
-    for (int s = 0; s < L; ++s) {
-      if (t < d) {
-        const double un = u[t] + eps * im[t] * pm[t];
-        u[t] = un;
-        double xv = 1.0 / (1.0 + exp(-un));
-        xv = xv < 1e-12 ? 1e-12 : (xv > 1.0 - 1e-12 ? 1.0 - 1e-12 : xv);
-        x[t] = xv;
-        xs[t] = xv / h.ls[t];
-      }
-      __syncthreads();
-      double ms = 0.0, gm[DCAP];
-#pragma unroll
-      for (int j = 0; j < DCAP; ++j) gm[j] = 0.0;
-      if (cached) {                                            // this thread's training points stay in registers
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          if (r < nrow) {                                      // uniform
-            double df[DCAP];
-            double r2 = 0.0;
-#pragma unroll
-            for (int j = 0; j < DCAP; ++j) {
-              df[j] = (j < d) ? cx[r][j] - xs[j] : 0.0;
-              r2 += df[j] * df[j];
-            }
-            const double kv = kern_eval<KERN>(r2, h.kvar);
-            const double ag = ca[r] * kern_grad_factor<KERN>(r2, h.kvar, kv);
-            ms += ca[r] * kv;
-#pragma unroll
-            for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
-          }
-        }
-      } else {
-        for (int64_t i = t; i < n; i += 256) {
-          double df[DCAP];
-          double r2 = 0.0;
-#pragma unroll
-          for (int j = 0; j < DCAP; ++j) {
-            df[j] = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
-            r2 += df[j] * df[j];
-          }
-          const double kv = kern_eval<KERN>(r2, h.kvar);
-          const double a = alpha[i];
-          const double ag = a * kern_grad_factor<KERN>(r2, h.kvar, kv);
-          ms += a * kv;
-#pragma unroll
-          for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
-        }
-      }
-      ms = wave_sum(ms);
-      if (lane == 0) red[wave][DCAP] = ms;
-#pragma unroll
-      for (int j = 0; j < DCAP; ++j) {
-        if (j < d) {
-          const double v = wave_sum(gm[j]);
-          if (lane == 0) red[wave][j] = v;
-        }
-      }
-      __syncthreads();
-      if (t < d) {
-        const double dm = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) / h.ls[t];
-        const double xv = x[t];
-        const double gv = dm * ystd / temp * (xv * (1.0 - xv)) + (1.0 - 2.0 * xv);
-        g[t] = gv;
-        pm[t] += ((s < L - 1) ? eps : 0.5 * eps) * gv;
-      }
-      if (wave == 1) {                                         // (wave 0 is busy with the gradient lanes)
-        double jl = (lane < d) ? log(x[lane]) + log1p(-x[lane]) : 0.0;
-        jl = wave_sum(jl);
-        if (lane == 0) {
-          const double m = (((red[0][DCAP] + red[1][DCAP]) + red[2][DCAP]) + red[3][DCAP]) * ystd + ymean;
-          mean_s = m;
-          lp_s = m / temp + jl;
-        }
-      }
-      __syncthreads();
-    }
-    if (t == 0) {                                              // Metropolis test and the chain's step-size update
-      double k0 = 0.0, k1 = 0.0;
-      for (int j = 0; j < d; ++j) {
-        k0 += p0[j] * p0[j] * im[j];
-        k1 += pm[j] * pm[j] * im[j];
-      }
-      const double h0 = lp0 - 0.5 * k0, h1 = lp_s - 0.5 * k1;
-      double ap = 0.0;
-      if (isfinite(h1)) ap = h1 >= h0 ? 1.0 : exp(h1 - h0);
-      const double r = hmc_u01(hmc_mix64(ikey + 4001));
-      const int acc = r < ap;
-      acc_s = acc;
-      if (acc) {
-        lp0 = lp_s;
-        mean0 = mean_s;
-      }
-      if (do_adapt) {
-        constexpr double t0 = 10.0, gamma = 0.05, kappa = 0.75, target = 0.8;
-        const double m = ad[4] + 1.0;
-        const double hbar = (1.0 - 1.0 / (m + t0)) * ad[2] + (target - ap) / (m + t0);
-        const double le = ad[1] - sqrt(m) / gamma * hbar;
-        const double eta = pow(m, -kappa);
-        ad[2] = hbar;
-        ad[3] = eta * le + (1.0 - eta) * ad[3];
-        ad[4] = m;
-        double e = exp(le);
-        e = e < 1e-4 ? 1e-4 : (e > 2.0 ? 2.0 : e);
-        ad[0] = e;
-        eps_s = e;
-      }
-      if (dbg && it == niter - 1) {
-        double* dc = dbg + c * (d + 3);
-        for (int j = 0; j < d; ++j) dc[j] = p0[j];
-        dc[d] = (double)L;
-        dc[d + 1] = r;
-        dc[d + 2] = ap;
-      }
-    }
-    __syncthreads();
-    if (t < d) {
-      if (acc_s) {
-        u0[t] = u[t];
-        g0[t] = g[t];
-        x0[t] = x[t];
-      }
-      if (hist && it >= hist_from) hist[((int64_t)(it - hist_from) * P + c) * d + t] = u0[t];
-      if (keep && (it + 1) % thin == 0) keep[((int64_t)((it + 1) / thin - 1) * P + c) * (d + 1) + t] = x0[t];
-    }
-    if (t == 0 && keep && (it + 1) % thin == 0) keep[((int64_t)((it + 1) / thin - 1) * P + c) * (d + 1) + d] = mean0;
-    __syncthreads();
-  }
-  if (t < d) {
-    Sc[t] = u0[t];
-    Sc[d + t] = g0[t];
-    Sc[2 * d + t] = x0[t];
-  }
-  if (t == 0) {
-    Sc[3 * d] = lp0;
-    Sc[3 * d + 1] = mean0;
-  }
-}
 
 // ---- WIPV / WIPStd and their gradients w.r.t. the candidate coordinates ---------------------------------------
 // (what the reference gets from jax.grad of WIPV.fun / WIPStd.fun in the local refinement, acquisition.py:403-412)
@@ -1381,17 +756,5 @@ __global__ __launch_bounds__(64) void k_wg_final(const double* __restrict__ part
   if (dwipstd) dwipstd[c * h.d + j] = ((dsd - qs) / h.ls[j] + b2 * dsj) * inv_m;
 }
 
-// mode 0: EI, 1: LogEI.  out = +EI / +logEI (the reference minimises the negative)
-__global__ void k_ei(const double* __restrict__ mu, const double* __restrict__ var, int64_t n, double best_y, double zeta,
-                     int mode, double* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double v = var[i];
-  const double lo = mode ? 1e-18 : 1e-20;
-  if (v < lo) v = lo;
-  const double sigma = sqrt(v);
-  const double u = (mu[i] - zeta - best_y) / sigma;
-  out[i] = mode ? (log_ei_helper(u) + log(sigma)) : (ei_helper(u) * sigma);
-}
 
 }  // namespace bobe

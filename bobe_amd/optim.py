@@ -50,9 +50,12 @@ class _LockStep:
             out = self.batch_fun(xs)
             for i, r in zip(ids, out):
                 self.results[i] = r
-        except Exception as e:          # delivered to every waiting minimisation
-            for i in ids:
-                self.results[i] = e
+        except Exception:               # narrowed down point by point: only the minimisation whose point raises gets it
+            for i, x in zip(ids, xs):
+                try:
+                    self.results[i] = self.batch_fun([x])[0]
+                except Exception as e:
+                    self.results[i] = e
         self.cv.notify_all()
 
     def call(self, wid: int, x):
@@ -202,19 +205,43 @@ class _RcRun:
 
 
 def _rc_minimize_all(batch_fun: Callable, starts, bounds, options) -> List:
+    """Every restart stepped by this thread; returns an OptimizeResult - or the exception that ended it - per restart.
+    An exception out of ``batch_fun`` is narrowed down by evaluating that round's points one by one: only the restart
+    whose point raises ends with it (what ``_LockStep`` / one ``minimize`` per thread would do), the others go on."""
     from scipy.optimize import _lbfgsb
     runs = [_RcRun(_lbfgsb, x0, bounds, **options) for x0 in starts]
+    failed: dict = {}
     waiting = [i for i, r in enumerate(runs) if r.advance()]
     while waiting:
         # (ScalarFunction hands the objective a copy of x and stores float(f): the values the routine sees are the same)
-        vals = batch_fun([np.array(runs[i].x) for i in waiting])
+        pts = [np.array(runs[i].x) for i in waiting]
+        try:
+            vals = batch_fun(pts)
+        except Exception:
+            vals = []
+            for x in pts:
+                try:
+                    vals.append(batch_fun([x])[0])
+                except Exception as e:
+                    vals.append(e)
         nxt = []
-        for i, (f, g) in zip(waiting, vals):
+        for i, v in zip(waiting, vals):
+            if isinstance(v, Exception):
+                failed[i] = v
+                continue
+            f, g = v
             runs[i].give(float(f), g)
             if runs[i].advance():
                 nxt.append(i)
         waiting = nxt
-    return [r.result() for r in runs]
+    return [failed[i] if i in failed else r.result() for i, r in enumerate(runs)]
+
+
+def lbfgs_driver() -> str:
+    """Which driver ``optimize_scipy`` uses for concurrent L-BFGS-B restarts with a batch objective: "stepped" (SciPy's
+    reverse-communication routine stepped by one thread, ``_rc_minimize_all``) or "threads" (one ``minimize`` per
+    restart in lock step, ``_LockStep``)."""
+    return "stepped" if _rc_available() else "threads"
 
 
 def _rc_available() -> bool:
@@ -226,6 +253,9 @@ def _rc_available() -> bool:
     try:
         import scipy
         if tuple(int(v) for v in scipy.__version__.split(".")[:2]) != (1, 15):
+            log.warning(f"SciPy {scipy.__version__}: the stepped L-BFGS-B driver was written against the private routine of "
+                        "SciPy 1.15 and is switched off; concurrent restarts run one `minimize` per thread (same results, "
+                        "slower at BO-loop sizes)")
             return False
         A = np.array([[3.0, 0.4, 0.1], [0.4, 2.0, -0.3], [0.1, -0.3, 1.5]])
         b = np.array([1.0, -2.0, 0.5])
@@ -240,10 +270,13 @@ def _rc_available() -> bool:
             ref = minimize(vg, x0, jac=True, method="L-BFGS-B", bounds=bounds, options=dict(opts))
             if not (np.array_equal(r.x, ref.x) and r.fun == ref.fun and r.nit == ref.nit and r.nfev == ref.nfev and
                     r.message == ref.message and bool(r.success) == bool(ref.success)):
+                log.warning("the stepped L-BFGS-B driver does not reproduce scipy.optimize.minimize on this SciPy build; "
+                            "concurrent restarts run one `minimize` per thread")
                 return False
         _RC_STATE["ok"] = True
+        log.info(f"concurrent L-BFGS-B restarts: stepped driver (SciPy {scipy.__version__}, verified against minimize)")
     except Exception as e:  # pragma: no cover
-        log.debug(f"stepped L-BFGS-B driver unavailable ({e}); the thread driver is used")
+        log.warning(f"stepped L-BFGS-B driver unavailable ({e}); concurrent restarts run one `minimize` per thread")
     return _RC_STATE["ok"]
 
 

@@ -186,10 +186,14 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
         dead_x.append(live[worst].copy())
         dead_logl.append(lstar)
         it += 1
-        # replacement with L > L*: pop pre-scored proposals, refill the pool in GPU batches
+        # replacement with L > L*: pop pre-scored proposals, refill the pool in GPU batches.  Two ways out without one:
+        # the call budget (``maxcall``) - handled like the check at the top of the loop, a TRUNCATED run, reported the way
+        # dynesty's would be - and 200 fruitless refills (a plateau / degenerate surrogate): the run is unsuccessful.
+        # Either way the pool just generated is scanned before giving up.
         found = False
         tries = 0
-        while not found and not gave_up:
+        out_of_calls = False
+        while not found:
             while pool_pos < len(pool_l):
                 if pool_l[pool_pos] > lstar:
                     live[worst] = pool_x[pool_pos]
@@ -198,7 +202,7 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
                     found = True
                     break
                 pool_pos += 1
-            if found:
+            if found or gave_up or out_of_calls:
                 break
             if use_rwalk:
                 pool_x, pool_l, calls, rate = _rwalk_pool(loglike, live, live_logl, worst, lstar, rng,
@@ -208,22 +212,21 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
                 ncall += calls
                 # keep the acceptance rate of a step near one half (dynesty adapts its scale the same way)
                 rw_scale = float(np.clip(rw_scale * math.exp((rate - 0.5) / max(ndim, 1) * 4.0), 1e-4, 4.0))
-                tries += 1
-                gave_up = tries > 200 or ncall >= maxcall
-                continue
-            if since_update >= update_every or tries > 0 or len(pool_l) == 0:
-                mask = np.ones(nlive, dtype=bool)
-                mask[worst] = False
-                mu, A = _bounding_ellipsoid(live[mask], enlarge)
-                since_update = 0
-            x = _draw_in_ellipsoid(mu, A, batch, rng)
-            if len(x) == 0:
-                x = rng.uniform(size=(batch, ndim))
-            pool_x, pool_l, pool_pos = x, loglike(x), 0
-            ncall += len(x)
+            else:
+                if since_update >= update_every or tries > 0 or len(pool_l) == 0:
+                    mask = np.ones(nlive, dtype=bool)
+                    mask[worst] = False
+                    mu, A = _bounding_ellipsoid(live[mask], enlarge)
+                    since_update = 0
+                x = _draw_in_ellipsoid(mu, A, batch, rng)
+                if len(x) == 0:
+                    x = rng.uniform(size=(batch, ndim))
+                pool_x, pool_l, pool_pos = x, loglike(x), 0
+                ncall += len(x)
             tries += 1
             gave_up = tries > 200                             # plateau / degenerate surrogate
-        if gave_up and not found:
+            out_of_calls = ncall >= maxcall                   # (the refreshed pool is still scanned once)
+        if not found:
             # No replacement: the point just retired is still a live point.  Take the retirement back (it is counted once,
             # among the final live points) and end the run as TRUNCATED - its evidence is not a converged one.
             dead_x.pop()
@@ -231,7 +234,7 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
             it -= 1
             logz = logz_before
             truncated = True
-            if tries > 200:
+            if gave_up:
                 log.warning("nested sampling: no acceptable replacement found; stopping early (run marked unsuccessful)")
             break
         since_update += 1
@@ -303,7 +306,9 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     as ONE batch of ``16 * num_chains`` chains that live on the device: a warm-up window or the whole sampling phase
     (momentum draws, 4-12 leapfrog steps per trajectory, Metropolis tests, per-chain step-size adaptation) is a single
     ``bobe_gp_hmc_run`` launch; ``device_chains=False`` steps trajectory by trajectory from the host
-    (``bobe_gp_hmc_leapfrog``), and a classifier-gated GP calls ``bobe_gp_predict_grad`` once per leapfrog step.  Same stationary distribution; the per-chain length shrinks by the same factor so the number of returned
+    (``bobe_gp_hmc_leapfrog``), ``fused_trajectories=False`` calls ``bobe_gp_predict_grad`` once per leapfrog step.  A
+    classifier-gated GP takes the same paths: its gate lives in the library (``bobe_gp_set_gate``) and is applied inside
+    the kernels.  Same stationary distribution; the per-chain length shrinks by the same factor so the number of returned
     samples is the reference's.  The cube constraint is handled like NumPyro does it, by sampling u = logit(x) with
     the Jacobian term; step size by dual averaging to 0.8 acceptance and a diagonal mass matrix from the warm-up
     spread of the chains.  Chains start at the best training point and at ``gp.get_random_point`` draws
@@ -319,9 +324,9 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     keep_per_chain = -(-n_keep_total // P)
     base_gp_grad = getattr(gp, "predict_grad")
     gated = hasattr(gp, "use_clf")
-    # a plain GP runs its trajectories on the device (bobe_gp_hmc_leapfrog); the classifier's gate is host code
-    # (scikit-learn), so a gated GP keeps one surrogate call per leapfrog step
-    fused = (not gated) and hasattr(gp, "hmc_leapfrog") and kwargs.get("fused_trajectories", True)
+    # trajectories run on the device (bobe_gp_hmc_leapfrog / bobe_gp_hmc_run), gated or not: the library applies the
+    # classifier's gate inside the kernels
+    fused = hasattr(gp, "hmc_leapfrog") and kwargs.get("fused_trajectories", True)
     on_device = fused and hasattr(gp, "hmc_run") and kwargs.get("device_chains", True)
 
     def logp_and_grad(U):
@@ -329,9 +334,8 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
         m, _, dm, _ = base_gp_grad(X, mean_only=True)
         mean = m * gp.y_std + gp.y_mean
         gx = dm * gp.y_std
-        if gated:                                              # classifier gate (clf_gp.py:173-205)
-            gm = np.asarray(gp.predict_mean_batched(X), dtype=np.float64)
-            bad = gm <= gp.minus_inf
+        if gated:                                              # classifier gate (clf_gp.py:173-205): the library has
+            bad = m <= gp.minus_inf                            # set the mean to minus_inf and zeroed its gradient
             mean = np.where(bad, gp.minus_inf, mean)
             gx = np.where(bad[:, None], 0.0, gx)
         jac = np.sum(np.log(X) + np.log1p(-X), axis=1)

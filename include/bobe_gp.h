@@ -167,6 +167,27 @@ int bobe_gp_hmc_run(bobe_gp_t* g, int64_t P, double* state, double* adapt, const
                     int64_t it0, int niter, int do_adapt, double y_std, double y_mean, double temp, int hist_from,
                     double* hist, int thin, double* keep, double* dbg);
 
+/* GPwithClassifier's gate (clf_gp.py:173-205) with the SVM-RBF decision function of clf.py:188-213, evaluated on the
+ * device by direct differences, as the reference computes it:
+ *   decision(x) = sum_i dual_coef[i] exp(-gamma |support_vectors[i] - x|^2) + intercept      (svm_predict)
+ *   proba(x)    = decision >= 0 ? 1 : 0                                                      (svm_predict_proba)
+ *   feasible(x) = proba >= probability_threshold                                             (clf_gp.py:179)
+ * support_vectors: n_sv x d (unit-cube coordinates), dual_coef: n_sv; scikit-learn's SVC supplies them (clf.py:36-69);
+ * support_vectors == NULL or n_sv == 0 clears the gate.  While a gate is set, an infeasible query point comes back as
+ *   bobe_gp_predict / bobe_gp_predict_grad   mean = -INFINITY (the mark for the wrapper, which returns minus_inf in the
+ *                                            units of the method at hand: clf_gp.py:179 physical, :203 standardised),
+ *                                            var = 1e-12 (clf_gp.py:189, 204), dmean = dvar = 0
+ *   bobe_gp_acq_ei                           EI / LogEI of (mean = minus_inf, var = 1e-12), i.e. what EI.fun computes from
+ *                                            the gated predict_single (acquisition.py:246, 323)
+ *   bobe_gp_hmc_leapfrog / bobe_gp_hmc_run   mean = minus_inf (physical units), no mean gradient: never accepted
+ * bobe_gp_wip_sweep, bobe_gp_fantasy_var and bobe_gp_wip_grad are NOT gated (fantasy_var is not, clf_gp.py:207-212).
+ * One summation order serves every entry point (256 lane-strided partial sums, a fixed tree), so a point near the
+ * boundary falls on the same side everywhere.  The gate is not part of the state bobe_gp_clone_state copies. */
+int bobe_gp_set_gate(bobe_gp_t* gp, const double* support_vectors, int64_t n_sv, const double* dual_coef, double intercept,
+                     double gamma, double probability_threshold, double minus_inf);
+/* decision[c] (svm_predict) and feasible[c] (1.0 / 0.0) of C query points; either output may be NULL. */
+int bobe_gp_gate_eval(bobe_gp_t* gp, const double* Xq, int64_t C, double* decision, double* feasible);
+
 /* GP.copy (gp.py:740-750) without leaving the device: dst (created with the same kernel, d and device) receives
  * src's training data, hyper-parameters and factorised state by device-to-device copies - no host round trip of the
  * N x N factor and no refactorisation (the reference copies through state_dict / from_state_dict). */

@@ -8,6 +8,7 @@ otherwise).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline le
   * the BO loop's refit policy                                             BOBE/bo.py:620-668
   * dynesty's trapezoid evidence integral and the GP +-sigma logZ bounds   BOBE/samplers.py:27-50, 172-185
   * the classifier gate of GPwithClassifier                                BOBE/clf_gp.py:173-205
+  * the SVM-RBF decision function behind it                               BOBE/clf.py:188-213
 """
 from __future__ import annotations
 
@@ -165,6 +166,36 @@ def clf_gate(mean, var, clf_probs, probability_threshold: float, minus_inf: floa
     gm = None if mean is None else np.where(ok, mean, minus_inf)
     gv = None if var is None else np.where(ok, var, O.SAFE_NOISE_FLOOR)
     return gm, gv
+
+
+def svm_predict(x, support_vectors, dual_coef, intercept: float, gamma: float):
+    """clf.py:188-208, line for line, for a batch of points: ``diff = support_vectors - x`` (203), ``norm_sq =
+    sum(diff**2, axis=1)`` (204), ``kernel_vals = exp(-gamma * norm_sq)`` (206), ``decision = sum(dual_coef *
+    kernel_vals) + intercept`` (208).  Direct differences - NOT the |x|^2 + |sv|^2 - 2 x.sv expansion libsvm uses."""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    sv = np.asarray(support_vectors, dtype=np.float64)
+    dual = np.asarray(dual_coef, dtype=np.float64).reshape(-1)
+    out = np.empty(x.shape[0])
+    for c in range(x.shape[0]):
+        diff = sv - x[c]
+        norm_sq = np.sum(diff ** 2, axis=1)
+        kernel_vals = np.exp(-gamma * norm_sq)
+        out[c] = np.sum(dual * kernel_vals) + intercept
+    return out
+
+
+def svm_predict_proba(x, support_vectors, dual_coef, intercept: float, gamma: float):
+    """clf.py:210-213: 1 where the decision is >= 0, else 0."""
+    return np.where(svm_predict(x, support_vectors, dual_coef, intercept, gamma) >= 0, 1.0, 0.0)
+
+
+def svm_decision_scale(x, support_vectors, dual_coef, gamma: float):
+    """sum_i |dual_i| exp(-gamma |sv_i - x|^2): the magnitude the decision's terms cancel from - rounding differences
+    between two summation orders are a few ulp of THIS, not of the decision itself (C = 1e7 makes the terms huge)."""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    sv = np.asarray(support_vectors, dtype=np.float64)
+    dual = np.abs(np.asarray(dual_coef, dtype=np.float64).reshape(-1))
+    return np.array([np.sum(dual * np.exp(-gamma * np.sum((sv - xc) ** 2, axis=1))) for xc in x])
 
 
 def clf_labels(train_y_clf: np.ndarray, clf_threshold: float):

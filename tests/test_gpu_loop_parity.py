@@ -94,7 +94,8 @@ def test_logz_dictionary_against_the_oracle_twin():
 
 def test_classifier_gate_against_the_oracle_twin():
     """clf_gp.py:86-93, 173-205: GP on the thresholded subset, predictions gated by the classifier's probability.
-    The SVM itself is scikit-learn on both sides; what is compared is the subset, the labels and the gate."""
+    The SVM is TRAINED by scikit-learn on both sides; its probabilities come from the oracle's restatement of
+    clf.py:188-213 (not from the product), and the subset, the labels and the gate are compared."""
     from bobe_amd.clf_gp import GPwithClassifier
     from oracle import bobe_oracle as O
     from oracle import bobe_oracle_loop as OL
@@ -108,7 +109,9 @@ def test_classifier_gate_against_the_oracle_twin():
     assert gp.npoints == int(mask.sum())
     og = O.OracleGP(X[mask], y[mask], noise=1e-6, lengthscales=np.array([0.4, 0.4]), lengthscale_prior="DSLP")
     q = rng.uniform(size=(200, 2))
-    probs = gp._clf_predict_func(q)
+    p = gp.clf_params
+    probs = OL.svm_predict_proba(q, p["support_vectors"], p["dual_coef"], p["intercept"], p["gamma_eff"])
+    assert np.array_equal(gp._clf_predict_func(q), probs)                         # (no query of this set sits on the boundary)
     assert 0 < np.sum(probs >= 0.5) < len(q)                                      # both sides of the gate are exercised
     labels = OL.clf_labels(y, 60.0)
     assert np.array_equal(labels, np.where(y < y.max() - 60.0, 0, 1))

@@ -1,6 +1,6 @@
 """Parity tests for code paths that ship but that the smaller parity cases never reach (round-2 verdict, weak #2):
 
-* the 128-tile variants of the inverse / K^-1-gradient kernels, selected from N = 6272 up (bobe_gp.hip, ``lauum`` /
+* the 128-tile variants of the inverse / K^-1-gradient kernels, selected from N = 6272 up (gp_factor.hip, ``lauum`` /
   ``trtri``): value, gradient and entries of K^-1 against the oracle's LAPACK evaluation (dpotrf / dpotri), both kernels;
 * Matern through the lock-step batch (N >= 1024: per-slot hyper-parameter arrays in the assembly and gradient kernels):
   bitwise the single evaluation, and against the oracle;
@@ -33,7 +33,7 @@ def noisy_data(n, d, seed):
 @pytest.mark.parametrize("kernel", ["rbf", "matern"])
 def test_value_gradient_and_kinv_through_the_128_tile_kernels(kernel):
     """N = 6400 = 50 blocks: 50*51/2 = 1275 >= 1200 selects k_lauum_grad<.,.,128> and the top inverse levels run
-    k_trtri_T/R<128> (bobe_gp.hip: lauum(), trtri()).  The largest gradient check before this one was N = 4096."""
+    k_trtri_T/R<128> (gp_factor.hip: lauum(), trtri()).  The largest gradient check before this one was N = 4096."""
     from bobe_amd import _lib
     from scipy.linalg import lapack
     n, d = 6400, 8

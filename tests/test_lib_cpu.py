@@ -247,3 +247,43 @@ def test_header_is_plain_c_and_a_c_host_links_against_the_library(tmp_path, lib)
         pytest.skip("a GPU is present: tests/test_gpu_parity.py runs the program")
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 77 and "no CPU compute path" in p.stderr
+
+
+def test_an_exception_in_one_restart_ends_that_restart_only():
+    """an exception out of the batch objective for one restart's point used to abort every restart and run
+    the whole fit again under the thread driver.  Now the round's points are evaluated one by one, the offending
+    restart ends with its exception (optimize_scipy skips it like any failed restart) and the others finish as
+    ``minimize`` would - under the stepped driver and under the thread driver alike."""
+    from scipy.optimize import minimize
+    from bobe_amd import optim
+
+    def vg(x):
+        x = np.asarray(x)
+        if x[0] < -1.5:
+            raise FloatingPointError("objective undefined here")
+        return float(np.sum((x - 0.3) ** 2) + 0.1 * np.sum(x ** 4)), 2 * (x - 0.3) + 0.4 * x ** 3
+
+    starts = np.array([[1.0, -1.0, 0.5], [-1.8, 0.2, 0.1], [0.9, 0.9, -0.9]])
+    kw = dict(method="L-BFGS-B", bounds=[(-2, 2)] * 3, options={"maxiter": 50})
+    ref = [minimize(vg, starts[i], jac=True, **kw) for i in (0, 2)]
+    calls = []
+
+    def batch(xs):
+        calls.append(len(xs))
+        return [vg(x) for x in xs]
+    for force_threads in (False, True):
+        saved = optim._RC_STATE["ok"]
+        assert optim._rc_available()
+        if force_threads:
+            optim._RC_STATE["ok"] = False
+        try:
+            out = optim._minimize_concurrently(batch, starts, True, **kw)
+        finally:
+            optim._RC_STATE["ok"] = saved
+        assert isinstance(out[1], FloatingPointError)
+        for r, o in zip(ref, (out[0], out[2])):
+            assert np.array_equal(o.x, r.x) and o.fun == r.fun and o.nit == r.nit and o.nfev == r.nfev
+    best_x, best_f = optim.optimize_scipy(vg, 3, [-2, 2], starts, n_restarts=3, batch_value_and_grad=batch)
+    # (optimize_scipy's own options differ from `kw`: same optimum, not the same last digits)
+    assert np.allclose(best_x, ref[0].x, atol=1e-3) and best_f == pytest.approx(min(r.fun for r in ref), rel=1e-4)
+    assert optim.lbfgs_driver() == "stepped"

@@ -303,3 +303,27 @@ def test_first_order_optimisers_follow_torch(name, kw):
     assert fv == pytest.approx(bests[i], rel=1e-12)
     with pytest.raises(ValueError):
         optimize_optax(vg, 3, [0.0, 1.0], x0, {"name": "lbfgs"}, 5, 2)
+
+
+def test_svm_decision_restatement_against_sklearn():
+    """oracle.bobe_oracle_loop.svm_predict is clf.py:188-213 line for line (direct differences); scikit-learn's own
+    decision_function (libsvm, the expanded form) must agree to a few ulp of the terms' magnitude, and the 0/1
+    probabilities wherever the decision is not inside that band."""
+    from sklearn.svm import SVC
+    from oracle import bobe_oracle_loop as OL
+    for d, n, seed in ((2, 120, 0), (6, 400, 1), (10, 600, 2)):
+        rng = np.random.default_rng(seed)
+        X = rng.uniform(size=(n, d))
+        y = -2000.0 * np.sum((X - 0.5) ** 2, axis=1)
+        labels = np.where(y < y.max() - 75.0 * d, 0, 1)
+        clf = SVC(kernel="rbf", gamma="scale", C=1e7).fit(X, labels)
+        sv, dual, b, gam = clf.support_vectors_, clf.dual_coef_[0], float(clf.intercept_[0]), float(clf._gamma)
+        q = np.vstack([rng.uniform(size=(1500, d)), X])
+        ref = clf.decision_function(q)
+        mine = OL.svm_predict(q, sv, dual, b, gam)
+        scale = OL.svm_decision_scale(q, sv, dual, gam)
+        tol = 1e-9 * np.abs(ref) + 1e-13 * scale
+        assert np.all(np.abs(mine - ref) <= tol)
+        clear = np.abs(ref) > tol
+        assert np.array_equal(OL.svm_predict_proba(q, sv, dual, b, gam)[clear], (ref >= 0).astype(float)[clear])
+        assert np.array_equal(clf.predict(q)[clear], (ref >= 0).astype(int)[clear])

@@ -28,6 +28,11 @@ for N, d, kern in SIZES:
     lsb = np.full((B, d), 0.4) + 0.03 * np.arange(B)[:, None]
     mb, gb = gp.mll_data_batch(lsb, np.ones(B))
     out[f"mb_{N}"], out[f"gb_{N}"] = np.array(mb), np.array(gb)
+    if os.environ.get("BITS_B8"):            # an eight-wide batch (its first panels do not fit one launch): the first four
+        ls8 = np.vstack([lsb, lsb + 0.2])    # members are the batch above and must return its bits
+        m8, g8 = gp.mll_data_batch(ls8, np.ones(8))
+        assert np.array_equal(m8[:4], mb) and np.array_equal(g8[:4], gb), "a batch member's bits depend on the batch width"
+        out[f"m8_{N}"], out[f"g8_{N}"] = np.array(m8), np.array(g8)
     mu, var = gp.predict_batched(rng.uniform(size=(50, d)))
     out[f"mu_{N}"], out[f"var_{N}"] = np.array(mu), np.array(var)
     if N <= 2048:     # a sweep of three chunks (the assembly stream runs ahead of the GEMM launches from two chunks up)
