@@ -418,27 +418,38 @@ def main():
             t5 = time.perf_counter()
             gp.mll_data, gp.mll_data_batch = orig, orig_b
             refactor()                                   # back to the cycle's state
+            import scipy
+            from bobe_amd.optim import lbfgs_driver
             lbfgs = {"restarts": 4, "maxiter": 200, "seconds": t5 - t4, "evaluations": calls[0],
-                     "ms_per_evaluation": (t5 - t4) * 1e3 / max(calls[0], 1), "mll": float(r_fit["mll"])}
+                     "ms_per_evaluation": (t5 - t4) * 1e3 / max(calls[0], 1), "mll": float(r_fit["mll"]),
+                     # which driver advanced the restarts: "stepped" (SciPy's reverse-communication L-BFGS-B stepped by one
+                     # thread, lock-step batches) or "threads" (one scipy.optimize.minimize per restart)
+                     "driver": lbfgs_driver(), "scipy": scipy.__version__}
     if rank == 0:
         chunk = args.chunk or 8192
         # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 per candidate, triangular) fused with
         # the cross-covariance rows W_Z^T K(X,C) (2 N M per candidate)
         flops_per_launch = {"trimul": (float(N) * N + 2.0 * N * M) * min(chunk, Cn),
                             "syrk": None, "lauum": 2.0 * N ** 3 / 3.0}.get(args.profile_class)
-        traffic = None
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_k_%s.json" % args.profile_class)
         if os.path.exists(tf):      # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
             tj = json.load(open(tf))
             if (tj.get("N"), tj.get("C"), tj.get("chunk")) == (N, Cn, chunk):
                 traffic = tj["hbm_bytes_per_launch"]
+                # NOT measured by this run: PMC counters need their own rocprofv3 passes (separate --pmc runs of this command)
+                traffic_source = ("profiles/traffic_k_%s.json: rocprofv3 --pmc passes of `%s` (%s), collected by "
+                                  "tools/pmc_traffic.py; not re-measured in this run" %
+                                  (args.profile_class, tj.get("command", "python bench.py --no-secondary"),
+                                   tj.get("collected", "round 3")))
         roof = None
         if flops_per_launch and launches.value:
             avg_s = tot_ms.value * 1e-3 / launches.value
             ach = flops_per_launch / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": "k_" + args.profile_class, "achieved": ach,
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                    "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "launches": int(launches.value),
+                    "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": avg_s * 1e3,
+                    "launches": int(launches.value),
                     "flops_per_launch": flops_per_launch,
                     "note": "largest single kernel of the cycle by time (the sweep's GEMM); the fit phase is priced in roofline_fit"}
         chol, potrf_ms, roof_fit = {}, None, None

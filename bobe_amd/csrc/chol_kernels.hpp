@@ -959,10 +959,35 @@ __global__ __launch_bounds__(256, 2) void k_trtri_R(double* __restrict__ Linv, i
   }
 }
 
+// ---- K^-1 = Linv^T Linv on 32 x 32 tiles, stored (no gradient) ------------------------------------------------------
+// The GEMM half of k_lauum_grad<., ., 64> as a launch of its own, for matrices so small that the fused launch is as long as
+// its longest 64 x 64 tile on ONE CU: the four 32 x 32 quarters of every lower 64 x 64 tile (all four of a diagonal tile too:
+// the gradient epilogue reads the whole tile) are four times as many workgroups with a quarter of the MFMAs per wave and
+// K-step.  An element's K range starts at the later of its row and column (before that one factor is a zero of the
+// triangular Linv) and runs in the same groups of four: the bits of the 64 x 64 tiles.  Tile-major grid like k_lauum_grad.
+__global__ __launch_bounds__(256, 2) void k_lauum_tiles32(const double* __restrict__ Linv, int64_t ldi, int64_t np,
+                                                          double* __restrict__ Kinv, int64_t ldk, int64_t bsL, int64_t bsK,
+                                                          int nbatch) {
+  extern __shared__ double smem[];
+  const int tile = (int)(blockIdx.x / nbatch), slot = (int)(blockIdx.x % nbatch);
+  Linv += slot * bsL;
+  Kinv += slot * bsK;
+  int ti, tj;
+  tri_decode(tile >> 2, ti, tj);                                   // the 64 x 64 tile, then its quarter
+  const int r32 = 2 * ti + ((tile >> 1) & 1), c32 = 2 * tj + (tile & 1);
+  v4d acc[1][1];
+  acc_zero(acc);
+  gemm_tile<RC, RC, 32, 32, BK32>(acc, Linv, ldi, (int64_t)r32 * 32, Linv, ldi, (int64_t)c32 * 32,
+                                  (int64_t)(r32 > c32 ? r32 : c32) * 32, np, smem);
+  store_tile<32, 32>(acc, Kinv, ldk, (int64_t)r32 * 32, (int64_t)c32 * 32, 1.0, 0.0);
+}
+
 // ---- K^-1 = Linv^T Linv fused with the MLL gradient reduction ------------------------------------------
 // lower T x T tile (ti >= tj): Kinv = sum_{k >= ti*T} Linv[k][ti]^T Linv[k][tj];  W = alpha alpha^T - Kinv.
-// partial[(blockIdx.x)*(DCAP+1) + j] = sum_ab W_ab dK_ab/dlog ls_j (j < d), [DCAP] = sum_ab W_ab Kt_ab,
+// partial[tile*(DCAP+1) + j] = sum_ab W_ab dK_ab/dlog ls_j (j < d), [DCAP] = sum_ab W_ab Kt_ab,
 // off-diagonal tiles weighted x2.  Optionally stores Kinv (lower tiles) for tests.
+// from_kinv: the tiles of K^-1 are already in Kinv (k_lauum_tiles, slot stride bsK): only the gradient epilogue runs, each
+// thread on the elements it would own after the GEMM - the partial sums are the fused kernel's, bit for bit.
 template <int KERN, int DCAP, int T>
 __global__ __launch_bounds__(256, 2) void k_lauum_grad(const double* __restrict__ Linv, int64_t ldi, int64_t np,
                                                        int64_t n, const double* __restrict__ alpha,
@@ -970,20 +995,29 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(const double* __restrict_
                                                        double* __restrict__ partial, double* __restrict__ Kinv,
                                                        int64_t ldk, const Hyper* __restrict__ hp = nullptr,
                                                        int64_t bsL = 0, int64_t bsV = 0, int64_t bsX = 0,
-                                                       int64_t bsP = 0) {
+                                                       int64_t bsP = 0, int nbatch = 1, int from_kinv = 0, int64_t bsK = 0) {
   extern __shared__ double smem[];
-  if (hp) h = hp[blockIdx.y];
-  Linv += blockIdx.y * bsL;
-  alpha += blockIdx.y * bsV;
-  XsT += blockIdx.y * bsX;
-  partial += blockIdx.y * bsP;
+  // One grid dimension, tile-major: workgroup id = tile * nbatch + slot.  A tile's K length falls with its row (the first
+  // tile row runs over all of K), and a launch lasts as long as the CU holding the most long tiles: with the slot in a second
+  // grid dimension every matrix's long tiles were dealt to CUs that already held those of the matrices before it; dealt
+  // tile-major, the long tiles of ALL matrices go out first, each to a CU of its own.
+  const int tile = (int)(blockIdx.x / nbatch), slot = (int)(blockIdx.x % nbatch);
+  if (hp) h = hp[slot];
+  Linv += slot * bsL;
+  alpha += slot * bsV;
+  XsT += slot * bsX;
+  partial += slot * bsP;
   int ti, tj;
-  tri_decode(blockIdx.x, ti, tj);
+  tri_decode(tile, ti, tj);
   v4d acc[T / 32][T / 32];
-  acc_zero(acc);
-  gemm_tile<RC, RC, T, T, TileCfg<T>::bk>(acc, Linv, ldi, (int64_t)ti * T, Linv, ldi, (int64_t)tj * T, (int64_t)ti * T, np,
-                                          smem);
-  if (Kinv) store_tile<T, T>(acc, Kinv, ldk, (int64_t)ti * T, (int64_t)tj * T, 1.0, 0.0);
+  if (from_kinv) {
+    load_tile<T, T>(acc, Kinv + slot * bsK, ldk, (int64_t)ti * T, (int64_t)tj * T);
+  } else {
+    acc_zero(acc);
+    gemm_tile<RC, RC, T, T, TileCfg<T>::bk>(acc, Linv, ldi, (int64_t)ti * T, Linv, ldi, (int64_t)tj * T, (int64_t)ti * T, np,
+                                            smem);
+    if (Kinv) store_tile<T, T>(acc, Kinv, ldk, (int64_t)ti * T, (int64_t)tj * T, 1.0, 0.0);
+  }
   // stage coordinates and alpha in the (now free) GEMM LDS
   double* xa = smem;                  // [d][T]
   double* xb = smem + MAX_D * T;      // [d][T]
@@ -1043,7 +1077,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(const double* __restrict_
   __syncthreads();
   if (t <= DCAP) {
     const double s = ((red[t] + red[(DCAP + 1) + t]) + red[2 * (DCAP + 1) + t]) + red[3 * (DCAP + 1) + t];
-    partial[(int64_t)blockIdx.x * (DCAP + 1) + t] = wt * s;
+    partial[(int64_t)tile * (DCAP + 1) + t] = wt * s;
   }
 }
 

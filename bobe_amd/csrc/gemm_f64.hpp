@@ -69,7 +69,11 @@ constexpr int BK64 = BOBE_BK64;   // 64x64 tiles: 40,960 B of LDS -> FOUR workgr
 constexpr int GEMM_SMEM_DOUBLES = gemm_smem_doubles<128, 128, BK128>();
 constexpr int GEMM_SMEM_BYTES = GEMM_SMEM_DOUBLES * 8;
 constexpr int GEMM64_SMEM_BYTES = gemm_smem_doubles<64, 64, BK64>() * 8;
-template <int T> struct TileCfg { static constexpr int bk = (T == 128) ? BK128 : BK64; };
+// 32 x 32 tiles serve launches that are bound by the latency of ONE workgroup's K loop (few MFMAs per K-step): K-steps of 32
+// halve the global -> LDS round trips (49,152 B of LDS, three workgroups per CU)
+constexpr int BK32 = 32;
+template <int T> struct TileCfg { static constexpr int bk = (T == 128) ? BK128 : (T == 64 ? BK64 : BK32); };
+constexpr int GEMM32_SMEM_BYTES = gemm_smem_doubles<32, 32, BK32>() * 8;
 
 // ---- global -> register staging (R*BK/512 x 16 B per thread per operand) -----------------------
 template <int L, int R, int BK>

@@ -34,6 +34,9 @@ void configure_factor_kernels() {
   allow_big_lds(k_syrk_trail<32, SYRK32_BK>, SYRK32_SMEM);
   allow_big_lds(k_trtri_T<64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_trtri_R<64>, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_trtri_T<32>, GEMM32_SMEM_BYTES);
+  allow_big_lds(k_trtri_R<32>, GEMM32_SMEM_BYTES);
+  allow_big_lds(k_lauum_tiles32, GEMM32_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 8, 64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 16, 64>, GEMM64_SMEM_BYTES);
   allow_big_lds(k_lauum_grad<0, 32, 64>, GEMM64_SMEM_BYTES);
@@ -217,18 +220,22 @@ int bobe_gp::panel_strips(int B, int rr) const {
   return B * panel_workgroups(rr, 3) <= std::max(num_cus, 1) ? 3 : 4;
 }
 
-// Where deferred updates in the panel launches pay (measured, profiles/r04_fill_rule.txt): the factorisation's FIRST panel
-// launch - its widest - occupies at most two fifths of the CUs, so that whole block columns of update tiles fit beside the
-// chain, and the matrix has at least 20 block columns (below, the update launches the fillers would replace last a few
-// microseconds each).  On 256 CUs: a lone factorisation of 2560 <= N <= 4992.  Larger matrices, or several in lock step:
-// the panel launches have few CUs to spare, a filler workgroup (one per CU, eight waves) runs the tile core at ~3/4 of its
-// usual rate, and a launch lasts as long as its slowest filler.  Never on an evaluation slot's private stream, where the
-// other slots' kernels want those CUs.  BOBE_FILL=2 forces the fillers on everywhere, BOBE_FILL=0 off.
+// Where deferred updates in the panel launches pay.  Measured on 256 CUs (profiles/r04_fill_rule.txt: a lone
+// factorisation, fillers forced on / off): N = 2048 1.008, 2560 0.990, 3072 1.017, 3584 0.989, 3840 0.974, 4096 0.965,
+// 4352 0.966, 4608 1.040, 4992 1.136, 5120 1.140, 6144 1.157, 8192 1.066.  They pay in a narrow band: the matrix must have
+// enough block columns for the update launches to be worth replacing (below ~28 they last a few microseconds each and the
+// difference is inside the noise), and the FIRST panel launch - the widest - must leave about two thirds of the chip free
+// (from 36 block columns up it occupies 94+ of 256 CUs, whole block columns of update tiles no longer fit beside the chain,
+// a filler workgroup runs the tile core at ~3/4 of its usual rate and every launch lasts as long as its slowest filler).
+// Hence: nb >= 28 and B * (panel workgroups of step 0) <= 35 % of the CUs - on 256 CUs a lone factorisation of 28 ... 34
+// block columns (N = 3457 ... 4352), never a lock-step batch (B >= 2 fails the second test for every nb >= 28).  Never on
+// an evaluation slot's private stream, where the other slots' kernels want those CUs.  BOBE_FILL=2 forces the fillers on
+// everywhere, BOBE_FILL=0 off.
 bool bobe_gp::fill_pays(int B) const {
   const int f = tuning().fill;
   if (f == 0 || in_slot) return false;
   if (f == 2) return true;
-  return nb >= 20 && 5 * B * panel_workgroups(nb - 1, panel_strips(B, nb - 1)) <= 2 * std::max(num_cus, 1);
+  return nb >= 28 && 20 * B * panel_workgroups(nb - 1, panel_strips(B, nb - 1)) <= 7 * std::max(num_cus, 1);
 }
 
 // The launch plan of a factorisation of B matrices in lock step (see potrf).  Block columns >= far_start are DEFERRED:
@@ -466,7 +473,17 @@ void bobe_gp::trtri(double* a, double* linv, double* tmp, int B, int64_t bsA, in
     // (64x64 tiles while a level of ONE matrix has too few 128x128 tiles to fill the chip; a tile's K order is the
     // same either way.  Batches keep the per-matrix choice: four in lock step at N = 4096 take 7.0 ms per evaluation
     // round with 64x64 tiles at every level against 7.4 with 128x128 tiles at the top level)
-    if (D.nblocks < tu.trtri64_below) {
+    if (B * 2 * D.nblocks <= std::max(num_cus, 1)) {
+      // A level with fewer 64 x 64 tile pairs than CUs (N <= 1024 in a batch of four, the deep levels of larger
+      // matrices): 32 x 32 tiles - four times the workgroups, a quarter of the work each.  Such a launch lasts as long as
+      // ONE workgroup's K loop, and a wave issues a 16 x 16 x 4 fp64 MFMA every 64 cycles at best: a quarter of the MFMAs
+      // per wave and K-step is a shorter launch.  Tile shape does not change an element's accumulation order (same bits).
+      const TileGrid tg = tile_grid(8 * D.nblocks);
+      hipLaunchKernelGGL(k_trtri_T<32>, dim3(tg.grid, B), dim3(256), GEMM32_SMEM_BYTES, stream, a, Np,
+                         (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT, tg.per);
+      hipLaunchKernelGGL(k_trtri_R<32>, dim3(tg.grid, B), dim3(256), GEMM32_SMEM_BYTES, stream, linv, Np,
+                         (const double*)tmp, Np, pr, D.count, bsL, bsT, tg.per);
+    } else if (D.nblocks < tu.trtri64_below) {
       const TileGrid tg = tile_grid(2 * D.nblocks);             // (tile pairs of complementary K: equal work)
       hipLaunchKernelGGL(k_trtri_T<64>, dim3(tg.grid, B), dim3(256), GEMM64_SMEM_BYTES, stream, a, Np,
                          (const double*)linv, Np, tmp, Np, pr, D.count, bsA, bsL, bsT, tg.per);
@@ -483,24 +500,35 @@ void bobe_gp::trtri(double* a, double* linv, double* tmp, int B, int64_t bsA, in
   LAUNCH_CHECK();
 }
 
-// K^-1 tiles fused with the gradient partial sums (optionally stores K^-1's lower tiles); returns #partials
+// K^-1 tiles fused with the gradient partial sums (optionally stores K^-1's lower tiles); returns #partials.
+// scratch (an Np x Np matrix per slot, stride bsS): small launches - fewer 64 x 64 tiles than four per CU - form K^-1 on
+// 32 x 32 tiles into it first (k_lauum_tiles) and run the gradient epilogue from there: N = 1024 in a batch of four,
+// 77 -> 36 us (the fused launch is as long as its longest tile, K = 1024 on one CU).  Same partial sums, same bits.
 int bobe_gp::lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
-                   const Hyper* hdev, double* gp_out, int B, int64_t bsL, int64_t bsV, int64_t bsX, int64_t bsP) {
+                   const Hyper* hdev, double* gp_out, int B, int64_t bsL, int64_t bsV, int64_t bsX, int64_t bsP,
+                   double* scratch, int64_t bsS) {
   // (the tile size fixes the order of the gradient's partial sums: it depends on N only, so that an evaluation
   // returns the same bits alone, on a slot and in a batch)
   const bool small = nb * (nb + 1) / 2 < LAUUM64_BELOW;
   const int nt = small ? 2 * nb : nb;
   const int ntiles = nt * (nt + 1) / 2;
   double* gpo = gp_out ? gp_out : gpart.d();
+  const bool split = small && scratch && !kinv_out && B * ntiles < 4 * std::max(num_cus, 1);
+  double* kio = split ? scratch : kinv_out;
+  const int64_t bsK = split ? bsS : 0;
+  prof_begin(BOBE_PROF_LAUUM);
+  if (split) {
+    hipLaunchKernelGGL(k_lauum_tiles32, dim3(4 * ntiles * B), dim3(256), GEMM32_SMEM_BYTES, stream, linv, Np, Np, scratch, Np,
+                       bsL, bsS, B);
+  }
 #define LG(KE, DC, TT)                                                                                          \
-  hipLaunchKernelGGL((k_lauum_grad<KE, DC, TT>), dim3(ntiles, B), dim3(256),                                    \
+  hipLaunchKernelGGL((k_lauum_grad<KE, DC, TT>), dim3(ntiles * B), dim3(256),                                   \
                      (TT == 128 ? GEMM_SMEM_BYTES : GEMM64_SMEM_BYTES), stream, linv, Np, Np, N, al, xst, Np, h, \
-                     gpo, kinv_out, Np, hdev, bsL, bsV, bsX, bsP)
+                     gpo, kio, Np, hdev, bsL, bsV, bsX, bsP, B, split ? 1 : 0, bsK)
 #define LGD(KE, TT)                                                                 \
   do {                                                                              \
     if (dcap == 8) LG(KE, 8, TT); else if (dcap == 16) LG(KE, 16, TT); else LG(KE, 32, TT); \
   } while (0)
-  prof_begin(BOBE_PROF_LAUUM);
   if (h.kern == 0) {
     if (small) LGD(0, 64); else LGD(0, 128);
   } else {
@@ -589,7 +617,7 @@ void bobe_gp::mll_enqueue_body(const Hyper& h, bool want_grad, const Hyper* hdev
   factor_into(h, XsT2.d(), A2.d(), Linv2.d(), w2.d(), alpha2.d(), hdev);
   if (want_grad) {
     const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
-    const int ntiles = lauum(h, Linv2.d(), alpha2.d(), XsT2.d(), nullptr, dcap, hdev);
+    const int ntiles = lauum(h, Linv2.d(), alpha2.d(), XsT2.d(), nullptr, dcap, hdev, nullptr, 1, 0, 0, 0, 0, Tmp.d(), 0);
     hipLaunchKernelGGL(k_mll_grad_reduce, dim3(d + 2), dim3(256), 0, stream, (const double*)gpart.d(), ntiles, dcap + 1, d,
                        dcap, res.d(), (const double*)w2.d(), (const double*)A2.d(), Np, Np, (const int*)info.p);
   } else {
@@ -716,7 +744,7 @@ void bobe_gp::mll_lockstep_enqueue(int B, const Hyper* hs, bool want_grad) {
   if (want_grad) {
     const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
     const int ntiles = lauum(hs[0], bw.Linv.d(), bw.alpha.d(), bw.XsT.d(), nullptr, dcap, hdev, bw.gpart.d(), B, mat, vec,
-                             xs, gps);
+                             xs, gps, bw.Tmp.d(), mat);
     hipLaunchKernelGGL(k_mll_grad_reduce, dim3(d + 2, B), dim3(256), 0, stream, (const double*)bw.gpart.d(), ntiles, dcap + 1,
                        d, dcap, bw.res.d(), (const double*)bw.w.d(), (const double*)bw.A.d(), Np, Np, (const int*)inf, gps,
                        (int64_t)128, vec, mat);

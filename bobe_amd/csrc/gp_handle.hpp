@@ -327,7 +327,7 @@ struct bobe_gp {
   void trtri(double* a, double* linv, double* tmp, int B = 1, int64_t bsA = 0, int64_t bsL = 0, int64_t bsT = 0);
   int lauum(const Hyper& h, const double* linv, const double* al, const double* xst, double* kinv_out, int dcap,
             const Hyper* hdev = nullptr, double* gp_out = nullptr, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
-            int64_t bsX = 0, int64_t bsP = 0);
+            int64_t bsX = 0, int64_t bsP = 0, double* scratch = nullptr, int64_t bsS = 0);
   // wv = Linv rhs, al = Linv^T wv (rhs: y unless given; bsY: its stride per batch member)
   void solve_alpha(const double* linv, double* wv, double* al, double* prt, int B = 1, int64_t bsL = 0, int64_t bsV = 0,
                    int64_t bsP = 0, const double* rhs = nullptr, int64_t bsY = 0);

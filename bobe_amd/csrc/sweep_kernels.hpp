@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void k_wip_score(const double* __restrict__ cr
     __syncthreads();
     const int zn = (m - z0 < ZT) ? (int)(m - z0) : ZT;
     if (live) {
-      for (int zz = sl; zz < zn; zz += 4) {
+      // one integration point of this thread's slice: cross-covariance from crossT (already loaded), fantasy variance, sums
+      auto score = [&](int zz, double ct) {
         double r2 = 0.0;
 #pragma unroll
         for (int j = 0; j < DCAP; ++j) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_wip_score(const double* __restrict__ cr
             r2 += df * df;
           }
         }
-        const double cross = kern_eval<KERN>(r2, h.kvar) - crossT[(z0 + zz) * ldx + c];
+        const double cross = kern_eval<KERN>(r2, h.kvar) - ct;
         double v = zsm[h.d * ZT + zz] - (cross * cross) / s;
         if (sbad) v = NOISE_FLOOR;
         if (v != v) v = NOISE_FLOOR;           // gp.py:574
@@ -160,7 +161,19 @@ __global__ __launch_bounds__(256) void k_wip_score(const double* __restrict__ cr
         sv += v;
         ss += sqrt(v);
         if (var_out) var_out[c * ldvo + z0 + zz] = v;
+      };
+      // (eight rows of crossT in flight per thread: one load per iteration left the loop waiting on memory - 83 us for
+      // 8192 candidates x 512 points; the sums keep their order)
+      const double* cp = crossT + z0 * ldx + c;
+      int zz = sl;
+      for (; zz + 28 < zn; zz += 32) {
+        double ct[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ct[q] = cp[(int64_t)(zz + 4 * q) * ldx];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) score(zz + 4 * q, ct[q]);
       }
+      for (; zz < zn; zz += 4) score(zz, cp[(int64_t)zz * ldx]);
     }
   }
   red[0][sl][cx] = sv;

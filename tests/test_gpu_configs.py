@@ -135,28 +135,29 @@ class _TrueSurface:
 
 def test_config5_rosenbrock_10d_full_loop_to_logz_convergence():
     """BASELINE config 5 (the reference's examples/Rosenbrock.py is 2-D; the 10-D likelihood is examples/rosenbrock10d.py):
-    the whole loop — Sobol design, fits, HMC integration points, kriging-believer WIPStd batches, nested sampling on
-    the surrogate — until the reference's stopping rule (bo.py:886-891, threshold 1.0 as its docs suggest for high
-    dimensions) or the evaluation budget.  Cross-check: nested sampling of the TRUE likelihood (-15.7 +- 0.1, batched
-    random-walk proposals, 1000-2000 live points); after ~600 evaluations in 10-D the surrogate's evidence sits within
-    ~1.5 of it, with an interval about as wide, so the stated band is +-3."""
+    the whole loop - Sobol design, lock-step fits, HMC integration points on the device, kriging-believer WIPStd batches,
+    rank-b appends, nested sampling on the surrogate - run to the REFERENCE'S STOPPING RULE (bo.py:886-934): the logZ
+    bounds from the GP's +-sigma within (upper - lower) / 2 < 1.0 (the threshold its docs suggest in high dimensions,
+    docs/source/examples/detailed_usage.rst:158) in TWO consecutive nested-sampling runs (convergence_n_iters = 2, so that
+    one lucky draw of the bounds does not end the run), with the budget this engine makes affordable (max_evals 3200,
+    max_gp_size 4096 - never reached: seeds 1-5 and 7 converge after 774 ... 929 evaluations in ~10 s each,
+    profiles/r04_config5.txt).  Cross-check: nested sampling of the TRUE likelihood with the same sampler."""
     from bobe_amd import samplers
     from bobe_amd.bo import BOBE
     D = 10
     b = BOBE(_rosen10, [f"x{i}" for i in range(D)], np.array([[-2.0, 2.0]] * D).T, n_sobol_init=64, seed=7)
-    res = b.run(acq="wipstd", min_evals=300, max_evals=650, max_gp_size=1200, logz_threshold=1.0, fit_n_points=10,
-                ns_n_points=20, batch_size=5, mc_points_size=256, num_hmc_warmup=256, num_hmc_samples=512,
+    res = b.run(acq="wipstd", min_evals=400, max_evals=3200, max_gp_size=4096, logz_threshold=1.0, convergence_n_iters=2,
+                fit_n_points=10, ns_n_points=50, batch_size=5, mc_points_size=256, num_hmc_warmup=256, num_hmc_samples=512,
                 do_final_ns=True)
-    assert res["termination_reason"] in ("LogZ converged", "Maximum evaluations reached")
-    assert 300 <= res["n_evals"] <= 655 and res["gp"].npoints == res["n_evals"]
+    assert res["termination_reason"] == "LogZ converged" and res["converged"]
+    assert 400 <= res["n_evals"] < 3200 and res["gp"].npoints == res["n_evals"]
     lz = res["logz"]
     assert lz and np.isfinite(lz["mean"]) and lz["lower"] < lz["mean"] < lz["upper"]
-    if res["termination_reason"] == "LogZ converged":
-        assert (lz["upper"] - lz["lower"]) / 2 < 1.0
+    assert (lz["upper"] - lz["lower"]) / 2 < 1.0
     _, truth, ok = samplers.nested_sampling(_TrueSurface(), ndim=D, mode="convergence", rng=np.random.default_rng(0),
                                             nlive=1000)
-    assert ok and abs(truth["mean"] - (-15.7)) < 0.5
-    assert abs(lz["mean"] - truth["mean"]) < 3.0
+    assert ok and abs(truth["mean"] - (-15.6)) < 0.5        # (-15.55 / -15.62 +- 0.07 with 2000 live points, two seeds)
+    assert abs(lz["mean"] - truth["mean"]) < 1.5
     assert res["best_val"] > -3.0                      # the maximum of the likelihood is 0 at x = 1
     s = res["samples"]
     assert s["x"].shape[1] == D and np.all(s["x"] >= -2.0 - 1e-9) and np.all(s["x"] <= 2.0 + 1e-9)
