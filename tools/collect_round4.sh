@@ -1,0 +1,33 @@
+#!/bin/bash
+# usage (GPU box, repo root): bash tools/collect_round4.sh <tag>      -> gpurun_out/r04_<tag>/
+# (1) kernel stats of the TIMED CYCLES ONLY (bench.py --no-secondary) for the headline and config 2,
+# (2) PMC passes of the same command: FETCH_SIZE / WRITE_SIZE -> traffic of k_trimul; MFMA busy cycles -> utilisation,
+# (3) one lock-step batch of four evaluations at N = 4096 and N = 1024: per-kernel totals + launch timeline,
+# (4) the bench lines (headline with the CPU baseline, small, shard on one GPU, large).
+tag=$1
+out=gpurun_out/r04_$tag
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p $out
+head=$(cat .git_head 2>/dev/null || echo "round 4")
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cycle -- python3 bench.py --steps 5 --warmup 2 --no-secondary > $out/bench_cycle.json 2> $out/bench_cycle.err || exit 1
+cp "$(ls $out/prof_cycle/*/*kernel_stats.csv | head -1)" $out/cycle_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cycle_small -- python3 bench.py --config small --steps 20 --warmup 3 --no-secondary > $out/bench_cycle_small.json 2> $out/bench_cycle_small.err || exit 1
+cp "$(ls $out/prof_cycle_small/*/*kernel_stats.csv | head -1)" $out/cycle_kernel_stats_config2.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-secondary > /dev/null 2>&1 || exit 1
+done
+python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE "k_trimul(" 4096 65536 8192 "python3 bench.py --steps 2 --warmup 1 --no-secondary" "round 4, $head" > $out/traffic_k_trimul.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-secondary > /dev/null 2>&1 || exit 1
+python3 tools/pmc_mfma.py $out/pmc_mfma > $out/mfma_util.json
+for cfg in "4096 4" "4096 1" "1024 4"; do
+  set -- $cfg
+  rocprofv3 --kernel-trace --output-format csv -d $out/trace_eval_N$1_B$2 -- python3 tools/eval_kstats.py run $1 $2 > /dev/null 2>&1 || exit 1
+  f="$(ls $out/trace_eval_N$1_B$2/*/*kernel_trace.csv | head -1)"
+  python3 tools/eval_kstats.py parse "$f" > $out/eval_kstats_N$1_B$2.txt
+  python3 tools/eval_kstats.py timeline "$f" > $out/eval_timeline_N$1_B$2.txt
+done
+python3 bench.py --steps 20 --warmup 3 > $out/bench_headline.json 2> $out/bench_headline.err || exit 1
+python3 bench.py --config small --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_config2.json 2> /dev/null || exit 1
+python3 bench.py --config shard --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_config4_one_gpu.json 2> /dev/null || exit 1
+python3 bench.py --config large --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_large.json 2> /dev/null || exit 1
+rm -rf $out/prof_cycle $out/prof_cycle_small $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_mfma $out/trace_eval_*
+tail -c 600 $out/bench_headline.json
