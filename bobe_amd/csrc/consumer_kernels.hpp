@@ -208,15 +208,16 @@ __device__ __forceinline__ double hmc_u01(unsigned long long bits) {          //
   return ((double)(bits >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
 
-template <int KERN, int DCAP>
-__global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT, int64_t ldx, int64_t n,
+template <int KERN, int DCAP, int NT>
+__global__ __launch_bounds__(NT) void k_hmc_run(const double* __restrict__ XsT, int64_t ldx, int64_t n,
                                                  const double* __restrict__ alpha, Hyper h, int64_t P,
                                                  double* __restrict__ S, double* __restrict__ adapt,
                                                  const double* __restrict__ inv_mass, unsigned long long seed,
                                                  int64_t it0, int niter, int do_adapt, double ystd, double ymean,
                                                  double temp, int hist_from, double* __restrict__ hist, int thin,
                                                  double* __restrict__ keep, double* __restrict__ dbg, Gate gt) {
-  __shared__ double u[DCAP], pm[DCAP], x[DCAP], xs[DCAP], g[DCAP], red[4][DCAP + 1], lp_s, mean_s, gred[4];
+  constexpr int NW = NT / 64;                 // waves of the workgroup (NT = 256, or 512 for large training sets)
+  __shared__ double u[DCAP], pm[DCAP], x[DCAP], xs[DCAP], g[DCAP], red[NW][DCAP + 1], lp_s, mean_s, gred[4];
   __shared__ double u0[DCAP], g0[DCAP], x0[DCAP], p0[DCAP], im[DCAP], lp0, mean0, eps_s;
   __shared__ int L_s, acc_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -237,15 +238,16 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
   }
   const unsigned long long ckey = hmc_mix64(seed ^ hmc_mix64((unsigned long long)c));
   // Up to RMAX training points per thread are loaded ONCE per launch (a launch is hundreds of leapfrog steps, each of
-  // which would otherwise wait for the same global loads again); points past n carry alpha = 0.
+  // which would otherwise wait for the same global loads again); points past n carry alpha = 0.  NT = 512 doubles what a
+  // workgroup holds (N <= 4096 at d <= 8, 2048 at d <= 16) and halves a step's share per thread.
   constexpr int RMAX = 64 / DCAP;
-  const bool cached = n <= (int64_t)256 * RMAX;
-  const int nrow = (int)((n + 255) / 256);
+  const bool cached = n <= (int64_t)NT * RMAX;
+  const int nrow = (int)((n + NT - 1) / NT);
   double cx[RMAX][DCAP], ca[RMAX];
   if (cached) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-      const int64_t i = t + 256 * r;
+      const int64_t i = t + NT * r;
       ca[r] = (i < n) ? alpha[i] : 0.0;
 #pragma unroll
       for (int j = 0; j < DCAP; ++j) cx[r][j] = (j < d && i < n) ? XsT[j * ldx + i] : 0.0;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
           }
         }
       } else {
-        for (int64_t i = t; i < n; i += 256) {
+        for (int64_t i = t; i < n; i += NT) {
           double df[DCAP];
           double r2 = 0.0;
 #pragma unroll
@@ -325,14 +327,21 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
       }
       // classifier gate (clf_gp.py:173-205): an infeasible point has mean = minus_inf and no mean gradient - its
       // trajectory ends in a state that the Metropolis test never accepts
-      if (gt.n_sv > 0) {
+      if (gt.n_sv > 0 && t < 256) {                            // (the gate's 256 partial sums: k_gate's order, whatever NT)
         const double gs = gate_partial<DCAP>(gt, x, d, t);
         if (lane == 0) gred[wave] = gs;
       }
       __syncthreads();
       const bool ok = gt.n_sv > 0 ? gate_feasible(gt, gate_combine(gt, gred)) : true;
+      // (the waves' sums in wave order: ((r0 + r1) + r2) + r3 for NT = 256)
+      auto wsum = [&](int j) {
+        double sres = red[0][j];
+#pragma unroll
+        for (int w_ = 1; w_ < NW; ++w_) sres += red[w_][j];
+        return sres;
+      };
       if (t < d) {
-        const double dm = ok ? (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) / h.ls[t] : 0.0;
+        const double dm = ok ? wsum(t) / h.ls[t] : 0.0;
         const double xv = x[t];
         const double gv = dm * ystd / temp * (xv * (1.0 - xv)) + (1.0 - 2.0 * xv);
         g[t] = gv;
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
         double jl = (lane < d) ? log(x[lane]) + log1p(-x[lane]) : 0.0;
         jl = wave_sum(jl);
         if (lane == 0) {
-          const double m = ok ? (((red[0][DCAP] + red[1][DCAP]) + red[2][DCAP]) + red[3][DCAP]) * ystd + ymean : gt.minus_inf;
+          const double m = ok ? wsum(DCAP) * ystd + ymean : gt.minus_inf;
           mean_s = m;
           lp_s = m / temp + jl;
         }

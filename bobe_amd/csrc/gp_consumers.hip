@@ -142,16 +142,22 @@ void bobe_gp::hmc_run(int64_t P, double* state, double* adapt, const double* inv
   HIPCHK(hipMemcpyAsync(dA, adapt, na * sizeof(double), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(dI, inv_mass, (size_t)d * sizeof(double), hipMemcpyHostToDevice, stream));
   const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
-#define HR(KE, DC)                                                                                                  \
-  hipLaunchKernelGGL((k_hmc_run<KE, DC>), dim3((unsigned)P), dim3(256), 0, stream, (const double*)XsT.d(), Np, \
-                     N, (const double*)alpha.d(), hyp, P, dS, dA, (const double*)dI,                       \
-                     (unsigned long long)seed, it0, niter, do_adapt, y_std, y_mean, temp, hist_from,                \
-                     hist ? dH : nullptr, thin, keep ? dK : nullptr, dbg ? dD : nullptr, gate)
+  // 512 threads per chain from 1025 training points on: twice the points in registers, half a step's loop per thread
+#define HR1(KE, DC, NTH)                                                                                            \
+  hipLaunchKernelGGL((k_hmc_run<KE, DC, NTH>), dim3((unsigned)P), dim3(NTH), 0, stream, (const double*)XsT.d(), Np, N, \
+                     (const double*)alpha.d(), hyp, P, dS, dA, (const double*)dI, (unsigned long long)seed, it0, niter, \
+                     do_adapt, y_std, y_mean, temp, hist_from, hist ? dH : nullptr, thin, keep ? dK : nullptr,       \
+                     dbg ? dD : nullptr, gate)
+#define HR(KE, DC)                            \
+  do {                                        \
+    if (N > 1024) HR1(KE, DC, 512); else HR1(KE, DC, 256); \
+  } while (0)
   if (hyp.kern == 0) {
     if (dcap == 8) HR(0, 8); else if (dcap == 16) HR(0, 16); else HR(0, 32);
   } else {
     if (dcap == 8) HR(1, 8); else if (dcap == 16) HR(1, 16); else HR(1, 32);
   }
+#undef HR1
 #undef HR
   LAUNCH_CHECK();
   HIPCHK(hipMemcpyAsync(state, dS, ns * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -174,11 +174,13 @@ def _hmc_state(gp, U, temp):
 def test_device_chain_iteration_replayed_on_the_host():
     """One iteration of bobe_gp_hmc_run with its draws (momentum, L, uniform) read back: the same trajectory through
     bobe_gp_hmc_leapfrog and the Metropolis rule on the host must give the same acceptance probability and the same
-    next state.  Then: launch boundaries and batch size do not change a chain (counter-based random numbers)."""
+    next state.  Then: launch boundaries and batch size do not change a chain (counter-based random numbers).  The sizes
+    cover both workgroup shapes of k_hmc_run (256 threads per chain up to 1024 training points, 512 above) with the training
+    set in registers (N <= threads x 64 / DCAP) and streamed from memory (N = 2500 at d = 12)."""
     from bobe_amd import GP
-    for kernel, d in (("rbf", 2), ("matern", 6), ("rbf", 12)):
+    for kernel, d, n in (("rbf", 2, 200), ("matern", 6, 200), ("rbf", 12, 200), ("rbf", 6, 1500), ("matern", 12, 2500)):
         rng = np.random.default_rng(10 + d)
-        X = rng.uniform(size=(200, d))
+        X = rng.uniform(size=(n, d))
         y = -15.0 * np.sum((X - 0.5) ** 2, axis=1)
         gp = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=np.linspace(0.4, 0.9, d), kernel_variance=2.0)
         P, temp, eps = 24, 1.0, 0.05
