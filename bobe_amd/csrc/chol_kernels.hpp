@@ -50,12 +50,6 @@ __device__ __forceinline__ void block_store_lower(const double* S, double* __res
   }
 }
 
-// diagnostic cycle stamps (template-disabled in the production instantiations)
-#define BOBE_STAMP(idx)                                                        \
-  do {                                                                         \
-    if (STAMP && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) stamps[(idx)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-
 // 1/sqrt(a): hardware estimate + two Newton steps (error ~1 ulp); NaN for a < 0, +inf for a = 0.
 // (One third-order step instead is 4 % faster but not accurate enough: with it the N = 40 fit of
 // tests/test_gpu_bo.py stops at a different optimum — the pivots feed an ill-conditioned K.)
@@ -67,13 +61,6 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   y = __builtin_fma(0.5 * y, e, y);
   return y;
 }
-
-// per-wave stamps of phase A (diagnostic builds): stamps[64 + 32 * wave + slot]
-#define BOBE_WSTAMP(slot)                                                                                   \
-  do {                                                                                                      \
-    if (STAMP && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0)                              \
-      stamps[64 + 32 * (threadIdx.x >> 6) + (slot)] = __builtin_amdgcn_s_memtime();                         \
-  } while (0)
 
 // ---- diagonal block -------------------------------------------------------------------------------
 // FACTOR: Cholesky of A[blk][blk] in place (lower, zeros above).  Always: the inverses of the eight
@@ -175,7 +162,7 @@ __device__ __forceinline__ void potf2_update_run(double* S, int o, int p, int a,
 // k_chol_panel's deferred tiles per helper wave and step.  Helpers in the order waves 1, 2, 3, 5, 6, 7; waves 1 and 5 share a
 // SIMD and both carry a row-solve side job (4 p + 4 dependent MFMAs in phase A of step p), waves 2 / 6 and 3 / 7 pair a
 // solver with a wave that has none.  A 16 x 16 x 4 fp64 MFMA holds a SIMD's pipe for 64 cycles and the leaf gives phase A
-// ~4 k: the counts below level tiles x 4 + side-job MFMAs over the three SIMDs (per-wave stamps, tools/ubench.hip: with an
+// ~4 k: the counts below level tiles x 4 + side-job MFMAs over the three SIMDs (per-wave cycle stamps, round 3: with an
 // even split the solver SIMD ran 5.5-6.8 k cycles in steps 1-4).  Which wave updates a tile does not change its arithmetic.
 constexpr unsigned pack4(int a, int b, int c, int d, int e, int f) {
   return (unsigned)a | ((unsigned)b << 4) | ((unsigned)c << 8) | ((unsigned)d << 12) | ((unsigned)e << 16) | ((unsigned)f << 20);
@@ -224,18 +211,16 @@ struct NoSideJob {
 // its rows below the block there, under the leaf of wave 0, instead of after the factor.
 // SKIPW > 0: that wave takes no phase-A work (with more than four waves, wave SKIPW = 4 shares the leaf wave's SIMD, and
 // MFMAs issued there slow the leaf down by half: measured 4.4-4.9 k -> 5.7-6.4 k cycles per step).
-template <bool STAMP, int NW = 4, class SIDE = NoSideJob, int SKIPW = -1, int STRIPS = 4>
+template <int NW = 4, class SIDE = NoSideJob, int SKIPW = -1, int STRIPS = 4>
 __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int nsteps, int colbase, int* __restrict__ info,
-                                                 unsigned long long* __restrict__ stamps, SIDE side = SIDE()) {
+                                                 SIDE side = SIDE()) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
   for (int p = 0; p < nsteps; ++p) {
     const int o = 16 * p;
     double* Dv = Dall + p * 16 * POTF2_DLD;
-    BOBE_STAMP(2 + 3 * p);
     if (wave == 0) {
-      BOBE_WSTAMP(3 * p);
       // ---- phase A, wave 0: 16x16 Cholesky + inverse (upper half-wave idle: EXEC[63:32] = 0) ----
       if (lane < 32) {
       const int li = lane & 15;
@@ -274,9 +259,7 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
       }
       if (bad && lane == 0) atomicMin(info, colbase + o + 1);
       }
-      BOBE_WSTAMP(3 * p + 2);
     } else if (p > 0 && wave != SKIPW) {
-      BOBE_WSTAMP(3 * p);
       // ---- phase A, waves 1..3: deferred updates of step p-1: every tile (ti, tj), p <= tj <= ti <= 7,
       //      except the diagonal tile (p, p), which wave 0 updated right after the previous phase B ----
       const int op = o - 16;
@@ -318,12 +301,9 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
           potf2_update2(S, op, p + a0, p + b0, p + a1, p + b1, two, lane);
         }
       }
-      BOBE_WSTAMP(3 * p + 1);
       side(p - 1);
-      BOBE_WSTAMP(3 * p + 2);
     }
     __syncthreads();
-    BOBE_STAMP(3 + 3 * p);
     // ---- phase B: rows below, X^T = inv(Lpp) * A^T per 16-row tile ----
     for (int tt = p + 1 + wave; tt < 8; tt += NW) {
       v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -337,7 +317,6 @@ __device__ __forceinline__ void potf2_factor_lds(double* S, double* Dall, int ns
       for (int r = 0; r < 4; ++r) S[(16 * tt + (lane & 15)) * PLD + o + (lane >> 4) + 4 * r] = y[r];
     }
     __syncthreads();
-    BOBE_STAMP(4 + 3 * p);
     // ---- phase C: the only urgent update is the next diagonal tile (p+1, p+1); wave 0 does it and runs
     //      straight into the next phase A (same wave: no barrier needed), the other waves go on to the
     //      deferred tiles ----
@@ -372,10 +351,9 @@ __device__ __forceinline__ void potf2_stage_out(const double* S, const double* D
   for (int c = 0; c < 8; ++c) dst[c] = src[c];
 }
 
-template <bool FACTOR, bool STAMP>
+template <bool FACTOR>
 __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv, int64_t ldl,
-                                           int blk, int* __restrict__ info, unsigned long long* __restrict__ stamps,
-                                           int nvalid = TILE) {
+                                           int blk, int* __restrict__ info, int nvalid = TILE) {
   extern __shared__ double S[];
   double* Dall = S + TILE * PLD;  // [8][16][POTF2_DLD]: inverses of the 16x16 diagonal sub-blocks
   // columns >= nvalid of a ragged last block are the identity padding: their sub-steps are skipped (L = I,
@@ -384,15 +362,11 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, 
   const int t = threadIdx.x;
   double* Ab = A + ((int64_t)blk * TILE) * lda + (int64_t)blk * TILE;
   double* Ib = Linv + ((int64_t)blk * TILE) * ldl + (int64_t)blk * TILE;
-  BOBE_STAMP(0);
   if (FACTOR) potf2_stage_in(S, Dall, Ab, lda, nsteps);
   else block_load<true>(S, Ab, lda);
   __syncthreads();
-  BOBE_STAMP(1);
-  if (FACTOR) potf2_factor_lds<STAMP>(S, Dall, nsteps, blk * TILE, info, stamps);
-  BOBE_STAMP(26);
+  if (FACTOR) potf2_factor_lds<>(S, Dall, nsteps, blk * TILE, info);
   if (FACTOR) potf2_stage_out(S, Dall, Ab, lda, Ib, ldl);
-  BOBE_STAMP(27);
   if (!FACTOR && t < 128) {
     // given L (restore path): inverses of the eight 16x16 diagonal sub-blocks, one column per thread
     const int bb = t >> 4, col = t & 15, o = 16 * bb;
@@ -407,16 +381,14 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int64_t lda, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) Ib[(int64_t)(o + r) * ldl + o + col] = x[r];
   }
-  BOBE_STAMP(28);
 }
 
-template <bool FACTOR, bool STAMP = false>
+template <bool FACTOR>
 __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                               int64_t ldl, int blk, int* __restrict__ info,
-                                               unsigned long long* __restrict__ stamps = nullptr, int nvalid = TILE,
+                                               int64_t ldl, int blk, int* __restrict__ info, int nvalid = TILE,
                                                int64_t bsA = 0, int64_t bsL = 0) {
   const int slot = blockIdx.x;
-  potf2_body<FACTOR, STAMP>(A + slot * bsA, lda, Linv + slot * bsL, ldl, blk, info + slot, stamps, nvalid);
+  potf2_body<FACTOR>(A + slot * bsA, lda, Linv + slot * bsL, ldl, blk, info + slot, nvalid);
 }
 
 // ---- inverse of every diagonal 128x128 block (grid = nb) --------------------------------------------
@@ -502,15 +474,12 @@ __global__ __launch_bounds__(256) void k_trti_diag(double* __restrict__ L, int64
 // (an accumulator's register r holds row (lane>>4)+4r, which serves as the k index of the next MFMA).
 constexpr int TRSM_DLD = 17;                                             // leading dim of a staged 16x16 inverse
 constexpr int TRSM_SMEM_BYTES = (TILE * PLD + 8 * 16 * TRSM_DLD) * 8;    // 150,528 B
-template <bool STAMP = false>
 __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int64_t lda,
                                                     const double* __restrict__ Dinv, int64_t ldl, int k,
-                                                    unsigned long long* __restrict__ stamps = nullptr,
                                                     int64_t bsA = 0, int64_t bsL = 0) {
   extern __shared__ double S[];
   A += blockIdx.y * bsA;
   Dinv += blockIdx.y * bsL;
-  BOBE_STAMP(0);
   double* D = S + TILE * PLD;   // [8][16][TRSM_DLD]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t row0 = (int64_t)(k + 1) * TILE + (int64_t)blockIdx.x * 64 + wave * 16;
@@ -556,7 +525,6 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
     for (int c = 0; c < 8; ++c) dst[c] = dr[c];
   }
   __syncthreads();
-  BOBE_STAMP(1);
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     v4d x = X[p];
@@ -576,7 +544,6 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
     X[p] = y;
   }
   __syncthreads();   // every wave is done with L_kk: the block is reused to transpose the results back
-  BOBE_STAMP(2);
 #pragma unroll
   for (int p = 0; p < 8; ++p)
 #pragma unroll
@@ -584,7 +551,6 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     *reinterpret_cast<v2d*>(Aw + (int64_t)i * lda + 2 * lane) = *reinterpret_cast<const v2d*>(Sw + i * PLD + 2 * lane);
-  BOBE_STAMP(3);
 }
 
 // ---- panel k of the batched factorisation ------------------------------------------------------------------------
@@ -608,16 +574,15 @@ constexpr int PANEL_THREADS = 512;
 // 16-row strips a panel workgroup solves, one per solver wave.  STRIPS = 3 (48 rows, waves 1, 2, 3): every helper SIMD has
 // one solver and one wave that only updates tiles - phase A of every step from 4 on is then the leaf's own 4.2 k cycles,
 // against 4.6-5.7 k with STRIPS = 4 (64 rows, waves 1, 2, 3, 5: two solvers' dependent MFMA chains on one SIMD).  A third
-// more workgroups: the host takes 3 strips wherever the launch still fits the chip, else 4 (tools/ubench.hip stamps: panel
+// more workgroups: the host takes 3 strips wherever the launch still fits the chip, else 4 (cycle stamps, round 3: panel
 // 64.3 k -> 60.2 k cycles).  Which workgroup solves a strip does not change its bits.
 __host__ __device__ inline int panel_workgroups(int blocks_below, int strips) {
   return blocks_below > 0 ? (blocks_below * TILE + 16 * strips - 1) / (16 * strips) : 1;
 }
-template <bool STAMP, int STRIPS>
+template <int STRIPS>
 __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                  int64_t ldl, int k, int pw, int npanel, int* __restrict__ info,
-                                                 int nvalid, double* __restrict__ Lkk_out,
-                                                 unsigned long long* __restrict__ stamps, int gridDim_rows_below) {
+                                                 int nvalid, double* __restrict__ Lkk_out, int gridDim_rows_below) {
   const bool has_rows = gridDim_rows_below > 0;
   extern __shared__ double S[];
   double* Dall = S + TILE * PLD;
@@ -627,7 +592,6 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
   const int64_t col0 = (int64_t)k * TILE;
   double* Ab = A + col0 * lda + col0;
   double* Ib = Linv + col0 * ldl + col0;
-  BOBE_STAMP(0);
   // Stage-in under the first leaf: wave 0 fetches only what its first leaf reads - the 16 x 16 tile (0, 0) - and starts
   // factoring; waves 1..7 (idle in phase A of step 0) bring in rows 16..127 meanwhile (lower part: rows 0..15 hold nothing
   // else that is read).  The barrier that ends phase A of step 0 publishes the block (it used to cost ~10 k cycles before
@@ -680,7 +644,6 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
     fetch(std::integral_constant<int, 1>());
   }
   // (no barrier here: phase A of step 0 touches only wave 0's own tile; the scattered loads of X pass under the first leaf)
-  BOBE_STAMP(1);
   // sub-block p in two parts: accumulate<p> (x = A^T_p - sum_{q<p} L_kk[p][q] X^T_q: needs the factor's steps < p only)
   // and finish<p> (X^T_p = invD_p x: needs leaf p).  Every LDS operand of a part is read first (one latency for all).
   auto accumulate = [&](auto pc) {
@@ -730,8 +693,7 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
     }
   };
 #undef BOBE_SIDE_CASE
-  potf2_factor_lds<STAMP, 8, decltype(side), 4, STRIPS>(S, Dall, nsteps, (int)col0, info, stamps, side);
-  BOBE_STAMP(26);
+  potf2_factor_lds<8, decltype(side), 4, STRIPS>(S, Dall, nsteps, (int)col0, info, side);
   // L_kk and the 16x16 inverses leave LDS once per slot: every workgroup of the launch holds the same factor, so
   // workgroup pw writes the rows pw, pw + npanel, ... of L_kk (zeros above the diagonal) and pw = 0 the inverses
   {
@@ -751,12 +713,10 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
       for (int c = 0; c < 8; ++c) dst[c] = src[c];
     }
   }
-  BOBE_STAMP(27);
   if (!has_rows) return;
   // (a block with rows below it is never the ragged last one: nsteps = 8 and the steps 0..6 ran under the leaves)
   if (solver) finish(std::integral_constant<int, 7>());
   __syncthreads();   // every wave is done with L_kk (and pw 0 with writing it back): reuse the block as transposer
-  BOBE_STAMP(28);
   if (!solver) return;
   double* Sw = S + (strip * 16) * PLD;
 #pragma unroll
@@ -767,7 +727,6 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     *reinterpret_cast<v2d*>(Aw + (int64_t)i * lda + 2 * lane) = *reinterpret_cast<const v2d*>(Sw + i * PLD + 2 * lane);
-  BOBE_STAMP(29);
 }
 
 // panel k of every slot as ONE launch (grid = npanel x nbatch, PANEL_THREADS threads).  Replaces the k_potf2 +
@@ -784,12 +743,11 @@ __device__ __forceinline__ void chol_panel_body5(double* __restrict__ A, int64_t
 constexpr int FILL_BK = 32;
 constexpr int FILL_SMEM_DOUBLES = gemm_smem_doubles_exact<KC, KC, 64, 64, FILL_BK>();   // per group; two groups fit the panel's 150 KB
 static_assert(2 * FILL_SMEM_DOUBLES * 8 <= POTF2_SMEM_BYTES, "update fillers exceed the panel's LDS");
-template <bool STAMP = false, bool FILL = false, int STRIPS = 4>
+template <bool FILL = false, int STRIPS = 4>
 __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict__ A, int64_t lda, int64_t bsA,
                                                               double* __restrict__ Linv, int64_t ldl, int64_t bsL, int k,
                                                               int npanel, int* __restrict__ info, int nvalid,
                                                               double* __restrict__ diag, int64_t bsD,
-                                                              unsigned long long* __restrict__ stamps = nullptr,
                                                               const FillJob* __restrict__ jobs = nullptr, int njobs = 0,
                                                               int rows_below = 0) {
   if (FILL && (int)blockIdx.x >= npanel) {
@@ -809,8 +767,8 @@ __global__ __launch_bounds__(PANEL_THREADS) void k_chol_panel(double* __restrict
     return;
   }
   const int slot = blockIdx.y;
-  chol_panel_body5<STAMP, STRIPS>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel, info + slot,
-                          nvalid, diag + slot * bsD + (int64_t)k * TILE * TILE, stamps, rows_below);
+  chol_panel_body5<STRIPS>(A + slot * bsA, lda, Linv + slot * bsL, ldl, k, (int)blockIdx.x, npanel, info + slot, nvalid,
+                           diag + slot * bsD + (int64_t)k * TILE * TILE, rows_below);
 }
 
 // A[blk][blk] <- scratch block blk for blk = first + blockIdx.x (slot = blockIdx.y): the L_kk the panel launches left aside

@@ -20,14 +20,14 @@ void configure_factor_kernels() {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || done[dev]) return;
-  allow_big_lds(k_potf2<true, false>, POTF2_SMEM_BYTES);
-  allow_big_lds(k_potf2<false, false>, POTF2_SMEM_BYTES);
+  allow_big_lds(k_potf2<true>, POTF2_SMEM_BYTES);
+  allow_big_lds(k_potf2<false>, POTF2_SMEM_BYTES);
   allow_big_lds(k_trti_diag, POTF2_SMEM_BYTES);
-  allow_big_lds(k_trsm_panel<false>, TRSM_SMEM_BYTES);
-  allow_big_lds((k_chol_panel<false, false, 3>), POTF2_SMEM_BYTES);
-  allow_big_lds((k_chol_panel<false, false, 4>), POTF2_SMEM_BYTES);
-  allow_big_lds((k_chol_panel<false, true, 3>), POTF2_SMEM_BYTES);
-  allow_big_lds((k_chol_panel<false, true, 4>), POTF2_SMEM_BYTES);
+  allow_big_lds(k_trsm_panel, TRSM_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<false, 3>), POTF2_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<false, 4>), POTF2_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<true, 3>), POTF2_SMEM_BYTES);
+  allow_big_lds((k_chol_panel<true, 4>), POTF2_SMEM_BYTES);
   allow_big_lds(k_trtri_T<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_trtri_R<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_syrk_trail<64, SYRK64_BK>, SYRK64_SMEM);
@@ -383,7 +383,7 @@ void bobe_gp::build_plans() {
 // for four on private streams (whose 150 KB-LDS panel kernels wait for a CU the others' update tiles keep occupied).
 // The panel launches leave most of the chip empty (one 150 KB workgroup per 48 / 64 rows): where that pays (fill_pays),
 // updates of block columns that are not needed soon are DEFERRED and ride in those launches as filler workgroups
-// (chol_plan, k_chol_panel<., true>).  Every matrix element sees the same operation sequence in all forms (same bits).
+// (chol_plan, k_chol_panel<true, .>).  Every matrix element sees the same operation sequence in all forms (same bits).
 void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, int64_t bsL, double* dg, bool defer_diag) {
   if (!dg) dg = diag.d();                                     // scratch for the L_kk of the panel launches
   const int64_t bsD = (int64_t)nb * TILE * TILE;
@@ -405,11 +405,11 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
 #define PANEL_LAUNCH(FILLV, GRIDX, ...)                                                                                        \
   do {                                                                                                                         \
     if (strips == 3)                                                                                                           \
-      hipLaunchKernelGGL((k_chol_panel<false, FILLV, 3>), dim3(GRIDX, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, \
-                         bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, __VA_ARGS__);       \
+      hipLaunchKernelGGL((k_chol_panel<FILLV, 3>), dim3(GRIDX, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, bsA, \
+                         linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, __VA_ARGS__);                                          \
     else                                                                                                                       \
-      hipLaunchKernelGGL((k_chol_panel<false, FILLV, 4>), dim3(GRIDX, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, \
-                         bsA, linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, (unsigned long long*)nullptr, __VA_ARGS__);       \
+      hipLaunchKernelGGL((k_chol_panel<FILLV, 4>), dim3(GRIDX, B), dim3(PANEL_THREADS), POTF2_SMEM_BYTES, stream, a, Np, bsA, \
+                         linv, Np, bsL, kk, np_, info_dev, nv, dg, bsD, __VA_ARGS__);                                          \
   } while (0)
         if (op.tab_cnt > 0) PANEL_LAUNCH(true, np_ + op.tab_cnt / 2, jobs + op.tab_off, op.tab_cnt, rows_below);
         else PANEL_LAUNCH(false, np_, (const FillJob*)nullptr, 0, rows_below);
@@ -417,13 +417,13 @@ void bobe_gp::potrf(double* a, double* linv, int* info_dev, int B, int64_t bsA, 
         prof_end(BOBE_PROF_POTF2);
       } else {
         prof_begin(BOBE_PROF_POTF2);
-        hipLaunchKernelGGL((k_potf2<true, false>), dim3(B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, kk,
-                           info_dev, (unsigned long long*)nullptr, nv, bsA, bsL);
+        hipLaunchKernelGGL(k_potf2<true>, dim3(B), dim3(256), POTF2_SMEM_BYTES, stream, a, Np, linv, Np, kk, info_dev, nv, bsA,
+                           bsL);
         prof_end(BOBE_PROF_POTF2);
         if (rr > 0) {
           prof_begin(BOBE_PROF_TRSM);
-          hipLaunchKernelGGL(k_trsm_panel<false>, dim3(2 * rr, B), dim3(256), TRSM_SMEM_BYTES, stream, a, Np,
-                             (const double*)linv, Np, kk, (unsigned long long*)nullptr, bsA, bsL);
+          hipLaunchKernelGGL(k_trsm_panel, dim3(2 * rr, B), dim3(256), TRSM_SMEM_BYTES, stream, a, Np, (const double*)linv, Np,
+                             kk, bsA, bsL);
           prof_end(BOBE_PROF_TRSM);
         }
       }
@@ -989,8 +989,8 @@ void bobe_gp::set_chol(const double* L, const double* alpha_in) {
                         is_device_ptr(alpha_in) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
   scale(X.d(), N, Np, hyp, XsT.d(), Np);
   for (int k = 0; k < nb; ++k)                       // the 16 x 16 diagonal inverses the block inverse starts from
-    hipLaunchKernelGGL((k_potf2<false, false>), dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, A.d(), Np, Linv.d(), Np, k,
-                       static_cast<int*>(info.p), (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_potf2<false>, dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, A.d(), Np, Linv.d(), Np, k,
+                       static_cast<int*>(info.p));
   LAUNCH_CHECK();
   trtri(A.d(), Linv.d(), Tmp.d());
   sync();

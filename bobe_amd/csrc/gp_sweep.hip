@@ -113,15 +113,17 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
         hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                            (const double*)part.d(), CH, nb, 0, nc, d_mean + s0 + c0);
       }
-      prof_begin(BOBE_PROF_TRIMUL);
-      hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)(nb + nzt)), dim3(256), GEMM_SMEM_BYTES,
-                         stream, (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, (double*)nullptr,
-                         (int64_t)0, qpart.d(), CH, (const double*)WZ.d(), Mp, nzt, do_wip ? pv.d() + c0 : nullptr, SC);
-      prof_end(BOBE_PROF_TRIMUL);
-      // s_c for the scorer, var for the caller
-      hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
-                         (const double*)qpart.d(), CH, nb, nc, kself, policy, sc.d() + c0,
-                         d_var ? d_var + s0 + c0 : nullptr);
+      if (do_wip || d_var) {       // (a mean-only prediction - nested sampling's likelihood calls - needs no triangular product)
+        prof_begin(BOBE_PROF_TRIMUL);
+        hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)(nb + nzt)), dim3(256), GEMM_SMEM_BYTES,
+                           stream, (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, (double*)nullptr,
+                           (int64_t)0, qpart.d(), CH, (const double*)WZ.d(), Mp, nzt, do_wip ? pv.d() + c0 : nullptr, SC);
+        prof_end(BOBE_PROF_TRIMUL);
+        // s_c for the scorer, var for the caller
+        hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
+                           (const double*)qpart.d(), CH, nb, nc, kself, policy, sc.d() + c0,
+                           d_var ? d_var + s0 + c0 : nullptr);
+      }
       LAUNCH_CHECK();
     }
     if (do_wip) {

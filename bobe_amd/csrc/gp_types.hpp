@@ -19,7 +19,7 @@ struct Hyper {
 // `off` counts T x T tiles: a problem owns (hi-mid)(mid-lo)(128/T)^2 consecutive blocks.
 struct TriProb { int lo, mid, hi, off; };
 
-// A filler job of a panel launch (k_chol_panel<., true>): update tile A[ti][tj] -= sum_k A[ti][k] A[tj][k]^T over the
+// A filler job of a panel launch (k_chol_panel<true, .>): update tile A[ti][tj] -= sum_k A[ti][k] A[tj][k]^T over the
 // 64-column units [k0, k1) - k_syrk_trail's tile.  The two jobs of a workgroup run the same number of K-steps
 // (workgroup-wide barriers): the plan pairs tiles of one block column; FILL_TWIN completes an odd count (computed, not stored).
 enum { FILL_TWIN = 1 };

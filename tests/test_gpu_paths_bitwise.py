@@ -51,7 +51,7 @@ def test_the_switches_that_only_act_on_large_matrices():
 
 def test_deferred_updates_in_the_panel_shadows_do_not_move_a_bit():
     """potrf() lets trailing-update tiles of far block columns ride in the panel launches as filler workgroups
-    (k_chol_panel<., true>, chol_plan in gp_factor.hip).  Where a tile is computed must not change what it holds: the
+    (k_chol_panel<true, .>, chol_plan in gp_factor.hip).  Where a tile is computed must not change what it holds: the
     factor, MLL, gradient, batch results and predictions with the fillers forced on everywhere (BOBE_FILL=2: lone and
     lock-step, ragged and full sizes, both kernels) equal, bit for bit, those with every update in its own launch (=0)
     and those of the default rule (=1: fill_pays)."""
