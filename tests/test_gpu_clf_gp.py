@@ -202,3 +202,57 @@ def test_gated_hmc_runs_on_the_device_and_matches_the_host_stepped_path():
         assert np.all(smp["logp"] > gp.minus_inf)
     assert np.allclose(dev["x"].mean(0), host["x"].mean(0), atol=0.02)
     assert np.allclose(dev["x"].std(0), host["x"].std(0), rtol=0.25)
+
+
+def test_gate_entry_points_through_the_c_abi():
+    """bobe_gp_set_gate / bobe_gp_gate_eval as a host program would call them: host or device pointers, NULL clears,
+    usage errors come back as status codes with text, the probability threshold is honoured, a NaN query is infeasible,
+    and the gate survives set_data / factor but is not copied by bobe_gp_clone_state."""
+    import ctypes as C
+    import torch
+    from bobe_amd import GP, _lib
+    rng = np.random.default_rng(4)
+    d, n_sv = 5, 37
+    sv = np.ascontiguousarray(rng.uniform(size=(n_sv, d)))
+    dual = np.ascontiguousarray(rng.normal(size=n_sv) * 50.0)
+    b, gamma = 0.3, 2.5
+    X = rng.uniform(size=(60, d))
+    gp = GP(X, np.sin(X.sum(1)), noise=1e-6, lengthscales=np.full(d, 0.5))
+    lib, h = gp._lib, gp._h
+    q = np.ascontiguousarray(rng.uniform(size=(300, d)))
+    dec, ok = np.empty(300), np.empty(300)
+    # no gate yet: an error code and a message, nothing thrown
+    rc = lib.bobe_gp_gate_eval(h, _lib.ptr(q), 300, _lib.ptr(dec), _lib.ptr(ok))
+    assert rc < 0 and b"no classifier gate" in lib.bobe_last_error()
+    assert lib.bobe_gp_set_gate(h, _lib.ptr(sv), n_sv, None, b, gamma, 0.5, -1e5) < 0          # dual_coef missing
+    assert lib.bobe_gp_set_gate(h, _lib.ptr(sv), n_sv, _lib.ptr(dual), b, gamma, 0.5, -1e5) == 0
+    assert lib.bobe_gp_gate_eval(h, _lib.ptr(q), 300, _lib.ptr(dec), _lib.ptr(ok)) == 0
+    want = np.exp(-gamma * ((q[:, None, :] - sv[None, :, :]) ** 2).sum(-1)) @ dual + b
+    scale = np.exp(-gamma * ((q[:, None, :] - sv[None, :, :]) ** 2).sum(-1)) @ np.abs(dual)
+    assert np.all(np.abs(dec - want) <= 1e-9 * np.abs(want) + 1e-13 * scale)
+    assert np.array_equal(ok, (dec >= 0).astype(float)) and 0 < ok.sum() < 300
+    # device pointers in and out (a torch tensor's memory), either output optional
+    qd = torch.from_numpy(q).cuda()
+    dd = torch.empty(300, dtype=torch.float64, device="cuda")
+    assert lib.bobe_gp_gate_eval(h, C.c_void_p(qd.data_ptr()), 300, C.c_void_p(dd.data_ptr()), None) == 0
+    assert np.array_equal(dd.cpu().numpy(), dec)
+    # the gated predictions: -inf marks / 1e-12, untouched elsewhere; NaN coordinates are infeasible
+    m, v = gp.predict_batched(q)
+    assert np.all(np.isneginf(m[ok == 0])) and np.all(v[ok == 0] == 1e-12) and np.all(np.isfinite(m[ok == 1]))
+    qn = q[:4].copy()
+    qn[1, 2] = np.nan
+    assert lib.bobe_gp_gate_eval(h, _lib.ptr(qn), 4, _lib.ptr(dec[:4].copy()), _lib.ptr(ok[:4])) == 0 and ok[1] == 0.0
+    # probability threshold (clf_gp.py:179): proba is 0 or 1, so <= 0 lets everything through and > 1 nothing
+    for thr, expect in ((0.0, 300), (1.5, 0)):
+        assert lib.bobe_gp_set_gate(h, _lib.ptr(sv), n_sv, _lib.ptr(dual), b, gamma, thr, -1e5) == 0
+        assert lib.bobe_gp_gate_eval(h, _lib.ptr(q), 300, None, _lib.ptr(ok)) == 0 and int(ok.sum()) == expect
+    assert lib.bobe_gp_set_gate(h, _lib.ptr(sv), n_sv, _lib.ptr(dual), b, gamma, 0.5, -1e5) == 0
+    # new data / a new factor keep the gate; a clone does not carry it
+    gp.update(rng.uniform(size=(3, d)), rng.normal(size=(3, 1)))
+    m2, _ = gp.predict_batched(q)
+    assert np.array_equal(np.isneginf(m2), np.isneginf(m))
+    twin = gp.copy()
+    assert np.all(np.isfinite(twin.predict_batched(q)[0]))
+    # NULL clears
+    assert lib.bobe_gp_set_gate(h, None, 0, None, 0.0, 0.0, 0.5, -1e5) == 0
+    assert np.all(np.isfinite(gp.predict_batched(q)[0]))
