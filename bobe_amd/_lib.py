@@ -59,6 +59,8 @@ SIGNATURES = [
     ("bobe_gp_hmc_run", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int,
                                   C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p]),
+    ("bobe_gp_rwalk", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_uint64,
+                                C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_set_gate", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                    C.c_double]),
     ("bobe_gp_gate_eval", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -421,6 +421,133 @@ __global__ __launch_bounds__(NT) void k_hmc_run(const double* __restrict__ XsT, 
 }
 
 
+// ---- constrained random walks for nested sampling, whole walks on the device -----------------------------------------
+// The replacement search of a nested-sampling iteration (dynesty's 'rwalk', the reference's choice: samplers.py:64, 152):
+// every walker starts at a live point and takes `walks` Metropolis steps inside {mean(x) > lstar, unit cube}; a step is
+// x' = x + step[d x d] z, z ~ N(0, I) (step = scale x the Cholesky factor of the live points' covariance, lower, row-major).
+// One workgroup = one walker, every step's surrogate mean by the reduction of k_hmc_run (training points in registers),
+// the classifier gate applied like everywhere else (an infeasible proposal has mean = minus_inf and is never accepted).
+// Random numbers: the counter hash of k_hmc_run on (seed, walker, step, index).
+//   X    [P][d]  in: start points, out: end points        logl [P]  in / out: physical-unit mean at the point
+//   nacc [P]     accepted steps                            nin  [P]  proposals inside the cube (= surrogate calls)
+//   dbg  [P][d]  the LAST proposal of every walker (tests)                                             (may be null)
+template <int KERN, int DCAP, int NT>
+__global__ __launch_bounds__(NT) void k_rwalk(const double* __restrict__ XsT, int64_t ldx, int64_t n,
+                                              const double* __restrict__ alpha, Hyper h, double* __restrict__ X,
+                                              double* __restrict__ logl, const double* __restrict__ step, double lstar,
+                                              int walks, unsigned long long seed, double ystd, double ymean,
+                                              int* __restrict__ nacc, int* __restrict__ nin, double* __restrict__ dbg,
+                                              Gate gt) {
+  constexpr int NW = NT / 64;
+  __shared__ double x[DCAP], xp[DCAP], xs[DCAP], z[DCAP], red[NW], gred[4], lx;
+  __shared__ int inside_s, na_s, ni_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t c = blockIdx.x;
+  const int d = h.d;
+  if (t < d) x[t] = X[c * d + t];
+  if (t == 0) {
+    lx = logl[c];
+    na_s = 0;
+    ni_s = 0;
+  }
+  const unsigned long long ckey = hmc_mix64(seed ^ hmc_mix64((unsigned long long)c));
+  constexpr int RMAX = 64 / DCAP;
+  const bool cached = n <= (int64_t)NT * RMAX;
+  const int nrow = (int)((n + NT - 1) / NT);
+  double cx[RMAX][DCAP], ca[RMAX];
+  if (cached) {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const int64_t i = t + NT * r;
+      ca[r] = (i < n) ? alpha[i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < DCAP; ++j) cx[r][j] = (j < d && i < n) ? XsT[j * ldx + i] : 0.0;
+    }
+  }
+  __syncthreads();
+  for (int s = 0; s < walks; ++s) {
+    const unsigned long long ikey = ckey + ((unsigned long long)s << 12);
+    if (t < d) {
+      const double a = hmc_u01(hmc_mix64(ikey + 2 * t)), b = hmc_u01(hmc_mix64(ikey + 2 * t + 1));
+      z[t] = sqrt(-2.0 * log(a)) * cos(6.283185307179586 * b);
+    }
+    __syncthreads();
+    if (t < d) {
+      double v = x[t];
+      for (int j = 0; j <= t; ++j) v += step[t * d + j] * z[j];          // (lower-triangular factor)
+      xp[t] = v;
+      xs[t] = v / h.ls[t];
+    }
+    __syncthreads();
+    if (t == 0) {
+      int in = 1;
+      for (int j = 0; j < d; ++j) in = in && (xp[j] >= 0.0) && (xp[j] <= 1.0);
+      inside_s = in;
+      ni_s += in;
+    }
+    __syncthreads();
+    if (inside_s) {                                                        // (uniform: a proposal outside costs no evaluation)
+      double ms = 0.0;
+      if (cached) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          if (r < nrow) {
+            double r2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < DCAP; ++j) {
+              const double df = (j < d) ? cx[r][j] - xs[j] : 0.0;
+              r2 += df * df;
+            }
+            ms += ca[r] * kern_eval<KERN>(r2, h.kvar);
+          }
+        }
+      } else {
+        for (int64_t i = t; i < n; i += NT) {
+          double r2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) {
+            const double df = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
+            r2 += df * df;
+          }
+          ms += alpha[i] * kern_eval<KERN>(r2, h.kvar);
+        }
+      }
+      ms = wave_sum(ms);
+      if (lane == 0) red[wave] = ms;
+      if (gt.n_sv > 0 && t < 256) {
+        const double gs = gate_partial<DCAP>(gt, xp, d, t);
+        if (lane == 0) gred[wave] = gs;
+      }
+      __syncthreads();
+      if (t == 0) {
+        double m = red[0];
+#pragma unroll
+        for (int w_ = 1; w_ < NW; ++w_) m += red[w_];
+        m = m * ystd + ymean;
+        if (gt.n_sv > 0 && !gate_feasible(gt, gate_combine(gt, gred))) m = gt.minus_inf;
+        const int acc = m > lstar;
+        inside_s = acc;                                                    // (reused: accepted)
+        if (acc) {
+          lx = m;
+          ++na_s;
+        }
+      }
+      __syncthreads();
+      if (inside_s && t < d) x[t] = xp[t];
+    }
+    __syncthreads();
+  }
+  if (t < d) {
+    X[c * d + t] = x[t];
+    if (dbg) dbg[c * d + t] = xp[t];
+  }
+  if (t == 0) {
+    logl[c] = lx;
+    nacc[c] = na_s;
+    nin[c] = ni_s;
+  }
+}
+
 // mode 0: EI, 1: LogEI.  out = +EI / +logEI (the reference minimises the negative).  A mean of -inf is the gate's mark
 // (k_gate): the reference's predict_single returns minus_inf there (clf_gp.py:201-204)
 __global__ void k_ei(const double* __restrict__ mu, const double* __restrict__ var, int64_t n, double best_y, double zeta,

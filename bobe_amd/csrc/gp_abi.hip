@@ -299,6 +299,15 @@ int bobe_gp_hmc_run(bobe_gp_t* g, int64_t P, double* state, double* adapt, const
   API_END
 }
 
+int bobe_gp_rwalk(bobe_gp_t* g, int64_t P, double* X, double* logl, const double* step, double lstar, int walks,
+                  uint64_t seed, double y_std, double y_mean, int* n_accepted, int* n_inside, double* dbg) {
+  API_BEGIN
+  NEED(g && X && logl && step && n_accepted && n_inside, "NULL argument");
+  g->rwalk(P, X, logl, step, lstar, walks, seed, y_std, y_mean, n_accepted, n_inside, dbg);
+  return BOBE_OK;
+  API_END
+}
+
 int bobe_gp_set_gate(bobe_gp_t* g, const double* support_vectors, int64_t n_sv, const double* dual_coef, double intercept,
                      double gamma, double probability_threshold, double minus_inf) {
   API_BEGIN

@@ -168,6 +168,48 @@ void bobe_gp::hmc_run(int64_t P, double* state, double* adapt, const double* inv
   sync();
 }
 
+void bobe_gp::rwalk(int64_t P, double* Xw, double* logl, const double* step, double lstar, int walks, uint64_t seed,
+                    double y_std, double y_mean, int* nacc, int* nin, double* dbg) {
+  if (!factored) throw Err(BOBE_ERR_STATE, "call bobe_gp_factor first");
+  if (P <= 0 || walks < 1) throw Err(BOBE_ERR_ARG, "bad argument");
+  use();
+  const size_t pd = (size_t)P * d;
+  // staging: X | logl | step | dbg (doubles), then nacc | nin (ints)
+  in_stage.ensure((2 * pd + (size_t)P + (size_t)d * d) * sizeof(double) + 2 * (size_t)P * sizeof(int));
+  double* dX = in_stage.d();
+  double* dL = dX + pd;
+  double* dS = dL + P;
+  double* dD = dS + (size_t)d * d;
+  int* dA = reinterpret_cast<int*>(dD + pd);
+  int* dN = dA + P;
+  HIPCHK(hipMemcpyAsync(dX, Xw, pd * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(dL, logl, (size_t)P * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(dS, step, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, stream));
+  const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+#define RW1(KE, DC, NTH)                                                                                           \
+  hipLaunchKernelGGL((k_rwalk<KE, DC, NTH>), dim3((unsigned)P), dim3(NTH), 0, stream, (const double*)XsT.d(), Np, N, \
+                     (const double*)alpha.d(), hyp, dX, dL, (const double*)dS, lstar, walks, (unsigned long long)seed, \
+                     y_std, y_mean, dA, dN, dbg ? dD : nullptr, gate)
+#define RW(KE, DC)                            \
+  do {                                        \
+    if (N > 1024) RW1(KE, DC, 512); else RW1(KE, DC, 256); \
+  } while (0)
+  if (hyp.kern == 0) {
+    if (dcap == 8) RW(0, 8); else if (dcap == 16) RW(0, 16); else RW(0, 32);
+  } else {
+    if (dcap == 8) RW(1, 8); else if (dcap == 16) RW(1, 16); else RW(1, 32);
+  }
+#undef RW
+#undef RW1
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(Xw, dX, pd * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(logl, dL, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(nacc, dA, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(nin, dN, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, stream));
+  if (dbg) HIPCHK(hipMemcpyAsync(dbg, dD, pd * sizeof(double), hipMemcpyDeviceToHost, stream));
+  sync();
+}
+
 void bobe_gp::kernel_eval(const double* A, int64_t nA, const double* B, int64_t nB, const double* ls, double kvar,
                           double noise, int include_noise, double* out) {
   if (nA < 1 || nB < 1) throw Err(BOBE_ERR_ARG, "empty input");

@@ -362,6 +362,8 @@ struct bobe_gp {
   void hmc_run(int64_t P, double* state, double* adapt, const double* inv_mass, uint64_t seed, int64_t it0, int niter,
                int do_adapt, double y_std, double y_mean, double temp, int hist_from, double* hist, int thin, double* keep,
                double* dbg);
+  void rwalk(int64_t P, double* Xw, double* logl, const double* step, double lstar, int walks, uint64_t seed, double y_std,
+             double y_mean, int* nacc, int* nin, double* dbg);
   void kernel_eval(const double* A, int64_t nA, const double* B, int64_t nB, const double* ls, double kvar, double noise,
                    int include_noise, double* out);
   void clone_from(bobe_gp& src);

@@ -566,6 +566,23 @@ class GP:
                                              _lib.ptr(dbg) if dbg is not None else None), "bobe_gp_hmc_run")
         return hist, keep, dbg
 
+    def rwalk(self, x, logl, step, lstar: float, walks: int, seed: int, debug: bool = False):
+        """Constrained random walks of P walkers on the surrogate's mean in ONE GPU launch (``bobe_gp_rwalk``): the
+        replacement search of nested sampling (dynesty's 'rwalk', samplers.py:64, 152).  ``x`` (P, d) start points with
+        their physical-unit means ``logl``; ``step`` (d, d) lower-triangular proposal factor; a step is accepted inside the
+        unit cube above ``lstar`` (and inside the classifier's region when a gate is set).
+        Returns (x', logl', n_accepted, n_inside[, last proposals])."""
+        x = _lib.as_f64(np.atleast_2d(x)).copy()
+        lg = _lib.as_f64(logl).reshape(-1).copy()
+        st = _lib.as_f64(step).reshape(self.ndim, self.ndim)
+        P = x.shape[0]
+        nacc, nin = np.zeros(P, dtype=np.int32), np.zeros(P, dtype=np.int32)
+        dbg = np.empty_like(x) if debug else None
+        _lib.check(self._lib.bobe_gp_rwalk(self._h, P, _lib.ptr(x), _lib.ptr(lg), _lib.ptr(st), float(lstar), int(walks),
+                                           int(seed), float(self.y_std), float(self.y_mean), C.c_void_p(nacc.ctypes.data),
+                                           C.c_void_p(nin.ctypes.data), _lib.ptr(dbg) if debug else None), "bobe_gp_rwalk")
+        return (x, lg, nacc, nin, dbg) if debug else (x, lg, nacc, nin)
+
     def get_random_point(self, rng=None, nstd=None):
         """BOBE/gp.py:578-585."""
         rng = rng if rng is not None else get_numpy_rng()

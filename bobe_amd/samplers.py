@@ -96,12 +96,13 @@ def logz_from_samples(gp, samples_x, logl, logvol, mean: float, logz_err: float)
             "var": var_logz, "std": 2 * math.sqrt(var_logz)}
 
 
-def _rwalk_pool(loglike, live, live_logl, worst, lstar, rng, n_walkers, walks, scale):
+def _rwalk_pool(loglike, live, live_logl, worst, lstar, rng, n_walkers, walks, scale, gp=None):
     """Replacement candidates by constrained random walks, the proposal dynesty's 'rwalk' uses (the reference's choice,
     samplers.py:64, 152) — run as ONE batch: ``n_walkers`` walkers start from random live points and take ``walks``
-    Metropolis steps inside {L > L*, unit cube}, every step one batched surrogate call.  Steps are drawn from the live
-    points' covariance ellipsoid scaled by ``scale``.  Returns (points, logl, calls, acceptance rate); walkers that
-    never moved are dropped (they would duplicate a live point)."""
+    Metropolis steps inside {L > L*, unit cube}.  Steps are drawn from the live points' covariance ellipsoid scaled by
+    ``scale``.  With a surrogate that has ``rwalk`` (the GPU GP) ALL steps of all walkers are one launch
+    (``bobe_gp_rwalk``); otherwise every step is one batched ``loglike`` call.  Returns (points, logl, calls, acceptance
+    rate); walkers that never moved are dropped (they would duplicate a live point)."""
     nlive, d = live.shape
     ok = np.ones(nlive, dtype=bool)
     ok[worst] = False
@@ -109,6 +110,11 @@ def _rwalk_pool(loglike, live, live_logl, worst, lstar, rng, n_walkers, walks, s
     A = np.linalg.cholesky(cov)
     start = rng.choice(np.flatnonzero(ok), size=n_walkers)
     x, lx = live[start].copy(), live_logl[start].copy()
+    if gp is not None and hasattr(gp, "rwalk"):
+        x, lx, nacc, nin = gp.rwalk(x, lx, scale * A, lstar, walks, int(rng.integers(0, 2 ** 62)))
+        moved = nacc > 0
+        perm = rng.permutation(np.flatnonzero(moved))
+        return x[perm], lx[perm], int(nin.sum()), float(nacc.sum()) / float(n_walkers * walks)
     moved = np.zeros(n_walkers, dtype=bool)
     n_acc, calls = 0, 0
     for _ in range(walks):
@@ -129,14 +135,15 @@ def _rwalk_pool(loglike, live, live_logl, worst, lstar, rng, n_walkers, walks, s
 def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", dlogz: float = 0.01,
                     maxcall: int = int(5e6), equal_weights: bool = False, rng=None, batch: int = 8192,
                     enlarge: float = 1.25, nlive: Optional[int] = None, sample_method: str = "auto",
-                    walks: Optional[int] = None) -> Tuple[Dict, Dict, bool]:
+                    walks: Optional[int] = None, device_walks: bool = True) -> Tuple[Dict, Dict, bool]:
     """Static nested sampling of exp(GP mean) over the unit cube -> (samples_dict, logz_dict, success).
 
     Settings follow ``nested_sampling_Dy`` (samplers.py:119-126): mode 'acq' uses nlive = max(100, min(500, 20 d))
     and dlogz = 0.1 with equal-weight samples; otherwise nlive = max(500, 40 d).
     ``sample_method``: 'ellipsoid' = uniform draws in the enlarged bounding ellipsoid of the live points (exact, cheap
     in a few dimensions), 'rwalk' = batched constrained random walks (``_rwalk_pool``; what the reference asks dynesty
-    for), 'auto' = ellipsoid up to 4 dimensions, rwalk above."""
+    for), 'auto' = ellipsoid up to 4 dimensions, rwalk above.  ``device_walks``: whole walks in one launch where the
+    surrogate offers ``rwalk`` (``bobe_gp_rwalk``); False steps them from the host, one batched prediction per step."""
     rng = rng if rng is not None else get_numpy_rng()
     ndim = ndim if ndim is not None else gp.ndim
     if mode == "acq":
@@ -207,7 +214,7 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
             if use_rwalk:
                 pool_x, pool_l, calls, rate = _rwalk_pool(loglike, live, live_logl, worst, lstar, rng,
                                                           n_walkers=max(256, min(batch // 8, 2 * nlive)), walks=walks,
-                                                          scale=rw_scale)
+                                                          scale=rw_scale, gp=gp if device_walks else None)
                 pool_pos = 0
                 ncall += calls
                 # keep the acceptance rate of a step near one half (dynesty adapts its scale the same way)

@@ -167,6 +167,18 @@ int bobe_gp_hmc_run(bobe_gp_t* g, int64_t P, double* state, double* adapt, const
                     int64_t it0, int niter, int do_adapt, double y_std, double y_mean, double temp, int hist_from,
                     double* hist, int thin, double* keep, double* dbg);
 
+/* The replacement search of nested sampling on the surrogate (the consumer behind nested_sampling_Dy, samplers.py:55-194,
+ * which hands gp.predict_mean_single to dynesty's 'rwalk' sampler one point per call, samplers.py:112-115, 152): P walkers,
+ * each `walks` constrained Metropolis steps x' = x + step z, z ~ N(0, I), accepted when x' lies in the unit cube and
+ * mean(x') * y_std + y_mean > lstar (and, with a classifier gate set, x' is feasible) - ALL steps of all walkers in ONE
+ * launch.  step: d x d lower-triangular, row-major (scale x Cholesky factor of the live points' covariance).
+ *   X [P][d]  in: start points (live points), out: end points     logl [P]  in / out: physical-unit mean at the point
+ *   n_accepted [P], n_inside [P]: accepted steps / proposals inside the cube (= surrogate evaluations) per walker
+ *   dbg [P][d]: every walker's LAST proposal (NULL: not recorded; tests replay it).  All pointers are HOST memory.
+ * Random numbers: a counter hash of (seed, walker, step, index). */
+int bobe_gp_rwalk(bobe_gp_t* gp, int64_t P, double* X, double* logl, const double* step, double lstar, int walks,
+                  uint64_t seed, double y_std, double y_mean, int* n_accepted, int* n_inside, double* dbg);
+
 /* GPwithClassifier's gate (clf_gp.py:173-205) with the SVM-RBF decision function of clf.py:188-213, evaluated on the
  * device by direct differences, as the reference computes it:
  *   decision(x) = sum_i dual_coef[i] exp(-gamma |support_vectors[i] - x|^2) + intercept      (svm_predict)
@@ -180,6 +192,7 @@ int bobe_gp_hmc_run(bobe_gp_t* g, int64_t P, double* state, double* adapt, const
  *   bobe_gp_acq_ei                           EI / LogEI of (mean = minus_inf, var = 1e-12), i.e. what EI.fun computes from
  *                                            the gated predict_single (acquisition.py:246, 323)
  *   bobe_gp_hmc_leapfrog / bobe_gp_hmc_run   mean = minus_inf (physical units), no mean gradient: never accepted
+ *   bobe_gp_rwalk                            mean = minus_inf: never accepted
  * bobe_gp_wip_sweep, bobe_gp_fantasy_var and bobe_gp_wip_grad are NOT gated (fantasy_var is not, clf_gp.py:207-212).
  * One summation order serves every entry point (256 lane-strided partial sums, a fixed tree), so a point near the
  * boundary falls on the same side everywhere.  The gate is not part of the state bobe_gp_clone_state copies. */

@@ -232,3 +232,71 @@ def test_device_chain_random_numbers():
     counts = np.bincount(L.astype(int), minlength=13)[4:]
     assert counts.sum() == P and np.all(np.abs(counts - P / 9) < 5 * np.sqrt(P / 9))
     assert abs(r.mean() - 0.5) < 0.02 and abs(r.var() - 1 / 12) < 0.01
+
+
+def test_device_random_walks_of_nested_sampling():
+    """bobe_gp_rwalk (all constrained Metropolis steps of all walkers in one launch) against the host rule, step by step:
+    (i) one step with the proposals read back: accepted exactly where the proposal is inside the cube and the surrogate's
+    mean there (bobe_gp_predict) exceeds L*; proposals are x + step z with z ~ N(0, I); (ii) many steps: every walker that
+    moved ends inside the cube above L* with its own mean; a walker's path depends on (seed, walker) only; (iii) under a
+    classifier gate no walker enters the infeasible region; (iv) nested sampling gets the same evidence with the walks on
+    the device and stepped from the host."""
+    from bobe_amd import GP, samplers
+    from bobe_amd.clf_gp import GPwithClassifier
+    for kernel, d, n in (("rbf", 3, 150), ("matern", 10, 1300)):
+        rng = np.random.default_rng(20 + d)
+        X = rng.uniform(size=(n, d))
+        y = -40.0 * np.sum((X - 0.5) ** 2, axis=1)
+        gp = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=np.full(d, 0.6), kernel_variance=2.0)
+        P = 4096
+        x0 = rng.uniform(0.05, 0.95, size=(P, d))
+        l0 = gp.predict_mean_batched(x0)
+        lstar = float(np.quantile(l0, 0.3))
+        A = np.linalg.cholesky(np.cov(x0[:500], rowvar=False) + 1e-12 * np.eye(d)) * 0.35
+        x1, l1, nacc, nin, prop = gp.rwalk(x0, l0, A, lstar, 1, seed=77, debug=True)
+        inside = np.all((prop >= 0) & (prop <= 1), axis=1)
+        assert np.array_equal(nin, inside.astype(np.int32)) and 0.3 < inside.mean() <= 1.0
+        lp = np.full(P, -np.inf)
+        lp[inside] = gp.predict_mean_batched(prop[inside])
+        clear = np.abs(lp - lstar) > 1e-9 * max(1.0, abs(lstar))
+        acc = inside & (lp > lstar)
+        assert np.array_equal(nacc[clear] > 0, acc[clear]) and 0.1 < acc.mean() < 0.95
+        assert np.array_equal(x1[acc & clear], prop[acc & clear]) and np.array_equal(x1[~acc & clear], x0[~acc & clear])
+        assert np.allclose(l1[acc & clear], lp[acc & clear], rtol=1e-10, atol=1e-9) and np.array_equal(l1[~acc & clear], l0[~acc & clear])
+        z = np.linalg.solve(A, (prop - x0).T).T                              # the draws behind the proposals
+        assert np.allclose(z.mean(0), 0.0, atol=0.08) and np.allclose(np.cov(z, rowvar=False), np.eye(d), atol=0.1)
+        # many steps
+        x2, l2, na2, ni2 = gp.rwalk(x0, l0, A, lstar, 30, seed=5)
+        moved = na2 > 0
+        assert moved.mean() > 0.5 and np.all((x2 >= 0) & (x2 <= 1)) and np.all(l2[moved] > lstar)
+        assert np.allclose(l2[moved], gp.predict_mean_batched(x2[moved]), rtol=1e-10, atol=1e-9)
+        assert np.array_equal(x2[~moved], x0[~moved]) and np.all(na2 <= ni2) and np.all(ni2 <= 30)
+        xa, la, _, _ = gp.rwalk(x0, l0, A, lstar, 30, seed=5)
+        xb, lb, _, _ = gp.rwalk(x0[:100], l0[:100], A, lstar, 30, seed=5)
+        assert np.array_equal(xa, x2) and np.array_equal(xb, x2[:100]) and np.array_equal(lb, l2[:100])
+    # (iii) gated
+    rng = np.random.default_rng(9)
+    d = 2
+    X = rng.uniform(size=(250, d))
+    y = -800.0 * np.sum((X - np.array([0.45, 0.55])) ** 2, axis=1)
+    g = GPwithClassifier(X, y, clf_threshold=40.0, gp_threshold=120.0, noise=1e-6, lengthscales=np.full(d, 0.3), minus_inf=-1e10)
+    assert g.use_clf
+    x0 = g.train_x_clf[g._clf_predict_func(g.train_x_clf) >= 0.5][:64]
+    x0 = np.tile(x0, (8, 1))
+    l0 = g.predict_mean_batched(x0)
+    xg, lg, nag, _ = g.rwalk(x0, l0, 0.2 * np.eye(d), float(np.min(l0)) - 50.0, 40, seed=3)
+    assert nag.sum() > 0 and np.all(g._clf_predict_func(xg) >= 0.5) and np.all(lg > g.minus_inf)
+    # (iv) the sampler end to end, 6-D
+    rng = np.random.default_rng(1)
+    d = 6
+    X = rng.uniform(size=(400, d))
+    y = -30.0 * np.sum((X - 0.5) ** 2, axis=1)
+    gp = GP(X, y, noise=1e-6, lengthscales=np.full(d, 0.8), kernel_variance=4.0)
+    _, lz_dev, ok_dev = samplers.nested_sampling(gp, mode="convergence", dlogz=0.05, rng=np.random.default_rng(2), nlive=400)
+    _, lz_host, ok_host = samplers.nested_sampling(gp, mode="convergence", dlogz=0.05, rng=np.random.default_rng(3), nlive=400,
+                                                   device_walks=False)
+    assert ok_dev and ok_host
+    err = 4.0 * np.hypot(lz_dev["dlogz_sampler"], lz_host["dlogz_sampler"])
+    assert abs(lz_dev["mean"] - lz_host["mean"]) < max(err, 0.3), (lz_dev, lz_host)
+    exact = np.log((np.pi / 30.0) ** (d / 2))                                # integral of exp(-30 |x - 1/2|^2) over the cube
+    assert abs(lz_dev["mean"] - exact) < 0.5 and abs(lz_host["mean"] - exact) < 0.5
