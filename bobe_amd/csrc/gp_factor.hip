@@ -54,7 +54,7 @@ void configure_factor_kernels() {
 
 const Tuning& tuning() {
   static Tuning t = [] {
-    Tuning v{512, 600, 300, 1024, BOBE_MAX_MLL_SLOTS, 2048, 1, 1, false, false};
+    Tuning v{512, 600, 300, 1, BOBE_MAX_MLL_SLOTS, 2048, 1, 1, false, false};
     auto geti = [](const char* name, int& dst) {
       const char* e = std::getenv(name);
       if (e) dst = std::atoi(e);
@@ -834,7 +834,10 @@ int bobe_gp::mll_batch(int64_t B, const double* ls, const double* kvar, double* 
   const Tuning& tu = tuning();
   int worst = BOBE_OK;
   if (B >= 2 && N >= tu.lockstep_min_n) {      // (kernel-class event timing works there too: one stream, no capture)
-    // GPU-bound sizes: the evaluations advance in lock step through one batched launch sequence
+    // The evaluations advance in lock step through ONE batched launch sequence.  At every size (round 4, with the launches
+    // of small matrices no longer as long as one workgroup's K loop): the 10-D Rosenbrock loop's fits 3.0 -> 2.2 s, the 2-D
+    // examples 0.8-1.2 -> 0.4-0.8 s against one graph replay per evaluation on private streams (BOBE_LOCKSTEP_MIN_N = 1024,
+    // the default until then); same bits either way.
     for (int64_t b0 = 0; b0 < B; b0 += BOBE_MAX_MLL_SLOTS) {
       const int nbat = (int)std::min<int64_t>(BOBE_MAX_MLL_SLOTS, B - b0);
       Hyper hs[BOBE_MAX_MLL_SLOTS];
@@ -849,8 +852,8 @@ int bobe_gp::mll_batch(int64_t B, const double* ls, const double* kvar, double* 
     }
     return worst;
   }
-  // (this path serves batches below lockstep_min_n points: kernels of a few workgroups each, where eight evaluations in
-  //  flight beat four - an 8-restart fit at N = 400 / 900: 59.5 / 93.7 against 66.5 / 102.3 ms; BOBE_MLL_SLOTS overrides)
+  // (batches below BOBE_LOCKSTEP_MIN_N points, when that is raised: one evaluation slot - private stream, workspace, graph
+  //  replay - per member, BOBE_MLL_SLOTS at a time; also what bobe_gp_mll_submit / _wait run on)
   const int width = std::max(1, std::min<int>(tu.mll_slots, BOBE_MAX_MLL_SLOTS));
   for (int64_t b0 = 0; b0 < B; b0 += width) {
     const int nbat = (int)std::min<int64_t>(width, B - b0);

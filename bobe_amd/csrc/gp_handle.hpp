@@ -88,7 +88,7 @@ void allow_big_lds(K kernel, int bytes) {
 //   BOBE_SYRK32_BELOW   64x64-tile count below which a single-panel trailing update takes 32x32 tiles (512)
 //   BOBE_TRTRI64        128-block count below which a level of the triangular inverse takes 64x64 tiles (600)
 //   BOBE_PAIR_MIN       K = 256 update pairs while B * rem^2 exceeds this (300; 0: never)
-//   BOBE_LOCKSTEP_MIN_N bobe_gp_mll_batch advances its evaluations in lock step from this many points (1024)
+//   BOBE_LOCKSTEP_MIN_N bobe_gp_mll_batch advances its evaluations in lock step from this many points (1: always)
 //   BOBE_MLL_SLOTS      evaluations in flight below that size (8)
 //   BOBE_GRAPH_MAX_N    a slot replays its pipeline as a hipGraph up to this many points (2048)
 //   BOBE_XCD_SHARES     0: row-major tile order on every XCD (1)
@@ -233,7 +233,7 @@ struct bobe_gp {
     std::swap(eg, s.eg);
     in_slot = !in_slot;
   }
-  // Lock-step batch workspace (bobe_gp_mll_batch from lockstep_min_n points up): the B evaluations of a batch go
+  // Lock-step batch workspace (bobe_gp_mll_batch; from BOBE_LOCKSTEP_MIN_N points up when that is set): the B evaluations of a batch go
   // through ONE launch sequence on the handle's stream, every kernel taking the slot from its last grid dimension;
   // slot b lives at offset b * stride of each of these contiguous buffers.
   struct BatchWs {

@@ -76,9 +76,10 @@ int bobe_gp_mll(bobe_gp_t* gp, const double* lengthscales, double kernel_varianc
 /* bobe_gp_mll for B hyper-parameter vectors at once: lengthscales is B x d, kernel_variance has B entries,
  * mll B, grad (may be NULL) B x (d+1), status (may be NULL) B per-vector codes (BOBE_OK / BOBE_NOT_PD).
  * The restarts of optimize_scipy (optim.py:335-354) are independent L-BFGS-B runs which the reference walks
- * one after the other; here up to BOBE_MAX_MLL_SLOTS of their evaluations run concurrently, each on a private
- * HIP stream and workspace, through exactly the kernels of bobe_gp_mll (bit-identical results).  Returns
- * BOBE_NOT_PD when any vector was not positive definite (its outputs are NaN), < 0 on usage / HIP errors. */
+ * one after the other; here up to BOBE_MAX_MLL_SLOTS of their evaluations advance together through ONE launch
+ * sequence on the handle's stream (every kernel takes the batch member from a grid dimension), with exactly the
+ * arithmetic of bobe_gp_mll per member (bit-identical results).  Returns BOBE_NOT_PD when any vector was not
+ * positive definite (its outputs are NaN), < 0 on usage / HIP errors. */
 #define BOBE_MAX_MLL_SLOTS 8
 int bobe_gp_mll_batch(bobe_gp_t* gp, int64_t B, const double* lengthscales, const double* kernel_variance,
                       double* mll, double* grad, int* status);

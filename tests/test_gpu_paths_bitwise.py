@@ -33,7 +33,8 @@ def test_every_launch_sequence_gives_the_same_bits():
     base = _digests({"BITS_MAX_N": "1500"})
     assert len(base) >= 30
     for variant in ({"BOBE_XCD_SHARES": "0"}, {"BOBE_PAIR_MIN": "0"}, {"BOBE_SYRK32_BELOW": "0"}, {"BOBE_TRTRI64": "0"},
-                    {"BOBE_GRAPH_MAX_N": "0"}, {"BOBE_MLL_SLOTS": "2"}, {"BOBE_LOCKSTEP_MIN_N": "64"}):
+                    {"BOBE_LOCKSTEP_MIN_N": "1024"}, {"BOBE_LOCKSTEP_MIN_N": "1024", "BOBE_GRAPH_MAX_N": "0"},
+                    {"BOBE_LOCKSTEP_MIN_N": "1024", "BOBE_MLL_SLOTS": "2"}, {"BOBE_LOCKSTEP_MIN_N": "200"}):
         _same(base, _digests(dict(variant, BITS_MAX_N="1500")), variant)
 
 
