@@ -23,7 +23,7 @@ if __name__ == "__main__":
     bobe = BOBE(loglike, [f"x{i}" for i in range(D)], bounds, n_sobol_init=64, seed=7)
     # to logZ convergence on the surrogate (bo.py:886-934): half-width of the GP's +-sigma logZ bounds below the threshold
     # in two consecutive nested-sampling runs; the reference's docs suggest thresholds of 0.5-1.0 in high dimensions
-    # (docs/source/examples/detailed_usage.rst:158).  Converges after ~800-900 evaluations, ~10 s on one MI355X
+    # (docs/source/examples/detailed_usage.rst:158).  Converges after ~650-1000 evaluations, 6-8 s on one MI355X
     # (profiles/r04_config5.txt; true-likelihood nested sampling gives logZ = -15.6 +- 0.1)
     res = bobe.run(acq="wipstd", min_evals=int(os.environ.get("MIN_EVALS", 400)),
                    max_evals=int(os.environ.get("MAX_EVALS", 3200)), max_gp_size=4096,
