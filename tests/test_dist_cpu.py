@@ -61,18 +61,21 @@ def _worker(rank, world, port, q):
         mll, par = merge_best_fit(1.0 + rank if rank == 0 else float("nan"), np.array([rank, 2.0 * rank]))
         ok = ok and mll == 1.0 and np.array_equal(par, [0.0, 0.0])
         mll, par = merge_best_fit(-3.0 + 5 * rank, np.array([rank, 2.0 * rank]))
-        ok = ok and mll == 2.0 and np.array_equal(par, [1.0, 2.0])
+        top = world - 1                                  # the largest mll sits on the last rank
+        ok = ok and mll == -3.0 + 5 * top and np.array_equal(par, [top, 2.0 * top])
         q.put((rank, bool(ok), int(gidx), int(full["argmin_s"])))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_sharded_sweep_gloo_world2():
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sweep_gloo(world):
+    """two ranks, and three (uneven shards of the 101 candidates: 34 / 34 / 33, np.array_split's bounds)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
