@@ -208,15 +208,64 @@ __device__ __forceinline__ double hmc_u01(unsigned long long bits) {          //
   return ((double)(bits >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
 
-template <int KERN, int DCAP, int NT>
-__global__ __launch_bounds__(NT) void k_hmc_run(const double* __restrict__ XsT, int64_t ldx, int64_t n,
+// Sum of D per-lane values over the 64 lanes of a wave, all D at once: a butterfly that halves what a lane holds at every
+// step (the lane keeps the half its bit selects and adds its partner's), log2 D such steps, then a plain butterfly over
+// the remaining lane bits: D - 1 + (6 - log2 D) exchanges instead of 6 D, and one dependency chain instead of D.
+// Returns component (lane >> (6 - log2 D)), complete in every lane of that group; fixed order.
+template <int D, int HLF, int O>
+__device__ __forceinline__ void wave_sum_halve(double (&v)[D], int lane) {
+  if constexpr (HLF >= 1) {
+    const bool up = (lane & O) != 0;
+#pragma unroll
+    for (int i = 0; i < HLF; ++i) {
+      const double mine = up ? v[HLF + i] : v[i];
+      const double send = up ? v[i] : v[HLF + i];
+      v[i] = mine + __shfl_xor(send, O, 64);
+    }
+    wave_sum_halve<D, HLF / 2, O / 2>(v, lane);
+  }
+}
+template <int D>
+__device__ __forceinline__ double wave_sum_components(double (&v)[D], int lane) {
+  static_assert(D == 8 || D == 16 || D == 32, "power of two");
+  wave_sum_halve<D, D / 2, 32>(v, lane);
+  double r = v[0];
+#pragma unroll
+  for (int o = 32 / D; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+  return r;
+}
+
+// Training points a thread of a 256-thread chain workgroup keeps in registers for the whole launch (a launch is hundreds
+// of leapfrog / random-walk steps over the same points): 256 x RESIDENT rows, the rest is streamed from L2 every step.
+// (One wave per SIMD: the 512 unified registers of a lane hold them; chosen as the largest counts without scratch spills.)
+template <int DCAP>
+struct ChainRows {
+  static constexpr int HMC = DCAP == 8 ? 16 : (DCAP == 16 ? 6 : 2);
+  static constexpr int WALK = DCAP == 8 ? 16 : (DCAP == 16 ? 8 : 4);
+  static constexpr int STREAM = DCAP == 32 ? 1 : 2;      // streamed rows in flight per thread
+};
+// ... and as many more as the CU's LDS holds next to them: groups of 256 rows of d coordinates + alpha, [d + 1][rows]
+// (a lane reads consecutive doubles: no bank conflicts).  Host side: the group count for n points and `resident` register rows.
+constexpr int CHAIN_LDS_BYTES = 148 * 1024;                            // (of 160 KB: the kernels' static arrays stay below 10 KB)
+inline int chain_lds_groups(int64_t n, int d, int resident) {
+  const int64_t left = n - 256 * (int64_t)resident;
+  if (left <= 0) return 0;
+  const int64_t cap = CHAIN_LDS_BYTES / (8 * (int64_t)(d + 1)) / 256;
+  const int64_t want = (left + 255) / 256;
+  return (int)(want < cap ? want : cap);
+}
+
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT, int64_t ldx, int64_t n,
                                                  const double* __restrict__ alpha, Hyper h, int64_t P,
                                                  double* __restrict__ S, double* __restrict__ adapt,
                                                  const double* __restrict__ inv_mass, unsigned long long seed,
                                                  int64_t it0, int niter, int do_adapt, double ystd, double ymean,
                                                  double temp, int hist_from, double* __restrict__ hist, int thin,
-                                                 double* __restrict__ keep, double* __restrict__ dbg, Gate gt) {
-  constexpr int NW = NT / 64;                 // waves of the workgroup (NT = 256, or 512 for large training sets)
+                                                 double* __restrict__ keep, double* __restrict__ dbg, Gate gt,
+                                                 int lgroups) {
+  constexpr int NT = 256, NW = NT / 64;
+  extern __shared__ double lrows[];            // [d + 1][256 lgroups]: training points resident in LDS (chain_lds_groups)
   __shared__ double u[DCAP], pm[DCAP], x[DCAP], xs[DCAP], g[DCAP], red[NW][DCAP + 1], lp_s, mean_s, gred[4];
   __shared__ double u0[DCAP], g0[DCAP], x0[DCAP], p0[DCAP], im[DCAP], lp0, mean0, eps_s;
   __shared__ int L_s, acc_s;
@@ -237,21 +286,24 @@ __global__ __launch_bounds__(NT) void k_hmc_run(const double* __restrict__ XsT, 
     eps_s = ad[0];
   }
   const unsigned long long ckey = hmc_mix64(seed ^ hmc_mix64((unsigned long long)c));
-  // Up to RMAX training points per thread are loaded ONCE per launch (a launch is hundreds of leapfrog steps, each of
-  // which would otherwise wait for the same global loads again); points past n carry alpha = 0.  NT = 512 doubles what a
-  // workgroup holds (N <= 4096 at d <= 8, 2048 at d <= 16) and halves a step's share per thread.
-  constexpr int RMAX = 64 / DCAP;
-  const bool cached = n <= (int64_t)NT * RMAX;
+  // The first RMAX training points of a thread (rows t, t + 256, ...) are loaded ONCE per launch - a launch is hundreds of
+  // leapfrog steps, each of which would otherwise wait for the same global loads again -; points past n carry alpha = 0.
+  // The next 256 lgroups rows live in LDS (every thread its own), and what fits neither is streamed from L2 in every step.
+  constexpr int RMAX = ChainRows<DCAP>::HMC, UNR = ChainRows<DCAP>::STREAM;
   const int nrow = (int)((n + NT - 1) / NT);
+  const int lld = NT * lgroups;
   double cx[RMAX][DCAP], ca[RMAX];
-  if (cached) {
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      const int64_t i = t + NT * r;
-      ca[r] = (i < n) ? alpha[i] : 0.0;
+  for (int r = 0; r < RMAX; ++r) {
+    const int64_t i = t + NT * r;
+    ca[r] = (i < n) ? alpha[i] : 0.0;
 #pragma unroll
-      for (int j = 0; j < DCAP; ++j) cx[r][j] = (j < d && i < n) ? XsT[j * ldx + i] : 0.0;
-    }
+    for (int j = 0; j < DCAP; ++j) cx[r][j] = (j < d && i < n) ? XsT[j * ldx + i] : 0.0;
+  }
+  for (int q = 0; q < lgroups; ++q) {
+    const int64_t i = t + (int64_t)NT * (RMAX + q);
+    for (int j = 0; j < d; ++j) lrows[j * lld + q * NT + t] = (i < n) ? XsT[j * ldx + i] : 0.0;
+    lrows[d * lld + q * NT + t] = (i < n) ? alpha[i] : 0.0;
   }
   __syncthreads();
   for (int it = 0; it < niter; ++it) {
@@ -281,49 +333,46 @@ __global__ __launch_bounds__(NT) void k_hmc_run(const double* __restrict__ XsT, 
       double ms = 0.0, gm[DCAP];
 #pragma unroll
       for (int j = 0; j < DCAP; ++j) gm[j] = 0.0;
-      if (cached) {                                            // this thread's training points stay in registers
+      // one training point: mean and mean-gradient contributions (the difference is formed twice rather than kept)
+      auto point = [&](const double (&xr)[DCAP], double a) {
+        double r2 = 0.0;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          if (r < nrow) {                                      // uniform
-            double df[DCAP];
-            double r2 = 0.0;
-#pragma unroll
-            for (int j = 0; j < DCAP; ++j) {
-              df[j] = (j < d) ? cx[r][j] - xs[j] : 0.0;
-              r2 += df[j] * df[j];
-            }
-            const double kv = kern_eval<KERN>(r2, h.kvar);
-            const double ag = ca[r] * kern_grad_factor<KERN>(r2, h.kvar, kv);
-            ms += ca[r] * kv;
-#pragma unroll
-            for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
-          }
+        for (int j = 0; j < DCAP; ++j) {
+          const double df = (j < d) ? xr[j] - xs[j] : 0.0;
+          r2 += df * df;
         }
-      } else {
-        for (int64_t i = t; i < n; i += NT) {
-          double df[DCAP];
-          double r2 = 0.0;
+        const double kv = kern_eval<KERN>(r2, h.kvar);
+        const double ag = a * kern_grad_factor<KERN>(r2, h.kvar, kv);
+        ms += a * kv;
 #pragma unroll
-          for (int j = 0; j < DCAP; ++j) {
-            df[j] = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
-            r2 += df[j] * df[j];
-          }
-          const double kv = kern_eval<KERN>(r2, h.kvar);
-          const double a = alpha[i];
-          const double ag = a * kern_grad_factor<KERN>(r2, h.kvar, kv);
-          ms += a * kv;
+        for (int j = 0; j < DCAP; ++j) gm[j] += ag * ((j < d) ? xr[j] - xs[j] : 0.0);
+      };
 #pragma unroll
-          for (int j = 0; j < DCAP; ++j) gm[j] += ag * df[j];
+      for (int r = 0; r < RMAX; ++r)
+        if (r < nrow) point(cx[r], ca[r]);                     // (uniform) this thread's points in registers,
+      for (int q = 0; q < lgroups; ++q) {                      // in LDS,
+        double xr[DCAP];
+#pragma unroll
+        for (int j = 0; j < DCAP; ++j) xr[j] = (j < d) ? lrows[j * lld + q * NT + t] : 0.0;
+        point(xr, lrows[d * lld + q * NT + t]);
+      }
+      for (int64_t i = t + (int64_t)NT * (RMAX + lgroups); i < n; i += UNR * NT) {  // and streamed: ascending rows throughout
+        double xr[UNR][DCAP], ar[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {                                // (all loads of the group first)
+          const int64_t iq = i + q * NT;
+          ar[q] = (iq < n) ? alpha[iq] : 0.0;
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) xr[q][j] = (j < d && iq < n) ? XsT[j * ldx + iq] : 0.0;
         }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) point(xr[q], ar[q]);
       }
       ms = wave_sum(ms);
       if (lane == 0) red[wave][DCAP] = ms;
-#pragma unroll
-      for (int j = 0; j < DCAP; ++j) {
-        if (j < d) {
-          const double v = wave_sum(gm[j]);
-          if (lane == 0) red[wave][j] = v;
-        }
+      {
+        const double v = wave_sum_components<DCAP>(gm, lane);
+        if ((lane & (64 / DCAP - 1)) == 0) red[wave][lane / (64 / DCAP)] = v;
       }
       // classifier gate (clf_gp.py:173-205): an infeasible point has mean = minus_inf and no mean gradient - its
       // trajectory ends in a state that the Metropolis test never accepts
@@ -347,7 +396,7 @@ __global__ __launch_bounds__(NT) void k_hmc_run(const double* __restrict__ XsT, 
         g[t] = gv;
         pm[t] += ((s < L - 1) ? eps : 0.5 * eps) * gv;
       }
-      if (wave == 1) {                                         // (wave 0 is busy with the gradient lanes)
+      if (wave == 1 && s == L - 1) {                           // the end point's log-density (wave 0 has the gradient lanes)
         double jl = (lane < d) ? log(x[lane]) + log1p(-x[lane]) : 0.0;
         jl = wave_sum(jl);
         if (lane == 0) {
@@ -431,38 +480,44 @@ __global__ __launch_bounds__(NT) void k_hmc_run(const double* __restrict__ XsT, 
 //   X    [P][d]  in: start points, out: end points        logl [P]  in / out: physical-unit mean at the point
 //   nacc [P]     accepted steps                            nin  [P]  proposals inside the cube (= surrogate calls)
 //   dbg  [P][d]  the LAST proposal of every walker (tests)                                             (may be null)
-template <int KERN, int DCAP, int NT>
-__global__ __launch_bounds__(NT) void k_rwalk(const double* __restrict__ XsT, int64_t ldx, int64_t n,
-                                              const double* __restrict__ alpha, Hyper h, double* __restrict__ X,
-                                              double* __restrict__ logl, const double* __restrict__ step, double lstar,
-                                              int walks, unsigned long long seed, double ystd, double ymean,
-                                              int* __restrict__ nacc, int* __restrict__ nin, double* __restrict__ dbg,
-                                              Gate gt) {
-  constexpr int NW = NT / 64;
-  __shared__ double x[DCAP], xp[DCAP], xs[DCAP], z[DCAP], red[NW], gred[4], lx;
+template <int KERN, int DCAP>
+__global__ __launch_bounds__(256) void k_rwalk(const double* __restrict__ XsT, int64_t ldx, int64_t n,
+                                               const double* __restrict__ alpha, Hyper h, double* __restrict__ X,
+                                               double* __restrict__ logl, const double* __restrict__ step, double lstar,
+                                               int walks, unsigned long long seed, double ystd, double ymean,
+                                               int* __restrict__ nacc, int* __restrict__ nin, double* __restrict__ dbg,
+                                               Gate gt, int lgroups) {
+  constexpr int NT = 256, NW = NT / 64;
+  extern __shared__ double lrows[];
+  __shared__ double x[DCAP], xp[DCAP], xs[DCAP], z[DCAP], red[NW], gred[4], lx, stp[DCAP * DCAP];
   __shared__ int inside_s, na_s, ni_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t c = blockIdx.x;
   const int d = h.d;
   if (t < d) x[t] = X[c * d + t];
+  for (int k = t; k < d * d; k += NT) stp[k] = step[k];               // (read in every step: keep it in LDS)
   if (t == 0) {
     lx = logl[c];
     na_s = 0;
     ni_s = 0;
   }
   const unsigned long long ckey = hmc_mix64(seed ^ hmc_mix64((unsigned long long)c));
-  constexpr int RMAX = 64 / DCAP;
-  const bool cached = n <= (int64_t)NT * RMAX;
+  // training points in registers, in LDS and streamed, like k_hmc_run (only the mean is needed here)
+  constexpr int RMAX = ChainRows<DCAP>::WALK, UNR = ChainRows<DCAP>::STREAM;
   const int nrow = (int)((n + NT - 1) / NT);
+  const int lld = NT * lgroups;
   double cx[RMAX][DCAP], ca[RMAX];
-  if (cached) {
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      const int64_t i = t + NT * r;
-      ca[r] = (i < n) ? alpha[i] : 0.0;
+  for (int r = 0; r < RMAX; ++r) {
+    const int64_t i = t + NT * r;
+    ca[r] = (i < n) ? alpha[i] : 0.0;
 #pragma unroll
-      for (int j = 0; j < DCAP; ++j) cx[r][j] = (j < d && i < n) ? XsT[j * ldx + i] : 0.0;
-    }
+    for (int j = 0; j < DCAP; ++j) cx[r][j] = (j < d && i < n) ? XsT[j * ldx + i] : 0.0;
+  }
+  for (int q = 0; q < lgroups; ++q) {
+    const int64_t i = t + (int64_t)NT * (RMAX + q);
+    for (int j = 0; j < d; ++j) lrows[j * lld + q * NT + t] = (i < n) ? XsT[j * ldx + i] : 0.0;
+    lrows[d * lld + q * NT + t] = (i < n) ? alpha[i] : 0.0;
   }
   __syncthreads();
   for (int s = 0; s < walks; ++s) {
@@ -472,49 +527,57 @@ __global__ __launch_bounds__(NT) void k_rwalk(const double* __restrict__ XsT, in
       z[t] = sqrt(-2.0 * log(a)) * cos(6.283185307179586 * b);
     }
     __syncthreads();
-    if (t < d) {
-      double v = x[t];
-      for (int j = 0; j <= t; ++j) v += step[t * d + j] * z[j];          // (lower-triangular factor)
-      xp[t] = v;
-      xs[t] = v / h.ls[t];
-    }
-    __syncthreads();
-    if (t == 0) {
-      int in = 1;
-      for (int j = 0; j < d; ++j) in = in && (xp[j] >= 0.0) && (xp[j] <= 1.0);
-      inside_s = in;
-      ni_s += in;
+    if (wave == 0) {                                                       // (d <= 32: the coordinates live in wave 0)
+      bool in = true;
+      if (t < d) {
+        double v = x[t];
+        for (int j = 0; j <= t; ++j) v += stp[t * d + j] * z[j];            // (lower-triangular factor)
+        xp[t] = v;
+        xs[t] = v / h.ls[t];
+        in = (v >= 0.0) && (v <= 1.0);
+      }
+      const int all_in = __all(in);
+      if (t == 0) {
+        inside_s = all_in;
+        ni_s += all_in;
+      }
     }
     __syncthreads();
     if (inside_s) {                                                        // (uniform: a proposal outside costs no evaluation)
       double ms = 0.0;
-      if (cached) {
+      auto point = [&](const double (&xr)[DCAP], double a) {
+        double r2 = 0.0;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          if (r < nrow) {
-            double r2 = 0.0;
-#pragma unroll
-            for (int j = 0; j < DCAP; ++j) {
-              const double df = (j < d) ? cx[r][j] - xs[j] : 0.0;
-              r2 += df * df;
-            }
-            ms += ca[r] * kern_eval<KERN>(r2, h.kvar);
-          }
+        for (int j = 0; j < DCAP; ++j) {
+          const double df = (j < d) ? xr[j] - xs[j] : 0.0;
+          r2 += df * df;
         }
-      } else {
-        for (int64_t i = t; i < n; i += NT) {
-          double r2 = 0.0;
+        ms += a * kern_eval<KERN>(r2, h.kvar);
+      };
 #pragma unroll
-          for (int j = 0; j < DCAP; ++j) {
-            const double df = (j < d) ? XsT[j * ldx + i] - xs[j] : 0.0;
-            r2 += df * df;
-          }
-          ms += alpha[i] * kern_eval<KERN>(r2, h.kvar);
+      for (int r = 0; r < RMAX; ++r)
+        if (r < nrow) point(cx[r], ca[r]);
+      for (int q = 0; q < lgroups; ++q) {
+        double xr[DCAP];
+#pragma unroll
+        for (int j = 0; j < DCAP; ++j) xr[j] = (j < d) ? lrows[j * lld + q * NT + t] : 0.0;
+        point(xr, lrows[d * lld + q * NT + t]);
+      }
+      for (int64_t i = t + (int64_t)NT * (RMAX + lgroups); i < n; i += UNR * NT) {
+        double xr[UNR][DCAP], ar[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {                                // (all loads of the group first)
+          const int64_t iq = i + q * NT;
+          ar[q] = (iq < n) ? alpha[iq] : 0.0;
+#pragma unroll
+          for (int j = 0; j < DCAP; ++j) xr[q][j] = (j < d && iq < n) ? XsT[j * ldx + iq] : 0.0;
         }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) point(xr[q], ar[q]);
       }
       ms = wave_sum(ms);
       if (lane == 0) red[wave] = ms;
-      if (gt.n_sv > 0 && t < 256) {
+      if (gt.n_sv > 0) {
         const double gs = gate_partial<DCAP>(gt, xp, d, t);
         if (lane == 0) gred[wave] = gs;
       }

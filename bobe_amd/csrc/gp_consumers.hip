@@ -8,7 +8,18 @@
 using namespace bobe;
 
 namespace bobe {
-void configure_consumer_kernels() {}      // (no kernel of this unit needs more than the default dynamic LDS)
+void configure_consumer_kernels() {       // (the chain kernels keep training points in up to 150 KB of LDS)
+  static bool done[64] = {false};
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || done[dev]) return;
+#define BIG(KE, DC)                                         \
+  allow_big_lds((k_hmc_run<KE, DC>), CHAIN_LDS_BYTES);      \
+  allow_big_lds((k_rwalk<KE, DC>), CHAIN_LDS_BYTES)
+  BIG(0, 8); BIG(0, 16); BIG(0, 32); BIG(1, 8); BIG(1, 16); BIG(1, 32);
+#undef BIG
+  done[dev] = true;
+}
 }  // namespace bobe
 
 // ---- classifier gate ------------------------------------------------------------------------------------------------
@@ -142,22 +153,20 @@ void bobe_gp::hmc_run(int64_t P, double* state, double* adapt, const double* inv
   HIPCHK(hipMemcpyAsync(dA, adapt, na * sizeof(double), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(dI, inv_mass, (size_t)d * sizeof(double), hipMemcpyHostToDevice, stream));
   const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
-  // 512 threads per chain from 1025 training points on: twice the points in registers, half a step's loop per thread
-#define HR1(KE, DC, NTH)                                                                                            \
-  hipLaunchKernelGGL((k_hmc_run<KE, DC, NTH>), dim3((unsigned)P), dim3(NTH), 0, stream, (const double*)XsT.d(), Np, N, \
-                     (const double*)alpha.d(), hyp, P, dS, dA, (const double*)dI, (unsigned long long)seed, it0, niter, \
-                     do_adapt, y_std, y_mean, temp, hist_from, hist ? dH : nullptr, thin, keep ? dK : nullptr,       \
-                     dbg ? dD : nullptr, gate)
-#define HR(KE, DC)                            \
-  do {                                        \
-    if (N > 1024) HR1(KE, DC, 512); else HR1(KE, DC, 256); \
+  // training points of a chain's workgroup: registers first, then LDS (chain_lds_groups), the rest streamed
+#define HR(KE, DC)                                                                                                  \
+  do {                                                                                                              \
+    const int lg = chain_lds_groups(N, d, ChainRows<DC>::HMC);                                                      \
+    hipLaunchKernelGGL((k_hmc_run<KE, DC>), dim3((unsigned)P), dim3(256), (size_t)lg * 256 * (d + 1) * sizeof(double), \
+                       stream, (const double*)XsT.d(), Np, N, (const double*)alpha.d(), hyp, P, dS, dA,             \
+                       (const double*)dI, (unsigned long long)seed, it0, niter, do_adapt, y_std, y_mean, temp,      \
+                       hist_from, hist ? dH : nullptr, thin, keep ? dK : nullptr, dbg ? dD : nullptr, gate, lg);    \
   } while (0)
   if (hyp.kern == 0) {
     if (dcap == 8) HR(0, 8); else if (dcap == 16) HR(0, 16); else HR(0, 32);
   } else {
     if (dcap == 8) HR(1, 8); else if (dcap == 16) HR(1, 16); else HR(1, 32);
   }
-#undef HR1
 #undef HR
   LAUNCH_CHECK();
   HIPCHK(hipMemcpyAsync(state, dS, ns * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -186,13 +195,13 @@ void bobe_gp::rwalk(int64_t P, double* Xw, double* logl, const double* step, dou
   HIPCHK(hipMemcpyAsync(dL, logl, (size_t)P * sizeof(double), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(dS, step, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, stream));
   const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
-#define RW1(KE, DC, NTH)                                                                                           \
-  hipLaunchKernelGGL((k_rwalk<KE, DC, NTH>), dim3((unsigned)P), dim3(NTH), 0, stream, (const double*)XsT.d(), Np, N, \
-                     (const double*)alpha.d(), hyp, dX, dL, (const double*)dS, lstar, walks, (unsigned long long)seed, \
-                     y_std, y_mean, dA, dN, dbg ? dD : nullptr, gate)
-#define RW(KE, DC)                            \
-  do {                                        \
-    if (N > 1024) RW1(KE, DC, 512); else RW1(KE, DC, 256); \
+#define RW(KE, DC)                                                                                                 \
+  do {                                                                                                             \
+    const int lg = chain_lds_groups(N, d, ChainRows<DC>::WALK);                                                    \
+    hipLaunchKernelGGL((k_rwalk<KE, DC>), dim3((unsigned)P), dim3(256), (size_t)lg * 256 * (d + 1) * sizeof(double), \
+                       stream, (const double*)XsT.d(), Np, N, (const double*)alpha.d(), hyp, dX, dL,               \
+                       (const double*)dS, lstar, walks, (unsigned long long)seed, y_std, y_mean, dA, dN,           \
+                       dbg ? dD : nullptr, gate, lg);                                                              \
   } while (0)
   if (hyp.kern == 0) {
     if (dcap == 8) RW(0, 8); else if (dcap == 16) RW(0, 16); else RW(0, 32);
@@ -200,7 +209,6 @@ void bobe_gp::rwalk(int64_t P, double* Xw, double* logl, const double* step, dou
     if (dcap == 8) RW(1, 8); else if (dcap == 16) RW(1, 16); else RW(1, 32);
   }
 #undef RW
-#undef RW1
   LAUNCH_CHECK();
   HIPCHK(hipMemcpyAsync(Xw, dX, pd * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIPCHK(hipMemcpyAsync(logl, dL, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -50,7 +50,7 @@ def test_destroyed_handles_return_their_device_memory():
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info(0)[0]
     for s in range(2, 10):
-        _exercise(s, 600 if s % 2 else 1400, 5)            # (1400: above the graph / 512-thread sampler thresholds' lower sizes)
+        _exercise(s, 600 if s % 2 else 1400, 5)            # (two sizes: every buffer is re-sized on the way)
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(0)[0]
     # one leaked N x N buffer per handle would be 8 x (2.9 ... 15.7 MB); the allowance is the allocator's granularity

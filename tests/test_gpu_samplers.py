@@ -175,10 +175,11 @@ def test_device_chain_iteration_replayed_on_the_host():
     """One iteration of bobe_gp_hmc_run with its draws (momentum, L, uniform) read back: the same trajectory through
     bobe_gp_hmc_leapfrog and the Metropolis rule on the host must give the same acceptance probability and the same
     next state.  Then: launch boundaries and batch size do not change a chain (counter-based random numbers).  The sizes
-    cover both workgroup shapes of k_hmc_run (256 threads per chain up to 1024 training points, 512 above) with the training
-    set in registers (N <= threads x 64 / DCAP) and streamed from memory (N = 2500 at d = 12)."""
+    cover the three homes of a chain's training points in k_hmc_run (consumer_kernels.hpp, ChainRows): registers only,
+    registers + LDS (N = 2500 at d = 12), and a streamed rest (N = 3000 at d = 12; N = 1500 at d = 20, the 32-wide variant)."""
     from bobe_amd import GP
-    for kernel, d, n in (("rbf", 2, 200), ("matern", 6, 200), ("rbf", 12, 200), ("rbf", 6, 1500), ("matern", 12, 2500)):
+    for kernel, d, n in (("rbf", 2, 200), ("matern", 6, 200), ("rbf", 12, 200), ("rbf", 6, 1500), ("matern", 12, 2500),
+                         ("rbf", 12, 3000), ("matern", 20, 1500)):
         rng = np.random.default_rng(10 + d)
         X = rng.uniform(size=(n, d))
         y = -15.0 * np.sum((X - 0.5) ** 2, axis=1)
@@ -243,8 +244,8 @@ def test_device_random_walks_of_nested_sampling():
     the device and stepped from the host."""
     from bobe_amd import GP, samplers
     from bobe_amd.clf_gp import GPwithClassifier
-    for kernel, d, n in (("rbf", 3, 150), ("matern", 10, 1300)):
-        rng = np.random.default_rng(20 + d)
+    for kernel, d, n in (("rbf", 3, 150), ("matern", 10, 1300), ("rbf", 20, 1600), ("matern", 12, 4000)):   # (registers;
+        rng = np.random.default_rng(20 + d)                                   # registers + LDS; + a streamed rest)
         X = rng.uniform(size=(n, d))
         y = -40.0 * np.sum((X - 0.5) ** 2, axis=1)
         gp = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=np.full(d, 0.6), kernel_variance=2.0)

@@ -2,6 +2,7 @@
 
   python tools/config5_run.py [key=value ...]
      max_evals=3200 max_gp=4096 thr=1.0 n_iters=2 batch=5 ns_every=50 min_evals=400 clf=0 seed=7 mc=256 fit_every=10
+     dim=10 (the same function in another dimension)  truth=1 (only the nested sampling of the true likelihood)
 Prints every nested-sampling result (N, logZ mean / upper / lower, half-width), the state at the checkpoints
 N = 600, 1200, 2400, 4096 (phase timers so far) and the final line.  `truth` = nested sampling of the TRUE likelihood
 with the same sampler (2000 live points): logZ = -15.6 +- 0.1 (profiles/r03_configs_1_and_5_runs.txt)."""
@@ -15,18 +16,37 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bobe_amd import samplers  # noqa: E402
 from bobe_amd.bo import BOBE  # noqa: E402
 
-D, LO, HI = 10, -2.0, 2.0
+LO, HI = -2.0, 2.0
 opt = dict(max_evals=3200, max_gp=4096, thr=1.0, n_iters=2, batch=5, ns_every=50, min_evals=400, clf=0, seed=7, mc=256,
-           fit_every=10, sobol=64, warmup=256, hmc=512)
+           fit_every=10, sobol=64, warmup=256, hmc=512, dim=10, truth=0)
 for a in sys.argv[1:]:
     k, v = a.split("=")
     opt[k] = type(opt[k])(float(v)) if k in opt else v
+D = opt["dim"]
 
 
 def rosen10(x):
     x = np.asarray(x)
     return -float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1.0 - x[:-1]) ** 2)) / 20.0
 
+
+if opt["truth"]:
+    class Truth:                                            # the sampler's view of a surrogate, on the true likelihood
+        ndim = D
+
+        def predict_mean_batched(self, u):
+            x = LO + (HI - LO) * np.atleast_2d(u)
+            return -np.sum(100.0 * (x[:, 1:] - x[:, :-1] ** 2) ** 2 + (1.0 - x[:, :-1]) ** 2, axis=1) / 20.0
+
+        def predict_var_batched(self, u):                   # (no surrogate error: upper = lower = mean)
+            return np.zeros(len(np.atleast_2d(u)))
+
+    for sd in (0, 1):
+        t0 = time.time()
+        _, lz, ok = samplers.nested_sampling(Truth(), nlive=2000, rng=np.random.default_rng(sd), device_walks=False)
+        print(f"truth dim={D} seed {sd}: logZ {lz['mean']:.3f} +- {lz.get('dlogz_sampler', float('nan')):.3f} ncall {lz.get('ncall')} "
+              f"ok {ok} ({time.time() - t0:.0f}s)", flush=True)
+    sys.exit(0)
 
 checkpoints = [600, 1200, 2400, 4096]
 t_start = time.time()
