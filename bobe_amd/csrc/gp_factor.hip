@@ -561,11 +561,13 @@ void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, 
   solve_alpha(linv, wv, al, part.d());
 }
 
-int bobe_gp::read_info() {
-  int v = 0;
-  HIPCHK(hipMemcpyAsync(&v, info.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-  sync();
-  return v;
+// the text of a BOBE_NOT_PD status: a non-positive pivot (the factorisation's info word), or pivots below pivot_floor
+std::string bobe_gp::not_pd_text(int inf, double min_diag) {
+  if (inf != 0x7f7f7f7f) return "kernel matrix not positive definite at column " + std::to_string(inf - 1);
+  char buf[160];
+  std::snprintf(buf, sizeof buf, "kernel matrix numerically singular: smallest pivot %.3g is below 64 ulp of its diagonal",
+                min_diag * min_diag);
+  return buf;
 }
 
 void bobe_gp::ensure_slots(int n) {
@@ -625,11 +627,12 @@ void bobe_gp::mll_enqueue_body(const Hyper& h, bool want_grad, const Hyper* hdev
                        res.d(), (int64_t)0, (int64_t)0, (int64_t)0, (const int*)info.p);
   }
   LAUNCH_CHECK();
-  HIPCHK(hipMemcpyAsync(h_res, res.p, 101 * sizeof(double), hipMemcpyDeviceToHost, stream));   // [100] = info (k_mll_terms)
+  HIPCHK(hipMemcpyAsync(h_res, res.p, 102 * sizeof(double), hipMemcpyDeviceToHost, stream));   // [100] = info, [101] = min L_jj
 }
 
 void bobe_gp::mll_enqueue(const Hyper& h, bool want_grad) {
   const Tuning& tu = tuning();
+  h_res[110] = pivot_floor(h);              // (host side of the pinned block, beyond what the device copy writes: read at collect)
   // Up to graph_max_n points an evaluation is tens of kernels of a few microseconds each, and with several slots
   // in flight the host cannot enqueue them as fast as the GPU retires them: a slot replays its pipeline as one
   // graph (N = 64 / 512 / 2048 with four in flight: 42 / 107 / 419 us per evaluation instead of 66 / 141 / 553).
@@ -676,11 +679,11 @@ int bobe_gp::slot_collect(Slot& sl, double* mll, double* grad) {
   const double* hr = sl.h_res;
   int inf;
   std::memcpy(&inf, hr + 100, sizeof(int));
-  if (inf != 0x7f7f7f7f) {
+  if (inf != 0x7f7f7f7f || !pivots_resolved(hr[101], hr[110])) {
     *mll = std::nan("");
     if (grad)
       for (int j = 0; j <= d; ++j) grad[j] = std::nan("");
-    g_err = "kernel matrix not positive definite at column " + std::to_string(inf - 1);
+    g_err = not_pd_text(inf, hr[101]);
     return BOBE_NOT_PD;
   }
   *mll = -0.5 * hr[0] - hr[1] - 0.5 * (double)N * std::log(2.0 * M_PI);
@@ -693,11 +696,11 @@ int bobe_gp::mll_collect(double* mll, double* grad) {
   sync();
   int inf;
   std::memcpy(&inf, h_res + 100, sizeof(int));
-  if (inf != 0x7f7f7f7f) {
+  if (inf != 0x7f7f7f7f || !pivots_resolved(h_res[101], h_res[110])) {
     *mll = std::nan("");
     if (grad)
       for (int j = 0; j <= d; ++j) grad[j] = std::nan("");
-    g_err = "kernel matrix not positive definite at column " + std::to_string(inf - 1);
+    g_err = not_pd_text(inf, h_res[101]);
     return BOBE_NOT_PD;
   }
   *mll = -0.5 * h_res[0] - h_res[1] - 0.5 * (double)N * std::log(2.0 * M_PI);
@@ -765,11 +768,11 @@ int bobe_gp::mll_lockstep_collect(int B, double* mll, double* grad, int* status)
     int st = BOBE_OK;
     int inf_b;
     std::memcpy(&inf_b, hr + 100, sizeof(int));
-    if (inf_b != 0x7f7f7f7f) {
+    if (inf_b != 0x7f7f7f7f || !pivots_resolved(hr[101], pivot_floor(bw.h_hyp[b]))) {
       mll[b] = std::nan("");
       if (gb)
         for (int j = 0; j <= d; ++j) gb[j] = std::nan("");
-      g_err = "kernel matrix not positive definite at column " + std::to_string(inf_b - 1);
+      g_err = not_pd_text(inf_b, hr[101]);
       st = BOBE_NOT_PD;
       worst = st;
     } else {
@@ -812,10 +815,18 @@ void bobe_gp::set_data(const double* Xin, const double* ys, int64_t n) {
 int bobe_gp::factor_state() {
   use();
   factor_into(hyp, XsT.d(), A.d(), Linv.d(), w.d(), alpha.d());
-  const int inf = read_info();
+  // the info word and the smallest pivot's root in one copy (k_mll_terms: res[100], res[101])
+  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w.d(), (const double*)A.d(), Np, Np, res.d(),
+                     (int64_t)0, (int64_t)0, (int64_t)0, (const int*)info.p);
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(h_res, res.p, 102 * sizeof(double), hipMemcpyDeviceToHost, stream));
+  sync();
+  int inf;
+  std::memcpy(&inf, h_res + 100, sizeof(int));
+  const double min_diag = h_res[101];
   factored = true;
   forget_z();
-  not_pd = (inf != 0x7f7f7f7f);
+  not_pd = (inf != 0x7f7f7f7f) || !pivots_resolved(min_diag, pivot_floor(hyp));
   if (not_pd) {
     const double nan = std::nan("");
     fill(A.d(), Np * Np, nan);
@@ -823,7 +834,7 @@ int bobe_gp::factor_state() {
     fill(alpha.d(), Np, nan);
     LAUNCH_CHECK();
     sync();
-    g_err = "kernel matrix not positive definite at column " + std::to_string(inf - 1);
+    g_err = not_pd_text(inf, min_diag);
     return BOBE_NOT_PD;
   }
   return BOBE_OK;

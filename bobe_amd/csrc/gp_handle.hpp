@@ -79,6 +79,18 @@ struct DBuf {
   double* d() const { return static_cast<double*>(p); }
 };
 
+// The factorisation's rank test.  A pivot (L_jj^2) below 64 ulp of the kernel matrix's diagonal k(x,x) + noise is as large as
+// the rounding accumulated in its column's update at N of a few thousand: it carries no information, and neither does the
+// log-determinant built on it (a too small one - the optimiser is drawn to exactly these hyper-parameters).  Such a
+// factorisation counts as NOT positive definite, like one with a non-positive pivot: NaN outputs, BOBE_NOT_PD.  (LAPACK's
+// dpotrf, the reference's Cholesky, tests the sign only and fails or passes on the last bit in this regime)
+inline double pivot_floor(const Hyper& h) {
+  const double f = 64.0 * 2.220446049250313e-16 * (h.kvar + h.noise);
+  return f < 0.25 ? f : 0.25;                        // (the identity padding's pivots are 1)
+}
+// min_diag: the smallest L_jj of a factor (k_mll_terms, res[101]); NaN counts as failed
+inline bool pivots_resolved(double min_diag, double floor) { return min_diag * min_diag >= floor; }
+
 template <typename K>
 void allow_big_lds(K kernel, int bytes) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -333,7 +345,7 @@ struct bobe_gp {
                    int64_t bsP = 0, const double* rhs = nullptr, int64_t bsY = 0);
   void factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al,
                    const Hyper* hdev = nullptr);
-  int read_info();
+  static std::string not_pd_text(int inf, double min_diag);
   int factor_state();                                  // bobe_gp_factor
   void copy_out_matrix(const double* src, double* dst, int lower_only);
   void get_chol(double* L, double* alpha_out);

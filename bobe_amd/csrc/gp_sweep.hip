@@ -476,7 +476,9 @@ int bobe_gp::append(const double* X_new, int64_t b, const double* y_all) {
       }
       hK[i * b + j] = kv + (i == j ? hyp.noise : 0.0) - hG[i * b + j];
     }
-  // L22 = chol(S), L22inv by forward substitution; a non-positive pivot = the appended matrix is not positive definite
+  // L22 = chol(S), L22inv by forward substitution; a pivot at or below the rank test's floor (pivot_floor; 0 at least) = the
+  // appended matrix is not positive definite
+  const double piv_floor = pivot_floor(hyp);
   std::vector<double> s22((size_t)2 * b * b, 0.0);
   double* L22 = s22.data();
   double* Li = s22.data() + b * b;
@@ -484,7 +486,7 @@ int bobe_gp::append(const double* X_new, int64_t b, const double* y_all) {
   for (int64_t j = 0; j < b && pd; ++j) {
     double dj = hK[j * b + j];
     for (int64_t k = 0; k < j; ++k) dj -= L22[j * b + k] * L22[j * b + k];
-    if (!(dj > 0.0)) { pd = false; break; }
+    if (!(dj > 0.0) || dj < piv_floor) { pd = false; break; }
     L22[j * b + j] = std::sqrt(dj);
     for (int64_t i = j + 1; i < b; ++i) {
       double v = hK[i * b + j];

@@ -213,7 +213,7 @@ static __global__ void k_colsum_parts(const double* __restrict__ part, int64_t l
 }
 
 // ---- scalar reductions ------------------------------------------------------------------------------
-// res[0] = sum_i w_i^2 ; res[1] = sum_i log L_ii        (single workgroup, fixed order)
+// res[0] = sum_i w_i^2 ; res[1] = sum_i log L_ii ; res[101] = min_i L_ii        (single workgroup, fixed order)
 __device__ __forceinline__ void mll_terms_body(int slot, const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
                                                    int64_t np, double* __restrict__ res, int64_t bsW,
                                                    int64_t bsL, int64_t bsR, const int* __restrict__ info) {
@@ -222,22 +222,28 @@ __device__ __forceinline__ void mll_terms_body(int slot, const double* __restric
   res += slot * bsR;
   // (the factorisation's info word rides along in res[100], so that one copy brings everything to the host)
   if (info && threadIdx.x == 0) reinterpret_cast<int*>(res + 100)[0] = info[slot];
-  __shared__ double r0[4], r1[4];
-  double a = 0.0, b = 0.0;
+  __shared__ double r0[4], r1[4], r2[4];
+  double a = 0.0, b = 0.0, mn = 1.0;                  // (the padding's diagonal is 1)
   for (int64_t i = threadIdx.x; i < np; i += 256) {
+    const double lii = L[i * ld + i];
     a += w[i] * w[i];
-    b += log(L[i * ld + i]);
+    b += log(lii);
+    mn = fmin(mn, lii);
   }
   a = wave_sum(a);
   b = wave_sum(b);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, __shfl_xor(mn, o, 64));
   if ((threadIdx.x & 63) == 0) {
     r0[threadIdx.x >> 6] = a;
     r1[threadIdx.x >> 6] = b;
+    r2[threadIdx.x >> 6] = mn;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     res[0] = ((r0[0] + r0[1]) + r0[2]) + r0[3];
     res[1] = ((r1[0] + r1[1]) + r1[2]) + r1[3];
+    res[101] = fmin(fmin(r2[0], r2[1]), fmin(r2[2], r2[3]));      // smallest pivot's root: the hosts's rank test (pivot_floor)
   }
 }
 static __global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w, const double* __restrict__ L, int64_t ld,

@@ -15,6 +15,10 @@
  *   - return value: 0 ok; > 0 numerical condition (BOBE_NOT_PD: outputs are NaN, like XLA's
  *     Cholesky, so np.isfinite filters such as optim.py:328,341 keep working); < 0 usage / HIP error,
  *     text in bobe_last_error().  Nothing throws or aborts across this boundary;
+ *   - BOBE_NOT_PD is raised by a pivot <= 0 (what LAPACK's dpotrf, the reference's Cholesky, reports) AND by a positive pivot
+ *     below 64 ulp of the kernel matrix's diagonal k(x,x) + noise: such a pivot is the rounding of its column's update, the
+ *     log-determinant built on it is too small, and a fit is drawn to exactly those hyper-parameters (dpotrf passes or fails
+ *     on the last bit there).  With the reference's default noise of 1e-8 this bounds the usable kernel variance near 1e6;
  *   - a handle is not thread-safe; distinct handles are independent (own stream).
  *   - limits: d <= 32.
  */

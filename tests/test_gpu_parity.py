@@ -129,6 +129,58 @@ def test_not_positive_definite_gives_nan_not_exception():
     assert np.isnan(og.neg_mll(np.log([0.5, 0.5, 1.0])))
 
 
+def test_numerically_singular_kernel_matrix_counts_as_not_positive_definite():
+    """The factorisation's rank test (gp_handle.hpp, pivot_floor): with the default noise of 1e-8 and a kernel variance
+    of 1e7 at long length scales every trailing pivot is rounding noise (64 ulp of the diagonal is 1.4e-7 > noise); the
+    log-determinant built on them is too small and draws the optimiser in (profiles/r04_config5.txt, section 9).  LAPACK -
+    the reference's Cholesky - fails or passes on the last bit there; the library says BOBE_NOT_PD every time: NaN value and
+    gradient from every evaluation path, a NaN state from bobe_gp_factor.  Moderate hyper-parameters on the same data are
+    untouched and agree with the oracle."""
+    from bobe_amd import _lib
+    rng = np.random.default_rng(3)
+    n, d = 500, 5
+    X = rng.uniform(size=(n, d))
+    y = -np.sum((X - 0.4) ** 2, axis=1) - 0.3 * np.prod(X[:, :2], axis=1)
+    gp = GP(X, y, noise=1e-8, lengthscales=np.full(d, 0.5), kernel_variance=1.0)
+    og = O.OracleGP(X, y, noise=1e-8, lengthscales=np.full(d, 0.5), kernel_variance=1.0)
+    assert not gp.not_pd
+    good, bad = (np.full(d, 0.5), 1.0), (np.full(d, 3.5), 1e7)
+    m, g = gp.mll_data(*good)
+    mo, go = O.cycle_value_and_grad(og.train_x, og.train_y.reshape(-1), good[0], good[1], 1e-8)
+    assert abs(m - mo) <= 1e-9 * abs(mo) and np.all(np.isfinite(g))
+    mb, gb = gp.mll_data(*bad)
+    assert np.isnan(mb) and np.all(np.isnan(gb))
+    ms, gs = gp.mll_data(*bad, slot=2)
+    assert np.isnan(ms) and np.all(np.isnan(gs))
+    mm, gg = gp.mll_data_batch(np.array([good[0], bad[0], good[0]]), np.array([good[1], bad[1], good[1]]))
+    assert mm[0] == m and mm[2] == m and np.isnan(mm[1]) and np.all(np.isnan(gg[1])) and np.array_equal(gg[0], g)
+    st = gp._lib.bobe_gp_mll(gp._h, _lib.ptr(bad[0]), bad[1], C.byref(C.c_double()), None)
+    assert st == _lib.BOBE_NOT_PD and gp._lib.bobe_last_error()      # (a pivot <= 0 or one below the floor, whichever came first)
+    f, gr = gp.neg_mll_value_and_grad(np.log(np.append(bad[0], bad[1])))
+    assert np.isnan(f) and np.all(np.isnan(gr))                                 # what optimize_scipy's isfinite filter sees
+    gp.update_hyperparams(np.log(np.append(bad[0], bad[1])))                    # the state: NaN factor, NaN predictions
+    assert gp.not_pd and np.all(np.isnan(gp.alphas)) and np.all(np.isnan(gp.predict_mean_batched(X[:5])))
+    gp.update_hyperparams(np.log(np.append(good[0], good[1])))                  # and back
+    assert not gp.not_pd and np.allclose(gp.predict_mean_batched(X[:5]), og.predict_mean_batched(X[:5]), rtol=1e-7, atol=1e-9)
+    # the floor itself, on a pair of points whose second pivot is known: kvar (1 - rho^2) with 1 - rho^2 ~ r^2 = 1e-15 is a
+    # POSITIVE pivot below 64 ulp of the diagonal (1.4e-14): refused; r^2 = 1e-12 is above it: factorised, equal to the oracle
+    for r2, refused in ((1e-15, True), (1e-12, False)):
+        X3 = np.array([[0.3], [0.3 + 0.5 * np.sqrt(r2)], [0.9]])
+        y3 = np.array([0.1, 0.1, -1.0])
+        g3 = GP(X3, y3, noise=0.0, lengthscales=[0.5], kernel_variance=1.0)
+        assert g3.not_pd == refused
+        v3, _ = g3.mll_data(np.array([0.5]), 1.0)
+        if refused:
+            assert np.isnan(v3) and b"numerically singular" in g3._lib.bobe_last_error()
+        else:
+            o3 = O.OracleGP(X3, y3, noise=0.0, lengthscales=[0.5], kernel_variance=1.0)
+            w3, _ = O.cycle_value_and_grad(o3.train_x, o3.train_y.reshape(-1), np.array([0.5]), 1.0, 0.0)
+            assert np.isfinite(v3) and abs(v3 - w3) <= 1e-3 * abs(w3)       # (cond ~ 1e12: three digits is what fp64 leaves)
+    # a fit from the singular corner walks out of it, like the reference's would from a NaN start (optim.py:328, 341)
+    res = gp.fit(x0=np.array([np.log(np.append(bad[0], bad[1])), np.log(np.append(good[0], good[1]))]), maxiter=20)
+    assert np.isfinite(res["mll"]) and np.all(np.isfinite(res["params"]))
+
+
 @pytest.mark.parametrize("kernel,prior,n,d", [("rbf", None, 200, 3), ("matern", None, 333, 4), ("rbf", "DSLP", 150, 2),
                                                ("rbf", "SAAS", 260, 9), ("matern", "SAAS", 140, 17)])
 def test_mll_and_gradient(kernel, prior, n, d):
