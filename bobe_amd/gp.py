@@ -213,10 +213,19 @@ class GP:
         ls = np.asarray(lengthscales, dtype=np.float64)
         if self.lengthscale_prior_spec == "SAAS":
             return P.saas_logprob_and_grad(ls, kernel_variance, tausq)
+        # the reference's default - Uniform on both (gp.py:313, 326) - is a constant with zero gradient: evaluated once (a
+        # fit asks thousands of times), by the same expressions as below so that the value keeps its bits
+        flat = (type(self.kernel_variance_prior_dist), type(self.lengthscale_prior_dist)) == (P.Uniform, P.Uniform)
+        key = (id(self.kernel_variance_prior_dist), id(self.lengthscale_prior_dist), ls.shape)
+        if flat and getattr(self, "_flat_prior_key", None) == key:
+            return self._flat_prior
         lp = float(np.sum(self.kernel_variance_prior_dist.log_prob(kernel_variance)))
         g_kvar = float(np.sum(self.kernel_variance_prior_dist.dlog_prob(kernel_variance)))
         lp += float(np.sum(self.lengthscale_prior_dist.log_prob(ls)))
         g_ls = np.asarray(self.lengthscale_prior_dist.dlog_prob(ls), dtype=np.float64)
+        if flat:
+            g_ls.setflags(write=False)
+            self._flat_prior_key, self._flat_prior = key, (lp, g_ls, g_kvar, 0.0)
         return lp, g_ls, g_kvar, 0.0
 
     def _parse_hyperparams(self, log_params):
