@@ -208,31 +208,86 @@ __device__ __forceinline__ double hmc_u01(unsigned long long bits) {          //
   return ((double)(bits >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
 
-// Sum of D per-lane values over the 64 lanes of a wave, all D at once: a butterfly that halves what a lane holds at every
-// step (the lane keeps the half its bit selects and adds its partner's), log2 D such steps, then a plain butterfly over
-// the remaining lane bits: D - 1 + (6 - log2 D) exchanges instead of 6 D, and one dependency chain instead of D.
-// Returns component (lane >> (6 - log2 D)), complete in every lane of that group; fixed order.
-template <int D, int HLF, int O>
-__device__ __forceinline__ void wave_sum_halve(double (&v)[D], int lane) {
+// ---- wave-level sums of the chain kernels without the LDS crossbar ---------------------------------------------------
+// __shfl_xor is a ds_bpermute (two per double, ~100+ cycles each, six in a row per sum); the chain kernels sit on that
+// latency d + 1 times per leapfrog step.  gfx950 exchanges lanes in the VALU instead: v_permlane32_swap / v_permlane16_swap
+// trade the upper 32 (odd 16) lanes of one register for the lower 32 (even 16) of another, and DPP reads a neighbour within a
+// row of 16 (row_ror:8, row_half_mirror, quad_perm).  Pairings per step: l ^ 32, l ^ 16, l ^ 8, 7 - l within eight, l ^ 2,
+// l ^ 1 - every step joins two lanes that differ in the step's lane bit, so six steps cover the wave.  Fixed order.
+// (Only the chain kernels' own sums: the classifier gate keeps wave_sum, the order it shares with k_gate.)
+constexpr int DPP_ROR8 = 0x128, DPP_HALF_MIRROR = 0x141, DPP_XOR2 = 0x4E /* quad_perm:[2,3,0,1] */,
+              DPP_XOR1 = 0xB1 /* quad_perm:[1,0,3,2] */;
+template <int CTRL>
+__device__ __forceinline__ double dpp_read(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// a[l] + a[l ^ W] in the lanes whose bit W is clear, b[l] + b[l ^ W] in the others (W = 32, 16): one swap per register half
+template <int W>
+__device__ __forceinline__ double swap_add(double a, double b) {
+  const unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a);
+  const unsigned bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+  if constexpr (W == 32) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  } else {
+    const auto lo = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+}
+// step K (0 .. 5, lane bit 32 >> K) on the pair (a, b): the lane keeps a (bit clear) or b (bit set) and adds its partner's
+template <int K>
+__device__ __forceinline__ double chain_halve(double a, double b, int lane) {
+  if constexpr (K == 0) return swap_add<32>(a, b);
+  else if constexpr (K == 1) return swap_add<16>(a, b);
+  else {
+    constexpr int CTRL = K == 2 ? DPP_ROR8 : (K == 3 ? DPP_HALF_MIRROR : (K == 4 ? DPP_XOR2 : DPP_XOR1));
+    const bool up = (lane & (32 >> K)) != 0;
+    return (up ? b : a) + dpp_read<CTRL>(up ? a : b);
+  }
+}
+// the same step on one value held by every lane
+template <int K>
+__device__ __forceinline__ double chain_fold(double r) {
+  if constexpr (K == 0) return swap_add<32>(r, r);
+  else if constexpr (K == 1) return swap_add<16>(r, r);
+  else {
+    constexpr int CTRL = K == 2 ? DPP_ROR8 : (K == 3 ? DPP_HALF_MIRROR : (K == 4 ? DPP_XOR2 : DPP_XOR1));
+    return r + dpp_read<CTRL>(r);
+  }
+}
+// the sum over the wave, in every lane
+__device__ __forceinline__ double chain_wave_sum(double r) {
+  r = chain_fold<0>(r);
+  r = chain_fold<1>(r);
+  r = chain_fold<2>(r);
+  r = chain_fold<3>(r);
+  r = chain_fold<4>(r);
+  return chain_fold<5>(r);
+}
+// Sums of D per-lane values over the wave, all D at once: at every step the lane keeps the half of its values that its
+// step bit selects and adds its partner's (log2 D steps: D - 1 exchanges), then folds the one value left over the remaining
+// bits - one dependency chain of six steps instead of D of them.  Returns component (lane >> (6 - log2 D)), complete in
+// every lane of that group.
+template <int D, int HLF, int K>
+__device__ __forceinline__ void chain_sum_halve(double (&v)[D], int lane) {
   if constexpr (HLF >= 1) {
-    const bool up = (lane & O) != 0;
 #pragma unroll
-    for (int i = 0; i < HLF; ++i) {
-      const double mine = up ? v[HLF + i] : v[i];
-      const double send = up ? v[i] : v[HLF + i];
-      v[i] = mine + __shfl_xor(send, O, 64);
-    }
-    wave_sum_halve<D, HLF / 2, O / 2>(v, lane);
+    for (int i = 0; i < HLF; ++i) v[i] = chain_halve<K>(v[i], v[HLF + i], lane);
+    chain_sum_halve<D, HLF / 2, K + 1>(v, lane);
   }
 }
 template <int D>
 __device__ __forceinline__ double wave_sum_components(double (&v)[D], int lane) {
   static_assert(D == 8 || D == 16 || D == 32, "power of two");
-  wave_sum_halve<D, D / 2, 32>(v, lane);
+  chain_sum_halve<D, D / 2, 0>(v, lane);
   double r = v[0];
-#pragma unroll
-  for (int o = 32 / D; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
-  return r;
+  if constexpr (D == 8) r = chain_fold<3>(r);
+  if constexpr (D <= 16) r = chain_fold<4>(r);
+  return chain_fold<5>(r);
 }
 
 // Training points a thread of a 256-thread chain workgroup keeps in registers for the whole launch (a launch is hundreds
@@ -240,7 +295,7 @@ __device__ __forceinline__ double wave_sum_components(double (&v)[D], int lane) 
 // (One wave per SIMD: the 512 unified registers of a lane hold them; chosen as the largest counts without scratch spills.)
 template <int DCAP>
 struct ChainRows {
-  static constexpr int HMC = DCAP == 8 ? 16 : (DCAP == 16 ? 6 : 2);
+  static constexpr int HMC = DCAP == 8 ? 14 : (DCAP == 16 ? 6 : 2);
   static constexpr int WALK = DCAP == 8 ? 16 : (DCAP == 16 ? 8 : 4);
   static constexpr int STREAM = DCAP == 32 ? 1 : 2;      // streamed rows in flight per thread
 };
@@ -266,9 +321,9 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
                                                  int lgroups) {
   constexpr int NT = 256, NW = NT / 64;
   extern __shared__ double lrows[];            // [d + 1][256 lgroups]: training points resident in LDS (chain_lds_groups)
-  __shared__ double u[DCAP], pm[DCAP], x[DCAP], xs[DCAP], g[DCAP], red[NW][DCAP + 1], lp_s, mean_s, gred[4];
-  __shared__ double u0[DCAP], g0[DCAP], x0[DCAP], p0[DCAP], im[DCAP], lp0, mean0, eps_s;
-  __shared__ int L_s, acc_s;
+  __shared__ double x[DCAP], xs[DCAP], red[NW][DCAP + 1], lp_s, mean_s, gred[4], kin_s[2];
+  __shared__ double u0[DCAP], g0[DCAP], x0[DCAP], lp0, mean0, eps_s;
+  __shared__ int acc_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t c = blockIdx.x;
   const int d = h.d, sw = 3 * d + 2;
@@ -278,7 +333,6 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
     u0[t] = Sc[t];
     g0[t] = Sc[d + t];
     x0[t] = Sc[2 * d + t];
-    im[t] = inv_mass[t];
   }
   if (t == 0) {
     lp0 = Sc[3 * d];
@@ -306,30 +360,43 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
     lrows[d * lld + q * NT + t] = (i < n) ? alpha[i] : 0.0;
   }
   __syncthreads();
+  // Thread t < d owns coordinate t of the trajectory (position, momentum, gradient: registers); the others only ever need
+  // the point itself (x, xs in LDS).  A leapfrog step is two barriers: [every thread: its training points, the wave sums]
+  // | [thread t < d: gradient, momentum, next position -> x, xs] |.  Thread 0 carries the chain's scalars and its dual-
+  // averaging state in registers for the whole launch.
+  const double im_r = (t < d) ? inv_mass[t] : 0.0, inv_ls = (t < d) ? 1.0 / h.ls[t] : 0.0;
+  double a_eps = 0.0, a_mu = 0.0, a_hbar = 0.0, a_leb = 0.0, a_m = 0.0;
+  if (t == 0) {
+    a_eps = ad[0];
+    a_mu = ad[1];
+    a_hbar = ad[2];
+    a_leb = ad[3];
+    a_m = ad[4];
+  }
   for (int it = 0; it < niter; ++it) {
     const unsigned long long ikey = ckey + ((unsigned long long)(it0 + it) << 12);
     const double eps = eps_s;
+    double u_r = 0.0, pm_r = 0.0, p0_r = 0.0, g_r = 0.0, x_r = 0.0;
+    // position update of thread t < d, and the point in cube coordinates for everybody
+    auto advance = [&]() {
+      u_r += eps * im_r * pm_r;
+      double xv = 1.0 / (1.0 + exp(-u_r));
+      xv = xv < 1e-12 ? 1e-12 : (xv > 1.0 - 1e-12 ? 1.0 - 1e-12 : xv);
+      x_r = xv;
+      x[t] = xv;
+      xs[t] = xv * inv_ls;
+    };
     if (t < d) {                                               // momentum ~ N(0, M), M = diag(1 / inv_mass)
       const double a = hmc_u01(hmc_mix64(ikey + 2 * t)), b = hmc_u01(hmc_mix64(ikey + 2 * t + 1));
       const double z = sqrt(-2.0 * log(a)) * cos(6.283185307179586 * b);
-      const double pv = z / sqrt(im[t]);
-      p0[t] = pv;
-      pm[t] = pv + 0.5 * eps * g0[t];
-      u[t] = u0[t];
+      p0_r = z / sqrt(im_r);
+      pm_r = p0_r + 0.5 * eps * g0[t];
+      u_r = u0[t];
+      advance();
     }
-    if (t == 0) L_s = 4 + (int)(hmc_mix64(ikey + 4000) % 9ull);
+    const int L = 4 + (int)(hmc_mix64(ikey + 4000) % 9ull);    // (every thread: the same counter hash)
     __syncthreads();
-    const int L = L_s;
     for (int s = 0; s < L; ++s) {
-      if (t < d) {
-        const double un = u[t] + eps * im[t] * pm[t];
-        u[t] = un;
-        double xv = 1.0 / (1.0 + exp(-un));
-        xv = xv < 1e-12 ? 1e-12 : (xv > 1.0 - 1e-12 ? 1.0 - 1e-12 : xv);
-        x[t] = xv;
-        xs[t] = xv / h.ls[t];
-      }
-      __syncthreads();
       double ms = 0.0, gm[DCAP];
 #pragma unroll
       for (int j = 0; j < DCAP; ++j) gm[j] = 0.0;
@@ -368,7 +435,7 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
 #pragma unroll
         for (int q = 0; q < UNR; ++q) point(xr[q], ar[q]);
       }
-      ms = wave_sum(ms);
+      ms = chain_wave_sum(ms);
       if (lane == 0) red[wave][DCAP] = ms;
       {
         const double v = wave_sum_components<DCAP>(gm, lane);
@@ -376,44 +443,47 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
       }
       // classifier gate (clf_gp.py:173-205): an infeasible point has mean = minus_inf and no mean gradient - its
       // trajectory ends in a state that the Metropolis test never accepts
-      if (gt.n_sv > 0 && t < 256) {                            // (the gate's 256 partial sums: k_gate's order, whatever NT)
+      if (gt.n_sv > 0) {                                       // (the gate's 256 partial sums: k_gate's order)
         const double gs = gate_partial<DCAP>(gt, x, d, t);
         if (lane == 0) gred[wave] = gs;
       }
       __syncthreads();
       const bool ok = gt.n_sv > 0 ? gate_feasible(gt, gate_combine(gt, gred)) : true;
-      // (the waves' sums in wave order: ((r0 + r1) + r2) + r3 for NT = 256)
+      // (the waves' sums in wave order: ((r0 + r1) + r2) + r3)
       auto wsum = [&](int j) {
         double sres = red[0][j];
 #pragma unroll
         for (int w_ = 1; w_ < NW; ++w_) sres += red[w_][j];
         return sres;
       };
+      const bool last = s == L - 1;
       if (t < d) {
-        const double dm = ok ? wsum(t) / h.ls[t] : 0.0;
-        const double xv = x[t];
-        const double gv = dm * ystd / temp * (xv * (1.0 - xv)) + (1.0 - 2.0 * xv);
-        g[t] = gv;
-        pm[t] += ((s < L - 1) ? eps : 0.5 * eps) * gv;
+        const double dm = ok ? wsum(t) * inv_ls : 0.0;
+        g_r = dm * ystd / temp * (x_r * (1.0 - x_r)) + (1.0 - 2.0 * x_r);
+        pm_r += (last ? 0.5 * eps : eps) * g_r;
+        if (!last) advance();
       }
-      if (wave == 1 && s == L - 1) {                           // the end point's log-density (wave 0 has the gradient lanes)
-        double jl = (lane < d) ? log(x[lane]) + log1p(-x[lane]) : 0.0;
-        jl = wave_sum(jl);
-        if (lane == 0) {
-          const double m = ok ? wsum(DCAP) * ystd + ymean : gt.minus_inf;
-          mean_s = m;
-          lp_s = m / temp + jl;
+      if (last) {
+        if (wave == 0) {                                       // kinetic energies at both ends (lanes = coordinates)
+          const double k0 = chain_wave_sum(p0_r * p0_r * im_r), k1 = chain_wave_sum(pm_r * pm_r * im_r);
+          if (lane == 0) {
+            kin_s[0] = k0;
+            kin_s[1] = k1;
+          }
+        } else if (wave == 1) {                                // the end point's log-density
+          double jl = (lane < d) ? log(x[lane]) + log1p(-x[lane]) : 0.0;
+          jl = chain_wave_sum(jl);
+          if (lane == 0) {
+            const double m = ok ? wsum(DCAP) * ystd + ymean : gt.minus_inf;
+            mean_s = m;
+            lp_s = m / temp + jl;
+          }
         }
       }
       __syncthreads();
     }
     if (t == 0) {                                              // Metropolis test and the chain's step-size update
-      double k0 = 0.0, k1 = 0.0;
-      for (int j = 0; j < d; ++j) {
-        k0 += p0[j] * p0[j] * im[j];
-        k1 += pm[j] * pm[j] * im[j];
-      }
-      const double h0 = lp0 - 0.5 * k0, h1 = lp_s - 0.5 * k1;
+      const double h0 = lp0 - 0.5 * kin_s[0], h1 = lp_s - 0.5 * kin_s[1];
       double ap = 0.0;
       if (isfinite(h1)) ap = h1 >= h0 ? 1.0 : exp(h1 - h0);
       const double r = hmc_u01(hmc_mix64(ikey + 4001));
@@ -425,38 +495,40 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
       }
       if (do_adapt) {
         constexpr double t0 = 10.0, gamma = 0.05, kappa = 0.75, target = 0.8;
-        const double m = ad[4] + 1.0;
-        const double hbar = (1.0 - 1.0 / (m + t0)) * ad[2] + (target - ap) / (m + t0);
-        const double le = ad[1] - sqrt(m) / gamma * hbar;
+        const double m = a_m + 1.0;
+        const double hbar = (1.0 - 1.0 / (m + t0)) * a_hbar + (target - ap) / (m + t0);
+        const double le = a_mu - sqrt(m) / gamma * hbar;
         const double eta = pow(m, -kappa);
-        ad[2] = hbar;
-        ad[3] = eta * le + (1.0 - eta) * ad[3];
-        ad[4] = m;
+        a_hbar = hbar;
+        a_leb = eta * le + (1.0 - eta) * a_leb;
+        a_m = m;
         double e = exp(le);
         e = e < 1e-4 ? 1e-4 : (e > 2.0 ? 2.0 : e);
-        ad[0] = e;
+        a_eps = e;
         eps_s = e;
       }
       if (dbg && it == niter - 1) {
         double* dc = dbg + c * (d + 3);
-        for (int j = 0; j < d; ++j) dc[j] = p0[j];
         dc[d] = (double)L;
         dc[d + 1] = r;
         dc[d + 2] = ap;
       }
     }
+    if (dbg && it == niter - 1 && t < d) dbg[c * (d + 3) + t] = p0_r;
     __syncthreads();
     if (t < d) {
       if (acc_s) {
-        u0[t] = u[t];
-        g0[t] = g[t];
-        x0[t] = x[t];
+        u0[t] = u_r;
+        g0[t] = g_r;
+        x0[t] = x_r;
       }
       if (hist && it >= hist_from) hist[((int64_t)(it - hist_from) * P + c) * d + t] = u0[t];
       if (keep && (it + 1) % thin == 0) keep[((int64_t)((it + 1) / thin - 1) * P + c) * (d + 1) + t] = x0[t];
     }
     if (t == 0 && keep && (it + 1) % thin == 0) keep[((int64_t)((it + 1) / thin - 1) * P + c) * (d + 1) + d] = mean0;
-    __syncthreads();
+    // (no barrier here: the next iteration's first one comes before anything of this one is read again - u0 / g0 / x0 are
+    //  read by their own thread only, x / xs are written by advance() after every reader of this iteration has passed the
+    //  barrier above, eps_s and acc_s were written before it)
   }
   if (t < d) {
     Sc[t] = u0[t];
@@ -466,6 +538,12 @@ __global__ __launch_bounds__(256) void k_hmc_run(const double* __restrict__ XsT,
   if (t == 0) {
     Sc[3 * d] = lp0;
     Sc[3 * d + 1] = mean0;
+    if (do_adapt) {
+      ad[0] = a_eps;
+      ad[2] = a_hbar;
+      ad[3] = a_leb;
+      ad[4] = a_m;
+    }
   }
 }
 
@@ -575,7 +653,7 @@ __global__ __launch_bounds__(256) void k_rwalk(const double* __restrict__ XsT, i
 #pragma unroll
         for (int q = 0; q < UNR; ++q) point(xr[q], ar[q]);
       }
-      ms = wave_sum(ms);
+      ms = chain_wave_sum(ms);
       if (lane == 0) red[wave] = ms;
       if (gt.n_sv > 0) {
         const double gs = gate_partial<DCAP>(gt, xp, d, t);
