@@ -205,7 +205,7 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
   if (C <= 16 && N <= 4096) {
     // A handful of candidates (the L-BFGS refinement sends one): matrix-vector stages spread over the chip instead of
     // 128-column tile passes and one workgroup per candidate (kernels.hpp, "the same for a HANDFUL of candidates").
-    const int nzw = (int)(Mp / 64), nnw = (int)((N + 63) / 64);
+    const int nzw = (int)(Mp / 64), nnw = (int)((N + WG_ROWS - 1) / WG_ROWS);
     const size_t n_vec = (size_t)C * Np, n_a = (size_t)C * Mp;
     wg_ws.ensure((3 * n_vec + 2 * n_a + (size_t)C * nzw * WG_ZS + (size_t)C * nnw * WG_NS) * sizeof(double));
     part.ensure((size_t)C * nb * Np * sizeof(double));
@@ -243,7 +243,7 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
     if (packed) {                                  // one copy through the pinned result block instead of four
       o_wipv.ensure(n_out * sizeof(double));
       double* ob = o_wipv.d();
-      hipLaunchKernelGGL(k_wg_final, dim3((unsigned)C), dim3(64), 0, stream, (const double*)pz, nzw, (const double*)pn,
+      hipLaunchKernelGGL(k_wg_final, dim3((unsigned)C), dim3(256), 0, stream, (const double*)pz, nzw, (const double*)pn,
                          nnw, h, M, ob, ob + C, ob + 2 * C, ob + 2 * C + C * d);
       LAUNCH_CHECK();
       HIPCHK(hipMemcpyAsync(h_res, ob, n_out * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -255,7 +255,7 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
       if (dwipstd) std::memcpy(dwipstd, hr + 2 * C + C * d, (size_t)C * d * sizeof(double));
       return;
     }
-    hipLaunchKernelGGL(k_wg_final, dim3((unsigned)C), dim3(64), 0, stream, (const double*)pz, nzw, (const double*)pn,
+    hipLaunchKernelGGL(k_wg_final, dim3((unsigned)C), dim3(256), 0, stream, (const double*)pz, nzw, (const double*)pn,
                        nnw, h, M, d_v, d_s, d_dv, d_ds);
     LAUNCH_CHECK();
     out_finish(wipv, C, o_wipv);

@@ -56,6 +56,89 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// ---- wave-level sums without the LDS crossbar (the chain kernels of the samplers, the few-candidate gradient path) ----------
+// __shfl_xor is a ds_bpermute (two per double, ~100+ cycles each, six in a row per sum); latency-bound kernels sit on that
+// several times per step.  gfx950 exchanges lanes in the VALU instead: v_permlane32_swap / v_permlane16_swap
+// trade the upper 32 (odd 16) lanes of one register for the lower 32 (even 16) of another, and DPP reads a neighbour within a
+// row of 16 (row_ror:8, row_half_mirror, quad_perm).  Pairings per step: l ^ 32, l ^ 16, l ^ 8, 7 - l within eight, l ^ 2,
+// l ^ 1 - every step joins two lanes that differ in the step's lane bit, so six steps cover the wave.  Fixed order.
+// (A different pairing than wave_sum's, i.e. different last bits: used where no other kernel has to reproduce the sum - the
+//  factorisation / sweep reductions and the classifier gate keep wave_sum.)
+constexpr int DPP_ROR8 = 0x128, DPP_HALF_MIRROR = 0x141, DPP_XOR2 = 0x4E /* quad_perm:[2,3,0,1] */,
+              DPP_XOR1 = 0xB1 /* quad_perm:[1,0,3,2] */;
+template <int CTRL>
+__device__ __forceinline__ double dpp_read(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// a[l] + a[l ^ W] in the lanes whose bit W is clear, b[l] + b[l ^ W] in the others (W = 32, 16): one swap per register half
+template <int W>
+__device__ __forceinline__ double swap_add(double a, double b) {
+  const unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a);
+  const unsigned bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+  if constexpr (W == 32) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  } else {
+    const auto lo = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+}
+// step K (0 .. 5, lane bit 32 >> K) on the pair (a, b): the lane keeps a (bit clear) or b (bit set) and adds its partner's
+template <int K>
+__device__ __forceinline__ double chain_halve(double a, double b, int lane) {
+  if constexpr (K == 0) return swap_add<32>(a, b);
+  else if constexpr (K == 1) return swap_add<16>(a, b);
+  else {
+    constexpr int CTRL = K == 2 ? DPP_ROR8 : (K == 3 ? DPP_HALF_MIRROR : (K == 4 ? DPP_XOR2 : DPP_XOR1));
+    const bool up = (lane & (32 >> K)) != 0;
+    return (up ? b : a) + dpp_read<CTRL>(up ? a : b);
+  }
+}
+// the same step on one value held by every lane
+template <int K>
+__device__ __forceinline__ double chain_fold(double r) {
+  if constexpr (K == 0) return swap_add<32>(r, r);
+  else if constexpr (K == 1) return swap_add<16>(r, r);
+  else {
+    constexpr int CTRL = K == 2 ? DPP_ROR8 : (K == 3 ? DPP_HALF_MIRROR : (K == 4 ? DPP_XOR2 : DPP_XOR1));
+    return r + dpp_read<CTRL>(r);
+  }
+}
+// the sum over the wave, in every lane
+__device__ __forceinline__ double chain_wave_sum(double r) {
+  r = chain_fold<0>(r);
+  r = chain_fold<1>(r);
+  r = chain_fold<2>(r);
+  r = chain_fold<3>(r);
+  r = chain_fold<4>(r);
+  return chain_fold<5>(r);
+}
+// Sums of D per-lane values over the wave, all D at once: at every step the lane keeps the half of its values that its
+// step bit selects and adds its partner's (log2 D steps: D - 1 exchanges), then folds the one value left over the remaining
+// bits - one dependency chain of six steps instead of D of them.  Returns component (lane >> (6 - log2 D)), complete in
+// every lane of that group.
+template <int D, int HLF, int K>
+__device__ __forceinline__ void chain_sum_halve(double (&v)[D], int lane) {
+  if constexpr (HLF >= 1) {
+#pragma unroll
+    for (int i = 0; i < HLF; ++i) v[i] = chain_halve<K>(v[i], v[HLF + i], lane);
+    chain_sum_halve<D, HLF / 2, K + 1>(v, lane);
+  }
+}
+template <int D>
+__device__ __forceinline__ double wave_sum_components(double (&v)[D], int lane) {
+  static_assert(D == 8 || D == 16 || D == 32, "power of two");
+  chain_sum_halve<D, D / 2, 0>(v, lane);
+  double r = v[0];
+  if constexpr (D == 8) r = chain_fold<3>(r);
+  if constexpr (D <= 16) r = chain_fold<4>(r);
+  return chain_fold<5>(r);
+}
+
 // ---- coordinate scaling: out[j*ldo + i] = in[i*d + j] / ls[j]  (0 for i >= n) ------------
 // (hp, when given, overrides h with the device-resident hyper-parameters: a captured graph replays with new values)
 // Batched launches: blockIdx.y = slot picks hp[slot] and offsets `out` by bsO doubles per slot.

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void k_wg_cross(const double* __restrict__ ZsT
   a1[c * lda + z] = w1;
   b1[c * lda + z] = u1;
   double* pz = partZ + (c * gridDim.x + blockIdx.x) * WG_ZS;
-  const double t0 = wave_sum(sv), t1 = wave_sum(ss), t2 = wave_sum(w2), t3 = wave_sum(u2);
+  const double t0 = chain_wave_sum(sv), t1 = chain_wave_sum(ss), t2 = chain_wave_sum(w2), t3 = chain_wave_sum(u2);
   if (lane == 0) {
     pz[0] = t0;
     pz[1] = t1;
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void k_wg_cross(const double* __restrict__ ZsT
 #pragma unroll
   for (int j = 0; j < DCAP; ++j) {
     if (j < h.d) {                                // uniform
-      const double a = wave_sum(w1 * gz * dz[j]), b = wave_sum(u1 * gz * dz[j]);
+      const double a = chain_wave_sum(w1 * gz * dz[j]), b = chain_wave_sum(u1 * gz * dz[j]);
       if (lane == 0) {
         pz[4 + j] = a;
         pz[4 + MAX_D + j] = b;
@@ -681,7 +681,9 @@ __global__ __launch_bounds__(256) void k_wg_cross(const double* __restrict__ ZsT
   }
 }
 
-// one workgroup = 64 training points, 16 per wave one after the other; lanes run over the integration points
+// one workgroup = WG_ROWS training points, one per wave; lanes run over the integration points.
+// (Sixteen per wave - 64 per workgroup - left a refinement step at N = 400 on seven CUs for 41 of its 90 us.)
+constexpr int WG_ROWS = 4;
 template <int KERN, int DCAP>
 __global__ __launch_bounds__(256) void k_wg_rows(const double* __restrict__ XsT, int64_t ldx, int64_t n, int64_t np,
                                                  const double* __restrict__ cand, Hyper h,
@@ -696,9 +698,12 @@ __global__ __launch_bounds__(256) void k_wg_rows(const double* __restrict__ XsT,
   b1 += c * lda;
   u += c * np;
   const double xl = (lane < h.d) ? cand[c * h.d + lane] / h.ls[lane] : 0.0;      // this lane's coordinate (lane = j)
+  double xc[DCAP];                                                                 // the candidate, scaled (every lane)
+#pragma unroll
+  for (int j = 0; j < DCAP; ++j) xc[j] = (j < h.d) ? cand[c * h.d + j] / h.ls[j] : 0.0;
   double aq = 0.0, as = 0.0, au = 0.0;
-  for (int r = 0; r < 16; ++r) {
-    const int64_t i = (int64_t)blockIdx.x * 64 + wave + 4 * r;
+  for (int r = 0; r < WG_ROWS / 4; ++r) {
+    const int64_t i = (int64_t)blockIdx.x * WG_ROWS + wave + 4 * r;
     if (i >= n) break;                            // uniform per wave
     double q = 0.0, qs = 0.0;
     for (int64_t z = lane; z < mp; z += 64) {
@@ -706,12 +711,12 @@ __global__ __launch_bounds__(256) void k_wg_rows(const double* __restrict__ XsT,
       q = __builtin_fma(a1[z], w, q);
       qs = __builtin_fma(b1[z], w, qs);
     }
-    q = wave_sum(q);
-    qs = wave_sum(qs);
+    q = chain_wave_sum(q);
+    qs = chain_wave_sum(qs);
     double r2 = 0.0;
 #pragma unroll
     for (int j = 0; j < DCAP; ++j) {
-      const double df = (j < h.d) ? XsT[j * ldx + i] - cand[c * h.d + j] / h.ls[j] : 0.0;
+      const double df = (j < h.d) ? XsT[j * ldx + i] - xc[j] : 0.0;
       r2 += df * df;
     }
     const double kv = kern_eval<KERN>(r2, h.kvar);
@@ -733,41 +738,54 @@ __global__ __launch_bounds__(256) void k_wg_rows(const double* __restrict__ XsT,
   }
 }
 
-__global__ __launch_bounds__(64) void k_wg_final(const double* __restrict__ partZ, int nzw,
-                                                 const double* __restrict__ partN, int nnw, Hyper h, int64_t m,
-                                                 double* __restrict__ wipv, double* __restrict__ wipstd,
-                                                 double* __restrict__ dwipv, double* __restrict__ dwipstd) {
-  const int j = threadIdx.x;
+// the partial sums of k_wg_cross (nzw of them) and k_wg_rows (nnw) -> scores and gradients of candidate blockIdx.x.
+// 256 threads: thread (j = t & 31, part = t >> 5) adds the partials part, part + 8, ... of coordinate j, the eight parts are
+// combined in order.
+__global__ __launch_bounds__(256) void k_wg_final(const double* __restrict__ partZ, int nzw,
+                                                  const double* __restrict__ partN, int nnw, Hyper h, int64_t m,
+                                                  double* __restrict__ wipv, double* __restrict__ wipstd,
+                                                  double* __restrict__ dwipv, double* __restrict__ dwipstd) {
+  __shared__ double acc[8][9][32];
+  const int t = threadIdx.x, j = t & 31, part = t >> 5;
   const int64_t c = blockIdx.x;
   const double* pz = partZ + c * nzw * WG_ZS;
   const double* pn = partN + c * nnw * WG_NS;
-  const double inv_m = 1.0 / (double)m;
-  double sv = 0.0, ss = 0.0, a2 = 0.0, b2 = 0.0;
-  for (int w = 0; w < nzw; ++w) {
+  double sv = 0.0, ss = 0.0, a2 = 0.0, b2 = 0.0, dv = 0.0, dsd = 0.0, qv = 0.0, qs = 0.0, ds = 0.0;
+  for (int w = part; w < nzw; w += 8) {
     sv += pz[w * WG_ZS];
     ss += pz[w * WG_ZS + 1];
     a2 += pz[w * WG_ZS + 2];
     b2 += pz[w * WG_ZS + 3];
-  }
-  if (j == 0) {
-    if (wipv) wipv[c] = sv * inv_m;
-    if (wipstd) wipstd[c] = ss * inv_m;
-  }
-  if (j >= h.d) return;
-  double dv = 0.0, dsd = 0.0, qv = 0.0, qs = 0.0, ds = 0.0;
-  for (int w = 0; w < nzw; ++w) {
     dv += pz[w * WG_ZS + 4 + j];
     dsd += pz[w * WG_ZS + 4 + MAX_D + j];
   }
-  for (int w = 0; w < nnw; ++w) {
+  for (int w = part; w < nnw; w += 8) {
     qv += pn[w * WG_NS + j];
     qs += pn[w * WG_NS + MAX_D + j];
     ds += pn[w * WG_NS + 2 * MAX_D + j];
   }
-  const double dsj = -2.0 * ds / h.ls[j];
-  if (dwipv) dwipv[c * h.d + j] = ((dv - qv) / h.ls[j] + a2 * dsj) * inv_m;
-  if (dwipstd) dwipstd[c * h.d + j] = ((dsd - qs) / h.ls[j] + b2 * dsj) * inv_m;
+  const double mine[9] = {sv, ss, a2, b2, dv, dsd, qv, qs, ds};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[part][k][j] = mine[k];
+  __syncthreads();
+  if (part != 0) return;
+  double tot[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    double v = acc[0][k][j];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v += acc[q][k][j];
+    tot[k] = v;
+  }
+  const double inv_m = 1.0 / (double)m;
+  if (j == 0) {
+    if (wipv) wipv[c] = tot[0] * inv_m;
+    if (wipstd) wipstd[c] = tot[1] * inv_m;
+  }
+  if (j >= h.d) return;
+  const double dsj = -2.0 * tot[8] / h.ls[j];
+  if (dwipv) dwipv[c * h.d + j] = ((tot[4] - tot[6]) / h.ls[j] + tot[2] * dsj) * inv_m;
+  if (dwipstd) dwipstd[c * h.d + j] = ((tot[5] - tot[7]) / h.ls[j] + tot[3] * dsj) * inv_m;
 }
-
 
 }  // namespace bobe
