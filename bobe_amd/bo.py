@@ -19,6 +19,7 @@ reference's ``'uniform'`` (scrambled Sobol, acquisition.py:476-479) or ``'NS'`` 
 from __future__ import annotations
 
 import json
+import math
 import os
 import time
 from typing import Callable, Dict, List, Optional, Sequence
@@ -36,6 +37,37 @@ log = get_logger("bo")
 _ACQ = {"wipv": WIPV, "wipstd": WIPStd, "ei": EI, "logei": LogEI}
 
 
+def _factorisable_start(gp: GP, init: np.ndarray) -> np.ndarray:
+    """Row 0 of a fit's starts when the surrogate's current hyper-parameters no longer factorise.
+
+    Not in the reference.  Its fit evaluates every start and keeps the best FINITE one (optim.py:325-345); when new points
+    have made K at the incumbent numerically singular (``gp.not_pd``: a long-length-scale, large-variance fit of a smooth
+    likelihood at the default noise of 1e-8 gets there as N grows) only the uniform random starts are left, and the fit
+    jumps to whatever local optimum they find - in the 10-D Rosenbrock run at threshold 0.02 to length scales of 0.03
+    and a logZ of +21 (profiles/r04_config5.txt, section 10).  Here the incumbent is first walked back along the kernel
+    variance, by factors of four, to the nearest point that does factorise (same length scales, same shape of the
+    posterior mean): the fit then starts from the edge of the resolvable region instead of from nowhere."""
+    if not getattr(gp, "not_pd", False) or gp.fixed_kernel_variance:
+        return init
+    k = gp.ndim                                                  # position of log kernel_variance (gp.py:339-355)
+    lo = gp.hyperparam_bounds[0][k]
+    cands = []
+    for step in range(1, 17):
+        c = np.array(init)
+        c[k] = max(init[k] - step * math.log(4.0), lo)
+        cands.append(c)
+        if c[k] <= lo:
+            break
+    for b0 in range(0, len(cands), 8):
+        vals = gp.neg_mll_value_and_grad_batch(cands[b0:b0 + 8], want_grad=False)
+        for c, (f, _) in zip(cands[b0:b0 + 8], vals):
+            if np.isfinite(f):
+                log.warning("the surrogate's hyper-parameters no longer factorise at N = %d (kernel variance %.3g): the fit "
+                            "starts from kernel variance %.3g instead", gp.npoints, math.exp(init[k]), math.exp(c[k]))
+                return c
+    return init
+
+
 def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.random.Generator] = None,
            group=None, distributed: bool = True) -> dict:
     """``MPI_Pool.gp_fit`` (pool.py:268-328): x0 row 0 = log(current hp), further rows uniform in the log-bounds;
@@ -48,7 +80,7 @@ def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.r
     ``distributed=False`` keeps the fit on this rank (no collective: for calls that not every rank makes)."""
     rng = np.random.default_rng() if rng is None else rng
     n_params = gp.hyperparam_bounds.shape[1]
-    init = np.log(gp.get_hyperparams())
+    init = _factorisable_start(gp, np.log(gp.get_hyperparams()))
     if n_restarts > 1:
         x0 = np.vstack([init, rng.uniform(gp.hyperparam_bounds[0], gp.hyperparam_bounds[1],
                                           size=(n_restarts - 1, n_params))])

@@ -287,3 +287,38 @@ def test_an_exception_in_one_restart_ends_that_restart_only():
     # (optimize_scipy's own options differ from `kw`: same optimum, not the same last digits)
     assert np.allclose(best_x, ref[0].x, atol=1e-3) and best_f == pytest.approx(min(r.fun for r in ref), rel=1e-4)
     assert optim.lbfgs_driver() == "stepped"
+
+
+def test_fit_start_is_walked_back_to_a_factorisable_kernel_variance():
+    """bo.py::_factorisable_start: when the surrogate's hyper-parameters no longer factorise (``not_pd``), row 0 of the
+    fit's starts is the incumbent with its kernel variance lowered by factors of four until the objective is finite;
+    otherwise (factorised state, fixed kernel variance, nothing finite down to the bound) the incumbent itself."""
+    import math
+    import numpy as np
+    from bobe_amd.bo import _factorisable_start
+
+    class Fake:
+        ndim, npoints, fixed_kernel_variance, not_pd = 3, 1000, False, True
+        hyperparam_bounds = np.log(np.array([[0.01] * 3 + [1e-4], [5.0] * 3 + [1e8]]))
+        wall = math.log(3.0e4)
+        calls = 0
+
+        def neg_mll_value_and_grad_batch(self, thetas, want_grad=True):
+            Fake.calls += 1
+            assert not want_grad and len(thetas) <= 8
+            return [((float("nan") if t[3] > self.wall else -100.0 - t[3]), None) for t in thetas]
+
+    init = np.log(np.array([2.0, 3.0, 4.0, 1.0e6]))
+    out = _factorisable_start(Fake(), init)
+    assert np.array_equal(out[:3], init[:3]) and out[3] <= Fake.wall < out[3] + math.log(4.0) and Fake.calls == 1
+    assert math.isclose(math.exp(out[3]), 1.0e6 / 4 ** 3)                       # 2.5e5, 6.25e4 are above the wall; 1.5625e4 is not
+    ok = Fake()
+    ok.not_pd = False
+    assert _factorisable_start(ok, init) is init
+    fixed = Fake()
+    fixed.fixed_kernel_variance = True
+    assert _factorisable_start(fixed, init) is init
+    hopeless = Fake()
+    hopeless.wall = -math.inf
+    Fake.calls = 0
+    assert _factorisable_start(hopeless, init) is init and Fake.calls == 2     # sixteen candidates, eight per batch
