@@ -112,3 +112,28 @@ def test_run_level_resume_continues_the_interrupted_run(tmp_path):
     fresh = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=5, likelihood_name="banana", resume=True,
                  resume_file=str(tmp_path / "nothing_here" / "banana"))
     assert fresh.fresh_start and fresh.gp.npoints == 8
+
+
+def test_fit_of_a_surrogate_whose_hyperparameters_no_longer_factorise(caplog):
+    """bo.py::_factorisable_start on the device: hyper-parameters at which K is numerically singular (``not_pd``: NaN factor,
+    NaN predictions) - the fit starts from the incumbent with a smaller kernel variance instead of from the random starts
+    alone, and ends with a factorised surrogate that still describes the data (the reference's fit would keep whichever
+    uniform random start happens to be finite, optim.py:325-345)."""
+    import logging
+    from bobe_amd import GP
+    from bobe_amd.bo import gp_fit
+    rng = np.random.default_rng(8)
+    n, d = 600, 5
+    X = rng.uniform(size=(n, d))
+    y = -np.sum((X - 0.4) ** 2, axis=1) - 0.3 * np.prod(X[:, :2], axis=1)
+    gp = GP(X, y, noise=1e-8, lengthscales=np.full(d, 1.0), kernel_variance=10.0)
+    assert not gp.not_pd
+    gp.update_hyperparams(np.log(np.append(np.full(d, 3.5), 1e7)))
+    assert gp.not_pd and np.all(np.isnan(gp.predict_mean_batched(X[:3])))
+    with caplog.at_level(logging.WARNING):
+        res = gp_fit(gp, maxiters=40, n_restarts=4, rng=np.random.default_rng(1))
+    assert any("no longer factorise" in r.getMessage() for r in caplog.records)
+    assert np.isfinite(res["mll"]) and not gp.not_pd and gp.kernel_variance < 1e7
+    assert np.min(gp.lengthscales) > 0.5                       # (not one of the random starts' short-length-scale optima)
+    pred = gp.predict_mean_batched(X[:50])
+    assert np.max(np.abs(pred - y[:50])) < 1e-3 * np.ptp(y)
