@@ -216,7 +216,8 @@ class GP:
         # the reference's default - Uniform on both (gp.py:313, 326) - is a constant with zero gradient: evaluated once (a
         # fit asks thousands of times), by the same expressions as below so that the value keeps its bits
         flat = (type(self.kernel_variance_prior_dist), type(self.lengthscale_prior_dist)) == (P.Uniform, P.Uniform)
-        key = (id(self.kernel_variance_prior_dist), id(self.lengthscale_prior_dist), ls.shape)
+        key = flat and (self.kernel_variance_prior_dist.low, self.kernel_variance_prior_dist.high,
+                        self.lengthscale_prior_dist.low, self.lengthscale_prior_dist.high, ls.shape)
         if flat and getattr(self, "_flat_prior_key", None) == key:
             return self._flat_prior
         lp = float(np.sum(self.kernel_variance_prior_dist.log_prob(kernel_variance)))
