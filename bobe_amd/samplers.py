@@ -175,21 +175,28 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
     it = 0
     update_every = max(1, nlive // 5)
     gave_up = truncated = False
+    log_shell = math.log1p(-math.exp(-1.0 / nlive))
+
+    def logaddexp(a, b):                                  # np.logaddexp's formula on Python floats (thousands of calls)
+        if a == -math.inf:
+            return b
+        hi, lo = (a, b) if a > b else (b, a)
+        return hi + math.log1p(math.exp(lo - hi))
+    lmax = float(np.max(live_logl))                       # (only ever rises: the retired point is the lowest)
     while True:
         worst = int(np.argmin(live_logl))
         lstar = float(live_logl[worst])
         # Stop BEFORE the worst point is retired — it then stays among the final live points and is counted once
         # (dynesty checks at the top of its iteration too).  Remaining evidence bound (dynesty's stopping rule):
         # dlogz = log(z + Lmax X) - log z.
-        lmax = float(np.max(live_logl))
-        if it > 0 and np.logaddexp(logz, lmax - it / nlive) - logz < dlogz:
+        if it > 0 and logaddexp(logz, lmax - it / nlive) - logz < dlogz:
             break
         if ncall >= maxcall:
             truncated = True
             break
-        logdx = -it / nlive + math.log1p(-math.exp(-1.0 / nlive))      # log(X_{i-1} - X_i)
+        logdx = -it / nlive + log_shell                                 # log(X_{i-1} - X_i)
         logz_before = logz
-        logz = np.logaddexp(logz, lstar + logdx)
+        logz = logaddexp(logz, lstar + logdx)
         dead_x.append(live[worst].copy())
         dead_logl.append(lstar)
         it += 1
@@ -205,6 +212,7 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
                 if pool_l[pool_pos] > lstar:
                     live[worst] = pool_x[pool_pos]
                     live_logl[worst] = pool_l[pool_pos]
+                    lmax = max(lmax, float(pool_l[pool_pos]))
                     pool_pos += 1
                     found = True
                     break
