@@ -28,7 +28,7 @@ __device__ __forceinline__ double log_ei_helper(double u) {
 // SVM-RBF decision function of clf.py:188-213 by DIRECT DIFFERENCES, as the reference computes it:
 //   diff = support_vectors - x;  norm_sq = sum_j diff_j^2;  decision = sum_i dual_i exp(-gamma norm_sq_i) + intercept.
 // One 256-thread workgroup per point, ONE summation order everywhere (the batch kernel and the HMC kernels share
-// gate_partial / gate_combine): thread t adds the vectors t, t + 256, ... in ascending order, lanes by butterfly, then the
+// gate_partial / gate_combine): thread t adds the vectors t, t + 256, ... in ascending order, lanes by chain_wave_sum, then the
 // four waves ((r0 + r1) + r2) + r3, then + intercept.  A point near the boundary is therefore classified the same way by
 // every entry point.  x: the point's d raw (unit-cube) coordinates, readable by every thread.
 template <int DCAP>
@@ -48,7 +48,7 @@ __device__ __forceinline__ double gate_partial(const Gate& gt, const double* x, 
     }
     s += gt.dual[i] * exp(-gt.gamma * r2);
   }
-  return wave_sum(s);
+  return chain_wave_sum(s);
 }
 // red[4]: the four waves' sums (written by lane 0 of each wave, followed by a barrier)
 __device__ __forceinline__ double gate_combine(const Gate& gt, const double* red) {

@@ -63,7 +63,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // row of 16 (row_ror:8, row_half_mirror, quad_perm).  Pairings per step: l ^ 32, l ^ 16, l ^ 8, 7 - l within eight, l ^ 2,
 // l ^ 1 - every step joins two lanes that differ in the step's lane bit, so six steps cover the wave.  Fixed order.
 // (A different pairing than wave_sum's, i.e. different last bits: used where no other kernel has to reproduce the sum - the
-//  factorisation / sweep reductions and the classifier gate keep wave_sum.)
+//  factorisation / sweep reductions keep wave_sum; the classifier gate uses this one in every kernel that evaluates it.)
 constexpr int DPP_ROR8 = 0x128, DPP_HALF_MIRROR = 0x141, DPP_XOR2 = 0x4E /* quad_perm:[2,3,0,1] */,
               DPP_XOR1 = 0xB1 /* quad_perm:[1,0,3,2] */;
 template <int CTRL>
