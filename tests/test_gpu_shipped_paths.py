@@ -153,3 +153,22 @@ def test_headline_sample_against_the_oracle_sweep():
     assert idx[int(np.argmin(ro["wipv"]))] == r["argmin_v"]
     assert idx[int(np.argmin(ro["wipstd"]))] == r["argmin_s"]
     assert r["argmin_v"] == int(np.argmin(r["wipv"])) and r["argmin_s"] == int(np.argmin(r["wipstd"]))
+
+
+def test_few_candidate_gradient_path_equals_the_batched_one_at_large_n():
+    """bobe_gp_wip_grad takes matrix-vector stages spread over the chip for up to 16 candidates (the acquisition's L-BFGS
+    refinement sends one) and 128-column tile passes above: the same scores and gradients, at sizes where the first has
+    hundreds of partial sums per candidate (k_wg_rows: one training row per wave)."""
+    from bobe_amd import GP
+    for n, d, m in ((3000, 7, 300), (130, 3, 64)):
+        rng = np.random.default_rng(1)
+        X = rng.uniform(size=(n, d))
+        gp = GP(X, -10 * np.sum((X - 0.5) ** 2, axis=1), noise=1e-6, lengthscales=np.full(d, 0.7), kernel_variance=2.0)
+        Z, c = rng.uniform(size=(m, d)), rng.uniform(size=(20, d))
+        big = gp.wip_grad(c, Z)
+        one = [gp.wip_grad(c[i:i + 1], Z) for i in range(20)]
+        five = gp.wip_grad(c[:5], Z)
+        for k in range(4):
+            scale = np.max(np.abs(big[k]))
+            assert np.max(np.abs(np.concatenate([f[k] for f in one]) - big[k])) < 1e-8 * scale
+            assert np.max(np.abs(five[k] - big[k][:5])) < 1e-8 * scale
