@@ -91,6 +91,7 @@ SIGNATURES = [
     ("bobe_gp_profile_select", C.c_int, [C.c_void_p, C.c_int]),
     ("bobe_gp_profile_read", C.c_int, [C.c_void_p, c_double_p, c_int64_p]),
     ("bobe_debug_mfma_peak", C.c_int, [C.c_int, C.c_int, c_double_p]),
+    ("bobe_debug_wave_sums", C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -5,6 +5,8 @@
 // bobe_last_error().
 #include "gp_handle.hpp"
 
+#include "kernels_common.hpp"
+
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -729,4 +731,46 @@ int bobe_debug_mfma_peak(int device, int waves_per_simd, double* tflops) {
   API_END
 }
 
+}  // extern "C"
+
+namespace {
+// the cross-lane sums of kernels_common.hpp on one wave (tests): in [64][D] row-major (lane, component), D = 8 / 16 / 32;
+// out [2 D]: out[j] = component j as wave_sum_components leaves it (taken from the first lane of the component's group),
+// out[D + j] = chain_wave_sum of component j read back from lane 63
+template <int D>
+__global__ __launch_bounds__(64) void k_debug_wave_sums(const double* __restrict__ in, double* __restrict__ out) {
+  const int lane = threadIdx.x;
+  double v[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) v[j] = in[lane * D + j];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const double s = chain_wave_sum(v[j]);
+    if (lane == 63) out[D + j] = s;
+  }
+  const double c = wave_sum_components<D>(v, lane);
+  if ((lane & (64 / D - 1)) == 0) out[lane / (64 / D)] = c;
+}
+}  // namespace
+
+extern "C" {
+int bobe_debug_wave_sums(int device, int D, const double* in, double* out) {
+  API_BEGIN
+  NEED(in && out && (D == 8 || D == 16 || D == 32), "bad argument");
+  HIPCHK(hipSetDevice(device));
+  DBuf di, dout;
+  di.ensure((size_t)64 * D * 8);
+  dout.ensure((size_t)2 * D * 8);
+  HIPCHK(hipMemcpy(di.p, in, (size_t)64 * D * 8, hipMemcpyHostToDevice));
+  if (D == 8) hipLaunchKernelGGL(k_debug_wave_sums<8>, dim3(1), dim3(64), 0, 0, (const double*)di.d(), dout.d());
+  else if (D == 16) hipLaunchKernelGGL(k_debug_wave_sums<16>, dim3(1), dim3(64), 0, 0, (const double*)di.d(), dout.d());
+  else hipLaunchKernelGGL(k_debug_wave_sums<32>, dim3(1), dim3(64), 0, 0, (const double*)di.d(), dout.d());
+  LAUNCH_CHECK();
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, dout.p, (size_t)2 * D * 8, hipMemcpyDeviceToHost));
+  di.release();
+  dout.release();
+  return BOBE_OK;
+  API_END
+}
 }  // extern "C"

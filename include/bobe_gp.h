@@ -277,6 +277,10 @@ int bobe_gp_profile_select(bobe_gp_t* gp, int kernel_class);
 int bobe_gp_profile_read(bobe_gp_t* gp, double* total_ms, int64_t* launches);
 /* back-to-back v_mfma_f64_16x16x4_f64 issue rate on all CUs (1 or 2 waves per SIMD), in TFLOP/s */
 int bobe_debug_mfma_peak(int device, int waves_per_simd, double* tflops);
+/* The samplers' cross-lane sums (v_permlane32/16_swap + DPP, kernels_common.hpp) on one wave: in [64][D] (lane, component),
+ * D = 8, 16 or 32; out[j] = sum over the lanes of component j by the all-components butterfly, out[D + j] = the same by the
+ * single-value sum. */
+int bobe_debug_wave_sums(int device, int D, const double* in, double* out);
 /* candidate chunk size of the sweep (multiple of 128); 0 keeps the default */
 int bobe_gp_set_chunk(bobe_gp_t* gp, int64_t chunk);
 

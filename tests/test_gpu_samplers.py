@@ -301,3 +301,28 @@ def test_device_random_walks_of_nested_sampling():
     assert abs(lz_dev["mean"] - lz_host["mean"]) < max(err, 0.3), (lz_dev, lz_host)
     exact = np.log((np.pi / 30.0) ** (d / 2))                                # integral of exp(-30 |x - 1/2|^2) over the cube
     assert abs(lz_dev["mean"] - exact) < 0.5 and abs(lz_host["mean"] - exact) < 0.5
+
+
+def test_cross_lane_sums_of_the_sampler_kernels():
+    """kernels_common.hpp: chain_wave_sum and wave_sum_components (v_permlane32/16_swap + DPP row_ror / half_mirror /
+    quad_perm pairings instead of ds_bpermute).  Integer-valued inputs make every order of summation exact: the sums must
+    equal NumPy's to the bit; with arbitrary doubles they agree to rounding; a single marked lane shows up in exactly its
+    component (no lane is lost or counted twice)."""
+    from bobe_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for D in (8, 16, 32):
+        ints = np.ascontiguousarray(rng.integers(-1000, 1000, size=(64, D)).astype(np.float64))
+        out = np.empty(2 * D)
+        assert lib.bobe_debug_wave_sums(0, D, _lib.ptr(ints), _lib.ptr(out)) == 0, lib.bobe_last_error()
+        assert np.array_equal(out[:D], ints.sum(0)) and np.array_equal(out[D:], ints.sum(0))
+        vals = np.ascontiguousarray(rng.normal(size=(64, D)) * 10.0 ** rng.integers(-3, 4, size=(64, D)))
+        assert lib.bobe_debug_wave_sums(0, D, _lib.ptr(vals), _lib.ptr(out)) == 0
+        scale = np.abs(vals).sum(0)
+        assert np.all(np.abs(out[:D] - vals.sum(0)) <= 1e-15 * scale) and np.all(np.abs(out[D:] - vals.sum(0)) <= 1e-15 * scale)
+        for lane in (0, 1, 5, 17, 31, 32, 47, 63):
+            one = np.zeros((64, D))
+            one[lane] = np.arange(1, D + 1)
+            assert lib.bobe_debug_wave_sums(0, D, _lib.ptr(np.ascontiguousarray(one)), _lib.ptr(out)) == 0
+            assert np.array_equal(out[:D], np.arange(1, D + 1)) and np.array_equal(out[D:], np.arange(1, D + 1))
+    assert lib.bobe_debug_wave_sums(0, 12, _lib.ptr(ints), _lib.ptr(out)) < 0            # only the three widths exist
