@@ -66,6 +66,12 @@ SIGNATURES = [
     ("bobe_gp_gate_eval", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("bobe_gp_kernel", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
                                  C.c_double, C.c_int, C.c_void_p]),
+    ("bobe_gp_dist_sq", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("bobe_gp_mll_from_k", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, c_double_p]),
+    ("bobe_gp_chol_row_update", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p,
+                                          c_double_p]),
+    ("bobe_gp_set_pivot_floor_ulp", C.c_int, [C.c_void_p, C.c_double]),
+    ("bobe_gp_get_pivot_floor_ulp", C.c_double, [C.c_void_p]),
     ("bobe_gp_get_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_set_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_clone_state", C.c_int, [C.c_void_p, C.c_void_p]),

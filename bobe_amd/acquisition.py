@@ -213,7 +213,7 @@ class WIPStd(WeightedIntegratedPosteriorBase):
     _key = "wipstd"
 
 
-def get_mc_samples(gp: GP, warmup_steps=512, num_samples=1024, thinning=4, method="uniform", num_chains=4,
+def get_mc_samples(gp: GP, warmup_steps=512, num_samples=1024, thinning=4, method="NUTS", num_chains=4,
                    np_rng=None, rng_key=None):
     """BOBE/acquisition.py:468-482: 'NUTS' (Hamiltonian Monte Carlo on the surrogate, batched on the GPU), 'NS'
     (nested sampling on the surrogate) or 'uniform' (scrambled Sobol)."""
@@ -229,7 +229,7 @@ def get_mc_samples(gp: GP, warmup_steps=512, num_samples=1024, thinning=4, metho
         rng = np_rng if isinstance(np_rng, np.random.Generator) else np.random.default_rng(np_rng)
         return sample_GP_NUTS(gp, np_rng=rng, rng_key=rng_key, num_chains=num_chains, warmup_steps=warmup_steps,
                               num_samples=num_samples, thinning=thinning)
-    raise NotImplementedError(f"mc-sample method {method!r} is not available")
+    raise ValueError(f"Unknown method {method} for sampling GP")          # acquisition.py:481
 
 
 def get_mc_points(mc_samples, mc_points_size=128, rng=None):

@@ -5,12 +5,13 @@ Mirrors the parts of ``BOBE/bo.py`` that *call* the hot path: Sobol initialisati
 WIPV / WIPStd / EI iteration (bo.py:1174-1224, 1226-1390: mc points -> get_next_batch -> evaluate ->
 update_gp) and the refit policy of ``update_gp`` (bo.py:620-668, strict ``<`` size classes included).
 
-Run-level resume (bo.py:327-381): ``save=True`` writes ``<save_dir>/<name>_gp.npz`` (the reference's file) plus
-``<name>_run.json`` / ``<name>_mc.npz`` (what its results manager keeps: iteration, evaluation count, acquisition
-history, convergence state — and, so that a resumed run CONTINUES the interrupted one, the generator state and the
-current integration samples); ``BOBE(..., resume=True, resume_file=<save_dir>/<name>)`` picks them up.
+Run-level resume (bo.py:327-381): ``save=True`` (the default, as there) writes ``<save_dir>/<name>_gp.npz`` (the
+reference's file) plus ``<name>_run.json`` naming one complete generation ``<name>_gp.<g>.npz`` / ``<name>_mc.<g>.npz``
+(what its results manager keeps: iteration, evaluation count, acquisition history, convergence state — and, so that a
+resumed run CONTINUES the interrupted one, the generator state and the current integration samples);
+``BOBE(..., resume=True, resume_file=<save_dir>/<name>)`` picks them up.
 
-Not reproduced (see DESIGN.md 7): the MPI pool itself (its restart sharding is, over torch.distributed: ``gp_fit``),
+Not reproduced (see DESIGN.md 8): the MPI pool itself (its restart sharding is, over torch.distributed: ``gp_fit``),
 NUTS.  The logZ convergence test (bo.py:886-891)
 runs on ``bobe_amd.samplers.nested_sampling`` (batched on the GPU GP) instead of dynesty; the loop also stops
 on ``max_evals``, ``max_gp_size`` or an acquisition-value threshold.  Integration points come from the
@@ -107,6 +108,14 @@ def load_gp_file(filename: str, clf: bool, device: int = 0):
     return GP.load(filename, device=device)
 
 
+def load_gp_statedict(state_dict: dict, clf: bool, device: int = 0):
+    """bo.py:45-65: the same from a state dictionary (what the reference's MPI workers are sent, pool.py:109-117)."""
+    if clf:
+        from .clf_gp import GPwithClassifier
+        return GPwithClassifier.from_state_dict(state_dict, device=device)
+    return GP.from_state_dict(state_dict, device=device)
+
+
 def refit_policy(n_train_before: int, n_since_last_fit: int, n_new: int, fit_n_points: int):
     """The size classes of ``update_gp`` (bo.py:632-655) -> (refit, n_restarts, maxiter, points since the last fit).
     Strict '<' on both sides as in the reference: N == 200 and N >= 750 both land in the last branch."""
@@ -121,50 +130,95 @@ def refit_policy(n_train_before: int, n_since_last_fit: int, n_new: int, fit_n_p
 
 
 class BOBE:
-    """``BOBE(loglikelihood, param_list, param_bounds, ...).run(acq=...)`` with the GP on a MI355X."""
+    """``BOBE(loglikelihood, param_list, param_bounds, ...).run(...)`` with the GP on a MI355X: the constructor, ``run`` and
+    the helper methods a script can reach (``update_gp``, ``get_next_batch``, ``evaluate_likelihood``,
+    ``check_max_evals_and_gpsize``, ``check_convergence_ei`` / ``_logz``, ``finalise_results``, ``run_EI`` / ``run_WIPStd`` /
+    ``run_WIPV`` / ``run_weighted_integrated_posterior``) carry the reference's names, argument order and defaults
+    (bo.py:69-96, 621, 681, 707, 758, 779, 838, 869, 967-984, 1174, 1226, 1392, 1396; pinned by
+    tests/golden/reference_signatures.json); what this driver adds is keyword-only and comes after them."""
 
     def __init__(self, loglikelihood: Callable[[np.ndarray], float], param_list: Sequence[str] = None,
                  param_bounds: np.ndarray = None, param_labels=None, likelihood_name: Optional[str] = None,
                  confidence_for_unbounded=0.9999995, gp_kwargs: Optional[dict] = None, n_cobaya_init: int = 4,
                  n_sobol_init: int = 16, init_train_x=None, init_train_y=None, resume: bool = False, resume_file=None,
-                 save_dir: str = ".", save: bool = False, save_step: int = 5, optimizer: str = "scipy",
+                 save_dir: str = ".", save: bool = True, save_step: int = 5, optimizer: str = "scipy",
                  acq: str = "WIPV", use_clf: bool = False, clf_type: str = "svm", clf_nsigma_threshold: float = 20,
                  clf_use_size: int = 10, clf_update_step: int = 1, minus_inf: float = -1e10,
-                 seed: Optional[int] = None, verbosity: str = "INFO", device: int = 0):
-        """Keywords of the reference constructor (bo.py:69-96) plus ``device``.  ``loglikelihood`` must be a callable
-        on physical parameters (Cobaya likelihoods belong to the parts that are not built, DESIGN.md 7);
-        ``save`` writes ``<save_dir>/<likelihood_name>_gp.npz`` (+ the run state) every ``save_step`` iterations
-        (bo.py:239); ``resume=True, resume_file=<save_dir>/<likelihood_name>`` continues from those files instead of
-        drawing and evaluating an initial design (bo.py:205-206, 327-381; a file that cannot be loaded falls back to a
-        fresh start, as there); ``use_clf`` selects ``GPwithClassifier`` (SVM) with the thresholds derived from
-        ``clf_nsigma_threshold``."""
+                 seed: Optional[int] = None, verbosity: str = "INFO", *, device: int = 0):
+        """Keywords, order and defaults of the reference constructor (bo.py:69-96) plus the keyword-only ``device``.
+        ``loglikelihood`` must be a callable on physical parameters (Cobaya likelihoods belong to the parts that are not
+        built).  ``acq`` is recorded among the settings only, as in the reference (bo.py:314): what runs is
+        ``run``'s own ``acq``.  ``save`` (default True, bo.py:84) writes ``<save_dir>/<likelihood_name>_gp.npz`` after the
+        initial fit (bo.py:239) and, with the run state beside it, every ``save_step`` iterations;
+        ``resume=True, resume_file=<save_dir>/<likelihood_name>`` continues from those files instead of drawing and
+        evaluating an initial design (bo.py:205-206, 327-381; a file that cannot be loaded falls back to a fresh start, as
+        there); ``use_clf`` selects ``GPwithClassifier`` (SVM) with the thresholds derived from ``clf_nsigma_threshold``."""
         import logging
         if not callable(loglikelihood):
             raise NotImplementedError("only a callable log-likelihood is supported (Cobaya adaptors are out of scope)")
         if param_list is None or param_bounds is None:
             raise ValueError("param_list and param_bounds are required with a callable log-likelihood")
+        if str(optimizer).lower() not in ("optax", "scipy"):                 # bo.py:299-300
+            raise ValueError("optimizer must be either 'optax' or 'scipy'")
         logging.getLogger("bobe_amd").setLevel(getattr(logging, str(verbosity).upper(), logging.INFO))
         self.loglikelihood = loglikelihood
         self.param_list = list(param_list)
         self.param_labels = list(param_labels) if param_labels is not None else list(param_list)
         self.likelihood_name = likelihood_name or "likelihood"
+        self.output_file = self.likelihood_name                             # bo.py:290
         self.param_bounds = np.asarray(param_bounds, dtype=np.float64)      # (2, ndim), like the reference
         self.ndim = len(self.param_list)
         self.np_rng = np.random.default_rng(seed)
         self.minus_inf = float(minus_inf)
+        self.optimizer = optimizer
         self.device = device
+        self.is_main, self.is_mpi = True, False                             # (no MPI pool: one process per GPU, DESIGN.md 7)
         self.save, self.save_dir, self.save_step = bool(save), save_dir, max(1, int(save_step))
-        self.default_acq = acq
+        self.settings = {"n_cobaya_init": n_cobaya_init, "n_sobol_init": n_sobol_init, "acq": acq, "use_clf": use_clf,
+                         "clf_type": clf_type, "clf_nsigma_threshold": clf_nsigma_threshold, "minus_inf": minus_inf,
+                         "seed": seed}                                      # bo.py:311-320
         self.timing: Dict[str, float] = {"GP Training": 0.0, "Acquisition Optimization": 0.0,
                                          "True Objective Evaluations": 0.0}
         self.n_points_since_last_fit = 0
+        self.n_points_since_last_ns = 0
+        self.fit_n_points = 10                                              # (run() stores its own, bo.py:1083)
+        self.start_iteration = 0
+        self.acquisition = None
+        self.acquisition_history: List[float] = []
+        self.gp_hyperparam_history: List[dict] = []
+        self.kl_history: List[dict] = []
+        self.convergence_history: List[dict] = []
+        self.prev_samples = None                                            # bo.py:243
+        self.results_dict: dict = {}
+        self.samples_dict: dict = {}
+        self.mc_samples: Optional[dict] = None
+        self.ns_samples: Optional[dict] = None
+        self._ns_success = False
+        self.converged, self.convergence_counter = False, 0
+        self.termination_reason = "Max evaluation budget reached"
         self.save_path = os.path.join(self.save_dir, self.likelihood_name)
+        self._ckpt_gen = 0
         self.fresh_start, self._resume_state = True, None
         if resume and resume_file is not None:
             self._handle_resume(str(resume_file), use_clf)
-        if not self.fresh_start:
-            return
-        # Sobol initial design (bo.py:521-529), optionally after user-supplied points (bo.py:505-519)
+        if self.fresh_start:
+            self._handle_fresh_start(n_sobol_init, init_train_x, init_train_y, use_clf, clf_type, clf_use_size,
+                                     clf_update_step, clf_nsigma_threshold, optimizer, gp_kwargs)
+        # best point so far (bo.py:217-236)
+        y = self.gp.train_y * self.gp.y_std + self.gp.y_mean
+        ibest = int(np.argmax(y))
+        self.best_f = float(y.reshape(-1)[ibest])
+        self.best_pt = scale_from_unit(self.gp.train_x[ibest], self.param_bounds).reshape(-1)
+        self.best = {name: f"{float(val):.6f}" for name, val in zip(self.param_list, self.best_pt)}
+        self.best_pt_iteration = self.start_iteration
+        if self.save and self.fresh_start:                                  # bo.py:239
+            os.makedirs(self.save_dir, exist_ok=True)
+            self._save_gp_file()
+
+    def _handle_fresh_start(self, n_sobol_init, init_train_x, init_train_y, use_clf, clf_type, clf_use_size,
+                            clf_update_step, clf_nsigma_threshold, optimizer, gp_kwargs) -> None:
+        """bo.py:383-414: Sobol initial design (bo.py:521-529), optionally after user-supplied points (bo.py:505-519),
+        the surrogate (bo.py:571-612) and its first fit (bo.py:611)."""
         n_sobol = max(2, n_sobol_init)
         sobol = qmc.Sobol(d=self.ndim, scramble=True, seed=self.np_rng).random(n_sobol)
         pts = scale_from_unit(sobol, self.param_bounds)
@@ -184,15 +238,46 @@ class BOBE:
                                        clf_update_step=clf_update_step, probability_threshold=0.5,
                                        minus_inf=self.minus_inf, clf_threshold=clf_threshold,
                                        gp_threshold=2 * clf_threshold, param_names=self.param_list,
-                                       device=device, **kw)
+                                       device=self.device, **kw)
         else:
-            self.gp = GP(x_u, vals, param_names=self.param_list, device=device, **kw)
+            self.gp = GP(x_u, vals, param_names=self.param_list, device=self.device, **kw)
         gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng)        # bo.py:611
         self.timing["GP Training"] += time.time() - t0
 
+    # ------------------------------------------------------------------ files
     def _handle_resume(self, resume_file: str, use_clf: bool) -> None:
-        """bo.py:327-381: the GP from ``<resume_file>_gp.npz`` (tested with one prediction), the run state from
-        ``<resume_file>_run.json`` when it is there (a GP file alone resumes at iteration 0 with that training set)."""
+        """bo.py:327-381.  ``<resume_file>_run.json``, when it is there, names the generation of files it belongs to
+        (``_checkpoint``); the GP comes from that generation's file, tested with one prediction.  Without a usable run
+        state the reference's own file ``<resume_file>_gp.npz`` resumes at iteration 0 with that training set."""
+        st = None
+        try:
+            with open(resume_file + "_run.json") as fh:
+                st = json.load(fh)
+        except FileNotFoundError:
+            pass
+        except Exception as e:
+            log.warning(f"Run state {resume_file}_run.json unusable ({e}): resuming with the GP file alone")
+        base = os.path.dirname(resume_file)
+        if st is not None and st.get("gp_file"):
+            try:
+                log.info(f"Attempting to resume from file {resume_file} (generation {st.get('generation')})")
+                gp = load_gp_file(os.path.join(base, st["gp_file"])[:-len(".npz")], use_clf, device=self.device)
+                _ = gp.predict_mean_single(gp.train_x[0])
+                if int(st.get("gp_training_set_size", -1)) != int(gp.npoints):
+                    raise ValueError(f"run state is for {st.get('gp_training_set_size')} training points, its GP file has "
+                                     f"{gp.npoints}")
+                if st.get("mc_file"):
+                    z = np.load(os.path.join(base, st["mc_file"]), allow_pickle=False)
+                    st["mc"] = {k: (z[k] if z[k].shape != () else z[k].item()) for k in z.files}
+                self.gp, self.fresh_start, self._resume_state = gp, False, st
+                self._ckpt_gen = int(st.get("generation", 0))
+                self.start_iteration = int(st.get("iteration", 0))
+                log.info(f"Loaded GP with {gp.train_x.shape[0]} training points; resuming from iteration "
+                         f"{st['iteration']} ({st['current_evals']} evaluations so far)")
+                return
+            except Exception as e:
+                log.warning(f"Run state {resume_file}_run.json does not lead to a usable generation ({e}): resuming with "
+                            "the GP file alone")
         gp_file = resume_file + "_gp"
         try:
             log.info(f"Attempting to resume from file {resume_file}")
@@ -205,47 +290,66 @@ class BOBE:
             self.fresh_start = True
             return
         self.fresh_start = False
-        try:
-            with open(resume_file + "_run.json") as fh:
-                st = json.load(fh)
-            if int(st.get("gp_training_set_size", -1)) != int(self.gp.npoints):
-                raise ValueError(f"run state is for {st.get('gp_training_set_size')} training points, the GP file has "
-                                 f"{self.gp.npoints}")
-            mc_file = resume_file + "_mc.npz"
-            if st.get("has_mc") and os.path.exists(mc_file):
-                z = np.load(mc_file, allow_pickle=False)
-                st["mc"] = {k: (z[k] if z[k].shape != () else z[k].item()) for k in z.files}
-            self._resume_state = st
-            log.info(f"Resuming from iteration {st['iteration']} ({st['current_evals']} evaluations so far)")
-        except FileNotFoundError:
-            log.info("No run state beside the GP file: resuming with its training set at iteration 0")
-        except Exception as e:
-            log.warning(f"Run state {resume_file}_run.json unusable ({e}): resuming with the GP file alone")
+        log.info("No usable run state beside the GP file: resuming with its training set at iteration 0")
+
+    def _save_gp_file(self, source: Optional[str] = None) -> None:
+        """The reference's file ``<save_path>_gp.npz`` (bo.py:239; loadable by its ``load_gp_file``), moved into place
+        under its final name only when complete."""
+        tmp = self.save_path + "_gp.tmp"                                  # (np.savez appends .npz)
+        if source is None:
+            self.gp.save(tmp)
+        else:
+            import shutil
+            shutil.copyfile(source, tmp + ".npz")
+        os.replace(tmp + ".npz", self.save_path + "_gp.npz")
 
     def _checkpoint(self, state: dict, mc: Optional[dict]) -> None:
-        """``<save_path>_gp.npz`` (bo.py:239) and, beside it, the run state a resumed run continues from.  Every file is
-        written under a temporary name and moved into place (``os.replace``), the run state LAST: a kill at any moment
-        leaves the previous generation readable, and a run state never names a GP file that is newer or half written
-        (``_handle_resume`` checks ``gp_training_set_size``)."""
+        """One generation of run files: ``<save_path>_gp.<g>.npz`` and ``<save_path>_mc.<g>.npz`` first, then
+        ``<save_path>_run.json`` - replaced atomically, LAST, and naming the two files it belongs with.  A kill at any
+        moment therefore leaves a run state whose generation is complete on disk: the previous one until the replace,
+        the new one after it (older generations are pruned only then).  ``<save_path>_gp.npz``, the file the reference
+        writes and reads (bo.py:239, 25-43), is refreshed after that from the generation's file."""
         os.makedirs(self.save_dir, exist_ok=True)
-        tmp_gp = self.save_path + "_gp.tmp"                              # (np.savez appends .npz)
-        self.gp.save(tmp_gp)
+        self._ckpt_gen += 1
+        g = self._ckpt_gen
+        name = os.path.basename(self.save_path)
+        gp_file = f"{name}_gp.{g}.npz"
+        self.gp.save(os.path.join(self.save_dir, gp_file)[:-len(".npz")])
+        mc_file = None
+        if mc is not None:                                              # (arrays and scalars; acquisition uses 'x' only)
+            mc_file = f"{name}_mc.{g}.npz"
+            np.savez(os.path.join(self.save_dir, mc_file),
+                     **{k: np.asarray(v) for k, v in mc.items()
+                        if isinstance(v, (np.ndarray, float, int, str, np.generic))})
         st = dict(state, rng_state=self.np_rng.bit_generator.state, gp_training_set_size=int(self.gp.npoints),
                   n_points_since_last_fit=int(self.n_points_since_last_fit), timing=dict(self.timing),
-                  has_mc=mc is not None)
-        tmp_mc = None
-        if mc is not None:                                              # (arrays and scalars; acquisition uses 'x' only)
-            tmp_mc = self.save_path + "_mc.tmp.npz"
-            np.savez(tmp_mc, **{k: np.asarray(v) for k, v in mc.items()
-                                if isinstance(v, (np.ndarray, float, int, str, np.generic))})
+                  generation=g, gp_file=gp_file, mc_file=mc_file)
         tmp = self.save_path + "_run.json.tmp"
         with open(tmp, "w") as fh:
             json.dump(st, fh)
-        os.replace(tmp_gp + ".npz", self.save_path + "_gp.npz")
-        if tmp_mc is not None:
-            os.replace(tmp_mc, self.save_path + "_mc.npz")
         os.replace(tmp, self.save_path + "_run.json")                  # (never a half-written state file)
+        self._save_gp_file(os.path.join(self.save_dir, gp_file))
+        for f in os.listdir(self.save_dir):                             # prune the generations before this one
+            for stem in (name + "_gp.", name + "_mc."):
+                if f.startswith(stem) and f.endswith(".npz") and f[len(stem):-len(".npz")].isdigit() \
+                        and int(f[len(stem):-len(".npz")]) < g:
+                    try:
+                        os.remove(os.path.join(self.save_dir, f))
+                    except OSError:
+                        pass
 
+    def _run_state(self) -> dict:
+        """What a resumed run continues from (bo.py:337-372: iteration, histories, convergence state)."""
+        num = (int, float, np.floating, np.integer)
+        return {"acq": self.acquisition.name if self.acquisition is not None else None,
+                "iteration": int(self.current_iteration), "current_evals": int(self._current_evals),
+                "n_since_ns": int(self.n_points_since_last_ns), "counter": int(self.convergence_counter),
+                "acq_history": [float(a) for a in self.acquisition_history], "converged": bool(self.converged),
+                "termination_reason": self.termination_reason,
+                "logz": {k: (v if isinstance(v, bool) else float(v)) for k, v in (self.results_dict.get("logz") or {}).items()
+                         if isinstance(v, num + (bool,))}}
+
+    # ------------------------------------------------------------------ run helper methods (bo.py:617-934)
     def _evaluate(self, pts: np.ndarray) -> np.ndarray:
         """Safe likelihood wrapper (likelihood.py:69-91): NaN / exceptions / -inf -> minus_inf."""
         t0 = time.time()
@@ -259,215 +363,375 @@ class BOBE:
         self.timing["True Objective Evaluations"] += time.time() - t0
         return out
 
-    def update_gp(self, new_pts_u: np.ndarray, new_vals: np.ndarray, fit_n_points: int) -> None:
-        """bo.py:620-676 — count, decide (``refit_policy``), ``gp.update``, multi-restart fit, classifier retrain."""
+    def update_gp(self, new_pts_u, new_vals, step=0, verbose=True) -> None:
+        """bo.py:621-676 — count, decide (``refit_policy`` with the ``fit_n_points`` that ``run`` stored, bo.py:1083),
+        ``gp.update``, multi-restart fit, hyper-parameter tracking, classifier retrain."""
         t0 = time.time()
+        new_pts_u = np.atleast_2d(np.asarray(new_pts_u, dtype=np.float64))
         refit, n_restarts, maxiter, self.n_points_since_last_fit = refit_policy(
-            self.gp.train_x.shape[0], self.n_points_since_last_fit, new_pts_u.shape[0], fit_n_points)
+            self.gp.train_x.shape[0], self.n_points_since_last_fit, new_pts_u.shape[0], self.fit_n_points)
         self.gp.update(new_pts_u, new_vals)
         if getattr(self.gp, "not_pd", False):        # the new point made K numerically singular at the old
             refit = True                             # hyper-parameters (NaN factor, like XLA): refit now
         if refit:
+            if verbose:
+                log.info(f"Refitting GP hyperparameters with {self.gp.train_x.shape[0]} training points ")
             gp_fit(self.gp, n_restarts=n_restarts, maxiters=maxiter, rng=self.np_rng)
             self.n_points_since_last_fit = 0
         self.timing["GP Training"] += time.time() - t0
+        self.gp_hyperparam_history.append({"iteration": int(step), "lengthscales": [float(v) for v in self.gp.lengthscales],
+                                           "kernel_variance": float(self.gp.kernel_variance)})
         if hasattr(self.gp, "train_classifier"):     # bo.py:673-676: the labels move with the best value seen
             t0 = time.time()
             self.gp.train_classifier()
             self.timing["Classifier Training"] = self.timing.get("Classifier Training", 0.0) + time.time() - t0
 
-    def _mc_samples(self, method, num_hmc_warmup, num_hmc_samples, thinning, num_chains, num_mc_samples):
-        if method == "NUTS":                         # bo.py:1243-1255: HMC settings of run()
-            return get_mc_samples(self.gp, warmup_steps=num_hmc_warmup, num_samples=num_hmc_samples, thinning=thinning,
-                                  method="NUTS", num_chains=num_chains, np_rng=self.np_rng)
-        return get_mc_samples(self.gp, num_samples=num_mc_samples, method=method, np_rng=self.np_rng)
+    def get_next_batch(self, acq_kwargs, n_batch, n_restarts, maxiter, early_stop_patience, step, verbose=True):
+        """bo.py:681-705: the acquisition's kriging-believer batch + the mean acquisition value in the history."""
+        t0 = time.time()
+        new_pts_u, acq_vals = self.acquisition.get_next_batch(gp=self.gp, n_batch=n_batch, acq_kwargs=acq_kwargs,
+                                                              n_restarts=n_restarts, maxiter=maxiter,
+                                                              early_stop_patience=early_stop_patience, rng=self.np_rng)
+        self.timing["Acquisition Optimization"] += time.time() - t0
+        acq_val = float(np.mean(acq_vals))
+        if verbose:
+            log.debug(f"Mean acquisition value {acq_val:.4e} at new points")
+        self.acquisition_history.append(acq_val)
+        return new_pts_u, acq_vals
 
-    def run(self, acq=None, min_evals: int = 200, max_evals: int = 1500, max_gp_size: int = 1200,
-            logz_threshold: float = 0.01, convergence_n_iters: int = 1, do_final_ns: bool = False,
-            fit_n_points: int = 10, ns_n_points: int = 10, batch_size: int = 1, num_hmc_warmup: int = 512,
-            num_hmc_samples: int = 512, mc_points_size: int = 64, thinning: int = 4, num_chains: int = 4,
-            mc_points_method: str = "NUTS", zeta_ei: float = 0.01, ei_goal: float = 1e-10,
+    def evaluate_likelihood(self, new_pts_u, step, verbose=True):
+        """bo.py:707-756: likelihood values (n, 1) at unit-cube points; keeps the best point seen."""
+        new_pts_u = np.atleast_2d(np.asarray(new_pts_u, dtype=np.float64))
+        new_pts = scale_from_unit(new_pts_u, self.param_bounds)
+        new_vals = self._evaluate(new_pts)
+        ibest = int(np.argmax(new_vals))
+        if float(new_vals[ibest, 0]) > self.best_f:
+            self.best_f = float(new_vals[ibest, 0])
+            self.best_pt = new_pts[ibest].reshape(-1)
+            self.best = {name: f"{float(val):.6f}" for name, val in zip(self.param_list, self.best_pt)}
+            self.best_pt_iteration = step
+        return new_vals
+
+    def check_max_evals_and_gpsize(self, current_evals) -> bool:
+        """bo.py:758-777."""
+        if current_evals >= self.max_evals:
+            self.termination_reason = "Maximum evaluations reached"
+        elif self.gp.train_x.shape[0] >= self.max_gp_size:
+            self.termination_reason = "Maximum GP size reached"
+        else:
+            return False
+        self.results_dict["termination_reason"] = self.termination_reason
+        return True
+
+    def finalise_results(self) -> None:
+        """bo.py:779-836: the results dictionary - the reference's eight keys first (its results manager is a plain dict
+        here: histories, timing, settings), then this driver's conveniences."""
+        clf = hasattr(self.gp, "train_classifier")
+        gp_info = {"gp_training_set_size": int(self.gp.train_x.shape[0]), "gp_final_best_loglike": float(self.best_f),
+                   "classifier_used": bool(getattr(self.gp, "use_clf", False)) if clf else False,
+                   "classifier_type": str(self.gp.clf_type) if clf else None,
+                   "classifier_training_set_size": int(getattr(self.gp, "clf_data_size", 0)) if clf else 0}
+        logz = self.results_dict.get("logz", {})
+        if not logz:
+            log.warning("No logz information found, nested sampling has not been run yet.")
+        manager = {"likelihood_name": self.likelihood_name, "param_list": self.param_list,
+                   "param_labels": self.param_labels, "settings": dict(self.settings),
+                   "acquisition_history": list(self.acquisition_history),
+                   "gp_hyperparams": list(self.gp_hyperparam_history), "kl_divergences": list(self.kl_history),
+                   "convergence_history": list(self.convergence_history), "timing": dict(self.timing),
+                   "converged": bool(self.converged), "termination_reason": self.termination_reason, "gp_info": gp_info,
+                   "gp_training_set_size": int(self.gp.npoints)}
+        self.results_dict = {"gp": self.gp, "likelihood": self.loglikelihood, "results_manager": manager,
+                             "best_val": float(self.best_f), "best_pt": self.best_pt, "logz": logz,
+                             "termination_reason": self.termination_reason, "samples": self.samples_dict or {},
+                             # conveniences of this driver
+                             "best_x": self.best_pt, "n_evals": int(self.gp.npoints),
+                             "acq_history": list(self.acquisition_history), "timing": dict(self.timing),
+                             "lengthscales": np.array(self.gp.lengthscales),
+                             "kernel_variance": float(self.gp.kernel_variance), "converged": bool(self.converged)}
+
+    def check_convergence_ei(self, step, acq_val) -> bool:
+        """bo.py:838-867: log EI below log(ei_goal), ``convergence_n_iters`` times in a row."""
+        acq_val = float(np.asarray(acq_val).reshape(-1)[-1])
+        if self.acquisition.name.lower() == "ei":
+            acq_val = float(np.log(acq_val + 1e-100))
+        if acq_val < self.ei_goal_log:
+            self.convergence_counter += 1
+            return self.convergence_counter >= self.convergence_n_iters
+        self.convergence_counter = 0
+        return False
+
+    def check_convergence_logz(self, step, logz_dict, equal_samples, equal_logl, verbose=True, save_checkpoint=True) -> bool:
+        """bo.py:869-961: (upper - lower)/2 < ``logz_threshold``, ``convergence_n_iters`` times in a row; the Gaussian KL
+        divergence between successive posterior samples is recorded beside it; a new smallest half-width saves
+        ``<save_path>_checkpoint_gp.npz`` when files are written at all.  Not in the reference: a nested-sampling run cut
+        by its call budget is never taken as evidence of convergence."""
+        if logz_dict.get("truncated"):                           # the sampler was cut by its call budget: its evidence is a
+            log.warning("nested sampling hit its call budget; not testing convergence on a truncated run")
+            self.convergence_counter = 0                         # lower bound, not an estimate (the reference's dynesty run
+            return False                                         # would stop the same way, silently)
+        delta = (logz_dict["upper"] - logz_dict["lower"]) / 2.0
+        delta_crosscheck = float(logz_dict.get("std", 0.0))
+        below = delta < self.logz_threshold
+        eq = scale_from_unit(np.atleast_2d(np.asarray(equal_samples, dtype=np.float64)), self.param_bounds)
+        if self.prev_samples is not None and eq.shape[0] > self.ndim and self.prev_samples["x"].shape[0] > self.ndim:
+            from .utils import kl_divergence_gaussian
+            a = self.prev_samples["x"]
+            kl = kl_divergence_gaussian(np.mean(a, axis=0), np.atleast_2d(np.cov(a, rowvar=False)),
+                                        np.mean(eq, axis=0), np.atleast_2d(np.cov(eq, rowvar=False)))
+            self.kl_history.append(dict(kl, iteration=int(step)))
+            if verbose:
+                log.info(f"Successive KL: symmetric={kl.get('symmetric', 0):.4f}")
+        self.prev_samples = {"x": eq, "logl": np.asarray(equal_logl)}
+        self.convergence_history.append({"iteration": int(step), "delta": float(delta), "converged": bool(below),
+                                         "threshold": float(self.logz_threshold)})
+        if verbose:
+            log.info(f"Convergence check: delta = {delta:.4f}, step = {step}, threshold = {self.logz_threshold}")
+        if below:
+            self.convergence_counter += 1
+            converged = self.convergence_counter >= self.convergence_n_iters
+        else:
+            self.convergence_counter = 0
+            converged = False
+        if delta < self.min_delta_seen and delta_crosscheck < 1.0 and save_checkpoint:
+            self.min_delta_seen = delta
+            if not converged and self.save:
+                os.makedirs(self.save_dir, exist_ok=True)
+                self.gp.save(self.save_path + "_checkpoint_gp")
+        return converged
+
+    # ------------------------------------------------------------------ main run methods (bo.py:963-1397)
+    def run(self, acq="wipstd", min_evals: int = 200, max_evals: int = 1500, max_gp_size: int = 1200,
+            logz_threshold: float = 0.01, convergence_n_iters: int = 1, ei_goal: float = 1e-10,
+            do_final_ns: bool = False, fit_n_points: int = 10, batch_size: int = 4, ns_n_points: int = 10,
+            num_hmc_warmup: int = 512, num_hmc_samples: int = 512, mc_points_size: int = 64, thinning: int = 4,
+            num_chains: int = 4, mc_points_method: str = "NUTS", zeta_ei: float = 0.01, *,
             num_mc_samples: int = 1024, acq_threshold: Optional[float] = None, verbose: bool = False) -> dict:
-        """``BOBE.run`` (bo.py:967-1172): the keywords and defaults of the reference (plus ``num_mc_samples`` for the
-        'uniform' / 'NS' integration-point methods and an optional ``acq_threshold`` stop).
+        """``BOBE.run`` (bo.py:967-1172): the reference's keywords in its order with its defaults (``acq='wipstd'``,
+        batches of 4); keyword-only extras: ``num_mc_samples`` for the 'uniform' / 'NS' integration-point methods, an
+        optional ``acq_threshold`` stop, ``verbose``.  ``acq`` may be a tuple of stages, run one after the other on the
+        same surrogate (the evident intent of bo.py:1143-1156, whose tuple branch never binds ``acqs``).
 
-        WIPV / WIPStd (bo.py:1226-1385): integration samples once before the loop; per iteration a kriging-believer
-        batch, likelihood evaluations, ``update_gp``; when ``ns_n_points`` new evaluations have accumulated past
-        ``min_evals`` AND the last acquisition value is <= ``logz_threshold``, nested sampling on the surrogate —
-        its equal-weight samples become the next integration samples and (upper - lower)/2 < threshold,
-        ``convergence_n_iters`` times in a row, ends the run ("LogZ converged", bo.py:886-934); otherwise fresh
-        integration samples.  EI / LogEI (bo.py:1174-1224): one point per iteration, log-EI goal."""
-        from .samplers import nested_sampling, resample_equal
-        acq = acq if acq is not None else self.default_acq
-        if isinstance(acq, (tuple, list)):                       # the reference accepts a tuple of stages: first one
-            acq = acq[0]
-        acq_fn = _ACQ[acq.lower()]()
-        is_wip = acq.lower() in ("wipv", "wipstd")
-        acq_hist: List[float] = []
-        logz: dict = {}
-        ns_samples: Optional[dict] = None
-        ns_success = False
-        converged, counter, n_since_ns = False, 0, 0
-        reason, it = "Max evaluation budget reached", 0          # bo.py:1093
+        WIPV / WIPStd (``run_weighted_integrated_posterior``, bo.py:1226-1385): integration samples once before the
+        loop; per iteration a kriging-believer batch, likelihood evaluations, ``update_gp``; when ``ns_n_points`` new
+        evaluations have accumulated past ``min_evals`` AND the last acquisition value is <= ``logz_threshold``, nested
+        sampling on the surrogate — its equal-weight samples become the next integration samples and
+        (upper - lower)/2 < threshold, ``convergence_n_iters`` times in a row, ends the run ("LogZ converged",
+        bo.py:886-934); otherwise fresh integration samples.  EI / LogEI (``run_EI``, bo.py:1174-1224): one point per
+        iteration, log-EI goal."""
+        self.min_evals, self.max_evals, self.max_gp_size = min_evals, max_evals, max_gp_size
+        self.logz_threshold = logz_threshold
+        self.samples_dict, self.results_dict = {}, {}
+        self.convergence_n_iters = convergence_n_iters
+        self.ei_goal_log = np.log(ei_goal)
+        self.do_final_ns = do_final_ns
+        self.fit_n_points, self.ns_n_points, self.batch_size = fit_n_points, ns_n_points, batch_size
         self.n_points_since_last_fit = 0
+        self.n_points_since_last_ns = 0
+        self.num_hmc_warmup, self.num_hmc_samples, self.mc_points_size = num_hmc_warmup, num_hmc_samples, mc_points_size
+        self.hmc_thinning, self.hmc_num_chains, self.mc_points_method = thinning, num_chains, mc_points_method
+        self.zeta_ei = zeta_ei
+        self.num_mc_samples, self.acq_threshold, self.verbose = num_mc_samples, acq_threshold, verbose
+        self.converged, self.convergence_counter = False, 0
+        self.min_delta_seen = np.inf
+        self.termination_reason = "Max evaluation budget reached"          # bo.py:1118
+        self.settings.update({"min_evals": min_evals, "max_evals": max_evals, "max_gp_size": max_gp_size,
+                              "logz_threshold": logz_threshold, "convergence_n_iters": convergence_n_iters,
+                              "ei_goal": ei_goal, "do_final_ns": do_final_ns, "fit_n_points": fit_n_points,
+                              "batch_size": batch_size, "ns_n_points": ns_n_points, "num_hmc_warmup": num_hmc_warmup,
+                              "num_hmc_samples": num_hmc_samples, "mc_points_size": mc_points_size,
+                              "thinning": thinning, "num_chains": num_chains, "mc_points_method": mc_points_method,
+                              "zeta_ei": zeta_ei})                         # bo.py:1121-1139
         self.timing.setdefault("Nested Sampling", 0.0)
         self.timing.setdefault("MCMC Sampling", 0.0)
-        current_evals = self.gp.npoints
-        mc_args = (mc_points_method, num_hmc_warmup, num_hmc_samples, thinning, num_chains, num_mc_samples)
-
-        def check_logz(lz) -> bool:                              # bo.py:871-934 (the KL bookkeeping is results-manager work)
-            nonlocal counter
-            if lz.get("truncated"):                              # the sampler was cut by its call budget: its evidence is a
-                log.warning("nested sampling hit its call budget; not testing convergence on a truncated run")
-                counter = 0                                      # lower bound, not an estimate (the reference's dynesty run
-                return False                                     # would stop the same way, silently)
-            delta = (lz["upper"] - lz["lower"]) / 2.0
-            if delta < logz_threshold:
-                counter += 1
-                return counter >= convergence_n_iters
-            counter = 0
-            return False
-
-        def check_budget() -> Optional[str]:                     # bo.py:757-775
-            if current_evals >= max_evals:
-                return "Maximum evaluations reached"
-            if self.gp.train_x.shape[0] >= max_gp_size:
-                return "Maximum GP size reached"
-            return None
-
-        mc = None
-        rs = self._resume_state
-        self._resume_state = None                                # (a second run() on this object starts from its current state)
-        if rs is not None and rs.get("acq", acq).lower() == acq.lower():
+        self.acquisition_history = []
+        self.mc_samples, self.ns_samples, self._ns_success = None, None, False
+        self._current_evals = self.gp.npoints
+        acqs = [acq] if isinstance(acq, str) else list(acq)
+        for a in acqs:
+            if a.lower() not in _ACQ:
+                raise ValueError(f"Invalid acquisition function '{a}'. Valid options are: {list(_ACQ)}")
+        self.current_iteration = self.start_iteration
+        rs, self._resume_state = self._resume_state, None        # (a second run() on this object starts from its current state)
+        if rs is not None and str(rs.get("acq") or acqs[0]).lower() == acqs[0].lower():
             # continue the interrupted run (bo.py:337-372: iteration, histories, convergence state)
-            it, current_evals, n_since_ns, counter = rs["iteration"], rs["current_evals"], rs["n_since_ns"], rs["counter"]
-            acq_hist, logz = list(rs["acq_history"]), dict(rs.get("logz") or {})
+            self.current_iteration, self._current_evals = int(rs["iteration"]), int(rs["current_evals"])
+            self.n_points_since_last_ns, self.convergence_counter = int(rs["n_since_ns"]), int(rs["counter"])
+            self.acquisition_history = list(rs["acq_history"])
+            if rs.get("logz"):
+                self.results_dict["logz"] = dict(rs["logz"])
             self.n_points_since_last_fit = int(rs.get("n_points_since_last_fit", 0))
             for k_, v_ in (rs.get("timing") or {}).items():
                 self.timing[k_] = float(v_)
             self.np_rng.bit_generator.state = rs["rng_state"]
-            mc = rs.get("mc")
+            self.mc_samples = rs.get("mc")
             if rs.get("converged"):                              # the saved run had already met its stopping rule
-                converged, reason = True, rs.get("termination_reason", "LogZ converged")
-        if is_wip and mc is None:
-            t0 = time.time()
-            mc = self._mc_samples(*mc_args)
-            self.timing["MCMC Sampling"] += time.time() - t0
-
-        def run_state():
-            return {"acq": acq, "iteration": it, "current_evals": int(current_evals), "n_since_ns": int(n_since_ns),
-                    "counter": int(counter), "acq_history": [float(a) for a in acq_hist], "converged": bool(converged),
-                    "termination_reason": reason,
-                    "logz": {k_: (float(v_) if isinstance(v_, (int, float, np.floating, np.integer)) else v_)
-                             for k_, v_ in logz.items() if isinstance(v_, (int, float, bool, np.floating, np.integer))}}
-        while not converged:
-            it += 1
-            t0 = time.time()
-            if is_wip:
-                n_since_ns += batch_size
-                ns_flag = n_since_ns >= ns_n_points and current_evals >= min_evals
-                kwargs = {"mc_samples": mc, "mc_points_size": mc_points_size}
-                new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=batch_size, acq_kwargs=kwargs, n_restarts=1,
-                                                    maxiter=100, early_stop_patience=10, rng=self.np_rng)  # bo.py:1274
-                n_new = batch_size
+                self.converged = True
+                self.termination_reason = rs.get("termination_reason", "LogZ converged")
+        for a in acqs:
+            self.acquisition = _ACQ[a.lower()](optimizer=self.optimizer)
+            if a.lower() == "wipv":
+                self.run_WIPV(ii=self.current_iteration)
+            elif a.lower() == "wipstd":
+                self.run_WIPStd(ii=self.current_iteration)
             else:
-                kwargs = {"zeta": zeta_ei, "best_y": float(np.max(self.gp.train_y)) if self.gp.train_y.size else 0.0}
-                new_u, vals = acq_fn.get_next_batch(self.gp, n_batch=1, acq_kwargs=kwargs, n_restarts=50,
-                                                    maxiter=1000, early_stop_patience=50, rng=self.np_rng)  # bo.py:1194
-                n_new = 1
-            new_u = np.atleast_2d(new_u)
-            vals = np.atleast_1d(vals)
-            self.timing["Acquisition Optimization"] += time.time() - t0
-            acq_hist.append(float(np.mean(vals)))
-            new_vals = self._evaluate(scale_from_unit(new_u, self.param_bounds))
-            current_evals += n_new                               # a proposal the GP rejects as a duplicate still counts
-            self.update_gp(new_u, new_vals, fit_n_points)
-            if verbose:
-                log.info(f"Iteration {it}: N={self.gp.npoints} acq={acq_hist[-1]:.3e}")
-            if is_wip:
-                if ns_flag and float(vals[-1]) <= logz_threshold:            # bo.py:1283-1311
-                    t0 = time.time()
-                    ns_samples, lz, ns_success = nested_sampling(self.gp, mode="convergence", dlogz=0.01,
-                                                                 equal_weights=False, rng=self.np_rng)
-                    self.timing["Nested Sampling"] += time.time() - t0
-                    if ns_success:
-                        eq_x, eq_l = resample_equal(ns_samples["x"], ns_samples["logl"], ns_samples["weights"],
-                                                    rng=self.np_rng)
-                        mc = {"x": eq_x, "logl": eq_l, "weights": np.ones(eq_x.shape[0]), "method": "NS",
-                              "best": ns_samples["best"]}
-                        logz = lz
-                        converged = check_logz(lz)
-                        if converged:
-                            reason = "LogZ converged"
-                    n_since_ns = 0
-                else:                                                        # bo.py:1313-1324
-                    t0 = time.time()
-                    mc = self._mc_samples(*mc_args)
-                    self.timing["MCMC Sampling"] += time.time() - t0
-                if acq_threshold is not None and acq_hist[-1] <= acq_threshold and not converged:
-                    reason = "Acquisition threshold reached"
-                    break
-            else:                                                            # bo.py:838-866, 1208-1218
-                goal_val = float(vals[-1])
-                if acq.lower() == "ei":
-                    goal_val = float(np.log(goal_val + 1e-100))
-                if goal_val < np.log(ei_goal):
-                    counter += 1
-                    if counter >= convergence_n_iters:
-                        converged, reason = True, f"{acq_fn.name.upper()} goal reached"
-                else:
-                    counter = 0
-            if self.save and it % self.save_step == 0:
-                self._checkpoint(run_state(), mc if is_wip else None)
+                self.run_EI(ii=self.current_iteration)
+        log.info(f"Final best point {self.best} with value = {self.best_f:.6f}, found at iteration {self.best_pt_iteration}")
+        log.info(f"Sampling stopped: {self.termination_reason}")
+        log.info(f"Final GP training set size: {self.gp.train_x.shape[0]}, max size: {self.max_gp_size}")
+        self.finalise_results()
+        self.start_iteration = self.current_iteration            # (a further run() on this object counts on)
+        return self.results_dict
+
+    def run_EI(self, ii=0):
+        """bo.py:1174-1224: one point per iteration; stops on the (log-)EI goal or the budgets."""
+        current_evals = self._current_evals
+        converged = self.converged
+        while not converged:
+            ii += 1
+            self.current_iteration = ii
+            if self.verbose:
+                log.info(f"Iteration {ii} of {self.acquisition.name}, objective evals {current_evals}/{self.max_evals}")
+            acq_kwargs = {"zeta": self.zeta_ei,
+                          "best_y": float(np.max(self.gp.train_y)) if self.gp.train_y.size > 0 else 0.0}
+            n_batch = 1
+            new_pts_u, acq_vals = self.get_next_batch(acq_kwargs, n_batch=n_batch, n_restarts=50, maxiter=1000,
+                                                      early_stop_patience=50, step=ii, verbose=self.verbose)
+            new_pts_u = np.atleast_2d(new_pts_u)
+            new_vals = self.evaluate_likelihood(new_pts_u, ii, verbose=self.verbose)
+            current_evals += n_batch
+            self._current_evals = current_evals
+            self.update_gp(new_pts_u, new_vals, step=ii, verbose=self.verbose)
+            converged = self.check_convergence_ei(ii, acq_vals)
+            if converged:
+                self.converged = True
+                self.termination_reason = f"{self.acquisition.name.upper()} goal reached"
+                self.results_dict["termination_reason"] = self.termination_reason
+            if self.save and ii % self.save_step == 0:
+                self._checkpoint(self._run_state(), None)
             if converged:
                 break
-            budget = check_budget()
-            if budget is not None:
-                reason = budget
+            if self.check_max_evals_and_gpsize(current_evals):
                 break
+        self.current_iteration = ii
+        if self.save:
+            self._checkpoint(self._run_state(), None)
+
+    def _draw_mc_samples(self) -> dict:
+        """The integration samples of the next iteration (bo.py:1243-1255, 1313-1324)."""
+        t0 = time.time()
+        if self.mc_points_method == "NUTS":
+            mc = get_mc_samples(self.gp, warmup_steps=self.num_hmc_warmup, num_samples=self.num_hmc_samples,
+                                thinning=self.hmc_thinning, method="NUTS", num_chains=self.hmc_num_chains,
+                                np_rng=self.np_rng)
+        else:
+            mc = get_mc_samples(self.gp, num_samples=self.num_mc_samples, method=self.mc_points_method,
+                                np_rng=self.np_rng)
+        self.timing["MCMC Sampling"] += time.time() - t0
+        return mc
+
+    def run_weighted_integrated_posterior(self, acq_func_class, ii=0):
+        """bo.py:1226-1390 for WIPV / WIPStd (``acq_func_class``)."""
+        from .samplers import nested_sampling, resample_equal
+        self.acquisition = acq_func_class(optimizer=self.optimizer)
+        acq_name = self.acquisition.name
+        current_evals = self._current_evals
+        if self.mc_samples is None:                               # (a resumed run brings its own)
+            self.mc_samples = self._draw_mc_samples()
+        self.ns_samples, self._ns_success = None, False
+        while not self.converged:
+            ii += 1
+            self.current_iteration = ii
+            t_it = time.time()
+            self.n_points_since_last_ns += self.batch_size
+            ns_flag = self.n_points_since_last_ns >= self.ns_n_points and current_evals >= self.min_evals
+            if self.verbose:
+                log.info(f"Iteration {ii} of {acq_name}, objective evals {current_evals}/{self.max_evals}")
+            acq_kwargs = {"mc_samples": self.mc_samples, "mc_points_size": self.mc_points_size}
+            new_pts_u, acq_vals = self.get_next_batch(acq_kwargs, n_batch=self.batch_size, n_restarts=1, maxiter=100,
+                                                      early_stop_patience=10, step=ii, verbose=self.verbose)  # bo.py:1274
+            new_pts_u = np.atleast_2d(new_pts_u)
+            acq_vals = np.atleast_1d(acq_vals)
+            new_vals = self.evaluate_likelihood(new_pts_u, ii, verbose=self.verbose)
+            current_evals += self.batch_size                       # a proposal the GP rejects as a duplicate still counts
+            self._current_evals = current_evals
+            self.update_gp(new_pts_u, new_vals, step=ii, verbose=self.verbose)
+            if self.verbose:
+                log.info(f"Iteration {ii}: N={self.gp.npoints} acq={self.acquisition_history[-1]:.3e} "
+                         f"({time.time() - t_it:.2f} s)")
+            if ns_flag and float(acq_vals[-1]) <= self.logz_threshold:        # bo.py:1283-1311
+                t0 = time.time()
+                ns_samples, logz_dict, ns_success = nested_sampling(self.gp, mode="convergence", dlogz=0.01,
+                                                                    equal_weights=False, rng=self.np_rng)
+                self.timing["Nested Sampling"] += time.time() - t0
+                self.ns_samples, self._ns_success = ns_samples, ns_success
+                if ns_success:
+                    equal_samples, equal_logl = resample_equal(ns_samples["x"], ns_samples["logl"], ns_samples["weights"],
+                                                               rng=self.np_rng)
+                    self.mc_samples = {"x": equal_samples, "logl": equal_logl,
+                                       "weights": np.ones(equal_samples.shape[0]), "method": "NS",
+                                       "best": ns_samples["best"]}
+                    self.results_dict["logz"] = logz_dict
+                    self.converged = self.check_convergence_logz(ii, logz_dict, equal_samples, equal_logl,
+                                                                 verbose=self.verbose)
+                    if self.converged:
+                        self.termination_reason = "LogZ converged"
+                        self.results_dict["termination_reason"] = self.termination_reason
+                self.n_points_since_last_ns = 0
+            else:                                                            # bo.py:1313-1324
+                self.mc_samples = self._draw_mc_samples()
+            if self.acq_threshold is not None and self.acquisition_history[-1] <= self.acq_threshold \
+                    and not self.converged:
+                self.termination_reason = "Acquisition threshold reached"
+                break
+            if self.save and ii % self.save_step == 0:
+                self._checkpoint(self._run_state(), self.mc_samples)
+            if self.converged:
+                break
+            if self.check_max_evals_and_gpsize(current_evals):
+                break
+        self.current_iteration = ii
         if self.save:
             # the state a resumed run continues from is the state at the END OF THE LOOP: what follows (a final fit and
             # nested sampling, the result samples) draws from the generator but is not part of the iteration
-            self._checkpoint(run_state(), mc if is_wip else None)
-        if is_wip and do_final_ns and not converged:                         # bo.py:1345-1366
+            self._checkpoint(self._run_state(), self.mc_samples)
+        ns_success = self._ns_success
+        if self.do_final_ns and not self.converged:                          # bo.py:1345-1366
             t0 = time.time()
             gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng)
             self.timing["GP Training"] += time.time() - t0
             t0 = time.time()
-            ns_samples, lz, ns_success = nested_sampling(self.gp, mode="convergence", dlogz=0.01, rng=self.np_rng)
+            self.ns_samples, logz_dict, ns_success = nested_sampling(self.gp, mode="convergence", dlogz=0.01,
+                                                                     rng=self.np_rng)
             self.timing["Nested Sampling"] += time.time() - t0
             if ns_success:
-                logz = lz
-                if check_logz(lz):
-                    converged, reason = True, "LogZ converged"
-        samples: dict = {}
-        if is_wip:                                                           # bo.py:1368-1385
-            if ns_samples is not None and ns_success:
-                x_u, weights, logl = ns_samples["x"], ns_samples["weights"], ns_samples["logl"]
-            else:
-                t0 = time.time()
-                hm = get_mc_samples(self.gp, warmup_steps=512, num_samples=2000 * self.ndim, thinning=4, method="NUTS",
-                                    np_rng=self.np_rng)
-                self.timing["MCMC Sampling"] += time.time() - t0
-                x_u = hm["x"]
-                weights = hm["weights"] if "weights" in hm else np.ones(hm["x"].shape[0])
-                logl = hm["logp"] if "logp" in hm else hm.get("logl")
-            samples = {"x": scale_from_unit(np.asarray(x_u), self.param_bounds), "weights": np.asarray(weights),
-                       "logl": np.asarray(logl)}
-        if self.save and is_wip and do_final_ns:                             # (the final fit changed the hyper-parameters)
-            self.gp.save(self.save_path + "_gp.tmp")
-            os.replace(self.save_path + "_gp.tmp.npz", self.save_path + "_gp.npz")
-        y = self.gp.train_y * self.gp.y_std + self.gp.y_mean
-        ibest = int(np.argmax(y))
-        best_x = scale_from_unit(self.gp.train_x[ibest], self.param_bounds)
-        manager = {"likelihood_name": self.likelihood_name, "param_list": self.param_list,
-                   "param_labels": self.param_labels, "acquisition_history": list(acq_hist),
-                   "timing": dict(self.timing), "converged": converged, "termination_reason": reason,
-                   "gp_training_set_size": int(self.gp.npoints)}
-        # keys of the reference's results dict (bo.py:827-836); the rest are conveniences of this driver
-        return {"gp": self.gp, "likelihood": self.loglikelihood, "results_manager": manager,
-                "best_val": float(y[ibest, 0]), "best_pt": best_x, "logz": logz, "termination_reason": reason,
-                "samples": samples,
-                "best_x": best_x, "n_evals": int(self.gp.npoints), "acq_history": acq_hist, "timing": dict(self.timing),
-                "lengthscales": np.array(self.gp.lengthscales), "kernel_variance": float(self.gp.kernel_variance),
-                "converged": converged}
+                equal_samples, equal_logl = resample_equal(self.ns_samples["x"], self.ns_samples["logl"],
+                                                           self.ns_samples["weights"], rng=self.np_rng)
+                self.converged = self.check_convergence_logz(ii + 1, logz_dict, equal_samples, equal_logl,
+                                                             verbose=self.verbose, save_checkpoint=False)
+                self.results_dict["logz"] = logz_dict
+                if self.converged:
+                    self.termination_reason = "LogZ converged"
+                    self.results_dict["termination_reason"] = self.termination_reason
+            if self.save:                                                    # (the final fit changed the hyper-parameters)
+                self._save_gp_file()
+        if self.ns_samples is not None and ns_success:                       # bo.py:1368-1385
+            x_u, weights, logl = self.ns_samples["x"], self.ns_samples["weights"], self.ns_samples["logl"]
+        else:
+            t0 = time.time()
+            hm = get_mc_samples(self.gp, warmup_steps=512, num_samples=2000 * self.ndim, thinning=4, method="NUTS",
+                                np_rng=self.np_rng)
+            self.timing["MCMC Sampling"] += time.time() - t0
+            x_u = hm["x"]
+            weights = hm["weights"] if "weights" in hm else np.ones(hm["x"].shape[0])
+            logl = hm["logp"] if "logp" in hm else hm.get("logl")
+        self.samples_dict = {"x": scale_from_unit(np.asarray(x_u), self.param_bounds), "weights": np.asarray(weights),
+                             "logl": np.asarray(logl)}
+
+    def run_WIPStd(self, ii=0):
+        """bo.py:1392-1394."""
+        return self.run_weighted_integrated_posterior(WIPStd, ii)
+
+    def run_WIPV(self, ii=0):
+        """bo.py:1396-1398."""
+        return self.run_weighted_integrated_posterior(WIPV, ii)

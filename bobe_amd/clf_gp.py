@@ -232,6 +232,10 @@ class GPwithClassifier(GP):
             self._push_data()
             self.recompute_cholesky()
 
+    def kernel(self, x1, x2, lengthscales=None, kernel_variance=None, noise=None, include_noise=True):
+        """clf_gp.py:248-252 (argument names of the reference's override)."""
+        return super().kernel(x1, x2, lengthscales, kernel_variance, noise, include_noise=include_noise)
+
     def get_random_point(self, rng=None, nstd=None):
         """clf_gp.py:254-277 (the nstd -> threshold map of utils/core.py is replaced by clf_threshold)."""
         rng = rng if rng is not None else get_numpy_rng()

@@ -296,6 +296,9 @@ int bobe_gp_hmc_run(bobe_gp_t* g, int64_t P, double* state, double* adapt, const
                     double* hist, int thin, double* keep, double* dbg) {
   API_BEGIN
   NEED(g && state && adapt && inv_mass, "NULL argument");
+  NEED(!is_device_ptr(state) && !is_device_ptr(adapt) && !is_device_ptr(inv_mass) && !is_device_ptr(hist) &&
+           !is_device_ptr(keep) && !is_device_ptr(dbg),
+       "bobe_gp_hmc_run takes host pointers");
   g->hmc_run(P, state, adapt, inv_mass, seed, it0, niter, do_adapt, y_std, y_mean, temp, hist_from, hist, thin, keep, dbg);
   return BOBE_OK;
   API_END
@@ -305,6 +308,9 @@ int bobe_gp_rwalk(bobe_gp_t* g, int64_t P, double* X, double* logl, const double
                   uint64_t seed, double y_std, double y_mean, int* n_accepted, int* n_inside, double* dbg) {
   API_BEGIN
   NEED(g && X && logl && step && n_accepted && n_inside, "NULL argument");
+  NEED(!is_device_ptr(X) && !is_device_ptr(logl) && !is_device_ptr(step) && !is_device_ptr(n_accepted) &&
+           !is_device_ptr(n_inside) && !is_device_ptr(dbg),
+       "bobe_gp_rwalk takes host pointers");
   g->rwalk(P, X, logl, step, lstar, walks, seed, y_std, y_mean, n_accepted, n_inside, dbg);
   return BOBE_OK;
   API_END
@@ -336,6 +342,43 @@ int bobe_gp_kernel(bobe_gp_t* g, const double* A, int64_t nA, const double* B, i
   return BOBE_OK;
   API_END
 }
+
+int bobe_gp_dist_sq(bobe_gp_t* g, const double* A, int64_t nA, const double* B, int64_t nB, double* out) {
+  API_BEGIN
+  NEED(g && A && B && out, "NULL argument");
+  g->kernel_eval(A, nA, B, nB, nullptr, 0.0, 0.0, 0, out, true);
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_mll_from_k(bobe_gp_t* g, const double* K, int64_t n, const double* y, double* mll) {
+  API_BEGIN
+  NEED(g && K && y && mll, "NULL argument");
+  NEED(n >= 1, "n must be >= 1");
+  return g->mll_from_k(K, n, y, mll);
+  API_END
+}
+
+int bobe_gp_chol_row_update(bobe_gp_t* g, const double* L, int64_t n, const double* k, double k_self, double* v,
+                            double* diag) {
+  API_BEGIN
+  NEED(g && L && k && v && diag, "NULL argument");
+  NEED(n >= 1, "n must be >= 1");
+  g->chol_row_update(L, n, k, k_self, v, diag);
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_set_pivot_floor_ulp(bobe_gp_t* g, double ulp) {
+  API_BEGIN
+  NEED(g, "gp is NULL");
+  NEED(ulp >= 0.0, "ulp must be >= 0 (0: the sign test alone)");      // (NaN fails too)
+  g->pivot_ulp = ulp;
+  return BOBE_OK;
+  API_END
+}
+
+double bobe_gp_get_pivot_floor_ulp(bobe_gp_t* g) { return g ? g->pivot_ulp : -1.0; }
 
 int bobe_gp_get_chol(bobe_gp_t* g, double* L, double* alpha) {
   API_BEGIN

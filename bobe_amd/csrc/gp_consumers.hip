@@ -28,7 +28,7 @@ void bobe_gp::set_gate(const double* sv, int64_t n_sv, const double* dual, doubl
   use();
   sync();
   if (!sv || n_sv <= 0) {                      // clear
-    gate = Gate{nullptr, nullptr, 0, 0, 0.0, 0.0, 0.5, minus_inf};
+    gate = Gate{nullptr, nullptr, 0, 0, 0.0, 0.0, threshold, minus_inf};
     return;
   }
   if (!dual) throw Err(BOBE_ERR_ARG, "dual_coef is NULL");
@@ -219,7 +219,7 @@ void bobe_gp::rwalk(int64_t P, double* Xw, double* logl, const double* step, dou
 }
 
 void bobe_gp::kernel_eval(const double* A, int64_t nA, const double* B, int64_t nB, const double* ls, double kvar,
-                          double noise, int include_noise, double* out) {
+                          double noise, int include_noise, double* out, bool sqdist) {
   if (nA < 1 || nB < 1) throw Err(BOBE_ERR_ARG, "empty input");
   if (include_noise && nA != nB) throw Err(BOBE_ERR_ARG, "include_noise needs a square kernel matrix (gp.py:153)");
   use();
@@ -228,6 +228,10 @@ void bobe_gp::kernel_eval(const double* A, int64_t nA, const double* B, int64_t 
     for (int j = 0; j < d; ++j) hk.ls[j] = ls[j];
     hk.kvar = kvar;
     hk.noise = noise;
+  }
+  if (sqdist) {                                  // dist_sq: unscaled coordinates, kernel id 2 = the distance itself
+    for (int j = 0; j < d; ++j) hk.ls[j] = 1.0;
+    hk.kern = 2;
   }
   const int64_t pa = round_up(nA, TILE), pb = round_up(nB, TILE);
   const double* a_in = fetch(A, (size_t)nA * d, in_stage);
@@ -270,6 +274,7 @@ void bobe_gp::clone_from(bobe_gp& src) {
   sync();
   N = src.N;
   hyp = src.hyp;
+  pivot_ulp = src.pivot_ulp;
   if (Np != src.Np) {
     Np = src.Np;
     nb = src.nb;

@@ -74,6 +74,16 @@ const Tuning& tuning() {
   return t;
 }
 
+double default_pivot_floor_ulp() {
+  static const double v = [] {
+    const char* e = std::getenv("BOBE_PIVOT_FLOOR_ULP");
+    if (!e) return 64.0;
+    const double u = std::atof(e);
+    return u >= 0.0 ? u : 64.0;
+  }();
+  return v;
+}
+
 }  // namespace bobe
 
 void bobe_gp::build_probs() {
@@ -156,6 +166,10 @@ void bobe_gp::scale(const double* in, int64_t n, int64_t npad, const Hyper& h, d
       if (dc_ == 8) KM_LAUNCH(0, SQ, 8, grid, __VA_ARGS__);                                           \
       else if (dc_ == 16) KM_LAUNCH(0, SQ, 16, grid, __VA_ARGS__);                                    \
       else KM_LAUNCH(0, SQ, 32, grid, __VA_ARGS__);                                                   \
+    } else if (!SQ && h.kern == 2) {   /* dist_sq: cross form only */                                 \
+      if (dc_ == 8) KM_LAUNCH(2, false, 8, grid, __VA_ARGS__);                                        \
+      else if (dc_ == 16) KM_LAUNCH(2, false, 16, grid, __VA_ARGS__);                                 \
+      else KM_LAUNCH(2, false, 32, grid, __VA_ARGS__);                                                \
     } else {                                                                                          \
       if (dc_ == 8) KM_LAUNCH(1, SQ, 8, grid, __VA_ARGS__);                                           \
       else if (dc_ == 16) KM_LAUNCH(1, SQ, 16, grid, __VA_ARGS__);                                    \
@@ -562,11 +576,15 @@ void bobe_gp::factor_into(const Hyper& h, double* xst, double* a, double* linv, 
 }
 
 // the text of a BOBE_NOT_PD status: a non-positive pivot (the factorisation's info word), or pivots below pivot_floor
-std::string bobe_gp::not_pd_text(int inf, double min_diag) {
+std::string bobe_gp::not_pd_text(int inf, double min_diag) const {
   if (inf != 0x7f7f7f7f) return "kernel matrix not positive definite at column " + std::to_string(inf - 1);
-  char buf[160];
-  std::snprintf(buf, sizeof buf, "kernel matrix numerically singular: smallest pivot %.3g is below 64 ulp of its diagonal",
-                min_diag * min_diag);
+  char buf[200];
+  if (min_diag != min_diag)
+    std::snprintf(buf, sizeof buf, "kernel matrix not positive definite: NaN pivot");
+  else
+    std::snprintf(buf, sizeof buf,
+                  "kernel matrix numerically singular: smallest pivot %.3g is below %g ulp of its diagonal (rank test)",
+                  min_diag * min_diag, pivot_ulp);
   return buf;
 }
 
@@ -1011,6 +1029,80 @@ void bobe_gp::set_chol(const double* L, const double* alpha_in) {
   factored = true;
   forget_z();
   not_pd = false;
+}
+
+// ---- the reference's free functions on caller-supplied matrices (gp.py:170-197), on a handle that holds no training data
+void bobe_gp::size_workspace(int64_t n) {
+  if (have_data && n != N) throw Err(BOBE_ERR_STATE, "the handle holds training data of another size (use a data-less handle)");
+  if (have_data) return;
+  const int64_t np_new = round_up(n, TILE);
+  N = n;
+  if (np_new != Np) {
+    Np = np_new;
+    nb = (int)(Np / TILE);
+    alloc_for_n();
+  }
+}
+
+// gp_mll(k, train_y, num_points) (gp.py:170-178): Cholesky of the matrix handed in, alpha, the three MLL terms.  The
+// matrix has no kernel variance to scale a rank test with: a pivot <= 0 (or NaN) fails, nothing else - LAPACK's rule.
+int bobe_gp::mll_from_k(const double* K, int64_t n, const double* yv, double* mll) {
+  use();
+  sync();
+  size_workspace(n);
+  const double* k_in = fetch(K, (size_t)n * n, kout);
+  hipLaunchKernelGGL(k_load_padded_lower, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, stream, k_in, n,
+                     A2.d(), Np, Np, 1);
+  HIPCHK(hipMemsetAsync(w.p, 0, (size_t)Np * sizeof(double), stream));            // (w: the padded right-hand side)
+  HIPCHK(hipMemcpyAsync(w.p, yv, (size_t)n * sizeof(double),
+                        is_device_ptr(yv) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemsetAsync(info.p, 0x7f, sizeof(int), stream));
+  potrf(A2.d(), Linv2.d(), static_cast<int*>(info.p), 1, 0, 0, nullptr, true);
+  trtri(A2.d(), Linv2.d(), Tmp.d());
+  solve_alpha(Linv2.d(), w2.d(), alpha2.d(), part.d(), 1, 0, 0, 0, w.d(), 0);
+  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w2.d(), (const double*)A2.d(), Np, Np, res.d(),
+                     (int64_t)0, (int64_t)0, (int64_t)0, (const int*)info.p);
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(h_res, res.p, 102 * sizeof(double), hipMemcpyDeviceToHost, stream));
+  sync();
+  int inf;
+  std::memcpy(&inf, h_res + 100, sizeof(int));
+  if (inf != 0x7f7f7f7f || !(h_res[101] > 0.0)) {
+    *mll = std::nan("");
+    g_err = not_pd_text(inf, h_res[101]);
+    return BOBE_NOT_PD;
+  }
+  *mll = -0.5 * h_res[0] - h_res[1] - 0.5 * (double)n * std::log(2.0 * M_PI);
+  return BOBE_OK;
+}
+
+// fast_update_cholesky(L, k, k_self) (gp.py:181-197): v = L^-1 k and the new diagonal entry sqrt(k_self - v.v) (NaN when
+// that is negative, like jnp.sqrt); the caller owns L and lays out the (n+1) x (n+1) factor itself.
+void bobe_gp::chol_row_update(const double* L, int64_t n, const double* k, double k_self, double* v, double* diag_out) {
+  use();
+  sync();
+  size_workspace(n);
+  const double* l_in = fetch(L, (size_t)n * n, kout);
+  hipLaunchKernelGGL(k_load_padded_lower, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, stream, l_in, n,
+                     A2.d(), Np, Np, 0);
+  HIPCHK(hipMemsetAsync(w.p, 0, (size_t)Np * sizeof(double), stream));
+  HIPCHK(hipMemcpyAsync(w.p, k, (size_t)n * sizeof(double),
+                        is_device_ptr(k) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+  for (int kb = 0; kb < nb; ++kb)                      // the 16 x 16 diagonal inverses the block inverse starts from
+    hipLaunchKernelGGL(k_potf2<false>, dim3(1), dim3(256), POTF2_SMEM_BYTES, stream, A2.d(), Np, Linv2.d(), Np, kb,
+                       static_cast<int*>(info.p));
+  LAUNCH_CHECK();
+  trtri(A2.d(), Linv2.d(), Tmp.d());
+  hipLaunchKernelGGL(k_gemv_lower, dim3((unsigned)(Np / 4), 1u), dim3(256), 0, stream, (const double*)Linv2.d(), Np, Np,
+                     (const double*)w.d(), w2.d(), (int64_t)0, (int64_t)0, (int64_t)0);
+  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w2.d(), (const double*)A2.d(), Np, Np, res.d(),
+                     (int64_t)0, (int64_t)0, (int64_t)0, (const int*)nullptr);
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(h_res, res.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));      // [0] = v.v
+  HIPCHK(hipMemcpyAsync(v, w2.p, (size_t)n * sizeof(double),
+                        is_device_ptr(v) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+  sync();
+  *diag_out = std::sqrt(k_self - h_res[0]);
 }
 
 void bobe_gp::kinv_debug(double* Kinv) {

@@ -84,12 +84,15 @@ struct DBuf {
 // log-determinant built on it (a too small one - the optimiser is drawn to exactly these hyper-parameters).  Such a
 // factorisation counts as NOT positive definite, like one with a non-positive pivot: NaN outputs, BOBE_NOT_PD.  (LAPACK's
 // dpotrf, the reference's Cholesky, tests the sign only and fails or passes on the last bit in this regime)
-inline double pivot_floor(const Hyper& h) {
-  const double f = 64.0 * 2.220446049250313e-16 * (h.kvar + h.noise);
+// The factor (64) is per handle: bobe_gp_set_pivot_floor_ulp, default from BOBE_PIVOT_FLOOR_ULP; 0 switches the rank test
+// off, leaving LAPACK's rule (a pivot <= 0 or NaN fails, nothing else).
+inline double pivot_floor(const Hyper& h, double ulp) {
+  const double f = ulp * 2.220446049250313e-16 * (h.kvar + h.noise);
   return f < 0.25 ? f : 0.25;                        // (the identity padding's pivots are 1)
 }
 // min_diag: the smallest L_jj of a factor (k_mll_terms, res[101]); NaN counts as failed
 inline bool pivots_resolved(double min_diag, double floor) { return min_diag * min_diag >= floor; }
+double default_pivot_floor_ulp();                    // BOBE_PIVOT_FLOOR_ULP, else 64
 
 template <typename K>
 void allow_big_lds(K kernel, int bytes) {
@@ -148,6 +151,8 @@ struct bobe_gp {
   int64_t N = 0, Np = 0;
   int nb = 0;
   Hyper hyp;
+  double pivot_ulp = bobe::default_pivot_floor_ulp();     // the rank test's factor (0: sign test only, as dpotrf)
+  double pivot_floor(const Hyper& h) const { return bobe::pivot_floor(h, pivot_ulp); }
   bool have_data = false, factored = false, not_pd = false;
   // prepare_z() keeps its results (ZsT, W_Z, base_z) while the same host Z arrives again and nothing they depend on
   // changed: an L-BFGS refinement of one acquisition point calls bobe_gp_wip_grad dozens of times with one Z
@@ -345,7 +350,11 @@ struct bobe_gp {
                    int64_t bsP = 0, const double* rhs = nullptr, int64_t bsY = 0);
   void factor_into(const Hyper& h, double* xst, double* a, double* linv, double* wv, double* al,
                    const Hyper* hdev = nullptr);
-  static std::string not_pd_text(int inf, double min_diag);
+  std::string not_pd_text(int inf, double min_diag) const;
+  // gp_mll(k, train_y, num_points) / fast_update_cholesky(L, k, k_self) on caller-supplied matrices (gp.py:170-197)
+  void size_workspace(int64_t n);
+  int mll_from_k(const double* K, int64_t n, const double* yv, double* mll);
+  void chol_row_update(const double* L, int64_t n, const double* k, double k_self, double* v, double* diag_out);
   int factor_state();                                  // bobe_gp_factor
   void copy_out_matrix(const double* src, double* dst, int lower_only);
   void get_chol(double* L, double* alpha_out);
@@ -376,8 +385,9 @@ struct bobe_gp {
                double* dbg);
   void rwalk(int64_t P, double* Xw, double* logl, const double* step, double lstar, int walks, uint64_t seed, double y_std,
              double y_mean, int* nacc, int* nin, double* dbg);
+  // sqdist: the squared distances of the rows as they are (dist_sq, gp.py:80-96) instead of kernel values
   void kernel_eval(const double* A, int64_t nA, const double* B, int64_t nB, const double* ls, double kvar, double noise,
-                   int include_noise, double* out);
+                   int include_noise, double* out, bool sqdist = false);
   void clone_from(bobe_gp& src);
   void release_all();
 };

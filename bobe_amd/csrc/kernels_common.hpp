@@ -22,6 +22,8 @@ template <int KERN>
 __device__ __forceinline__ double kern_eval(double r2, double kvar) {
   if (KERN == 0) {
     return kvar * exp(-0.5 * r2);
+  } else if (KERN == 2) {
+    return r2;                                // dist_sq (gp.py:80-96): the squared distance itself
   } else {
     const double dd = sqrt(r2 < 1e-30 ? 1e-30 : r2);
     const double e = exp(-SQRT5 * dd);
@@ -311,12 +313,15 @@ __device__ __forceinline__ void mll_terms_body(int slot, const double* __restric
     const double lii = L[i * ld + i];
     a += w[i] * w[i];
     b += log(lii);
-    mn = fmin(mn, lii);
+    mn = (lii < mn || lii != lii) ? lii : mn;     // (fmin would drop a NaN diagonal: NaN counts as failed)
   }
   a = wave_sum(a);
   b = wave_sum(b);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, __shfl_xor(mn, o, 64));
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_xor(mn, o, 64);
+    mn = (other < mn || other != other) ? other : mn;
+  }
   if ((threadIdx.x & 63) == 0) {
     r0[threadIdx.x >> 6] = a;
     r1[threadIdx.x >> 6] = b;
@@ -326,7 +331,10 @@ __device__ __forceinline__ void mll_terms_body(int slot, const double* __restric
   if (threadIdx.x == 0) {
     res[0] = ((r0[0] + r0[1]) + r0[2]) + r0[3];
     res[1] = ((r1[0] + r1[1]) + r1[2]) + r1[3];
-    res[101] = fmin(fmin(r2[0], r2[1]), fmin(r2[2], r2[3]));      // smallest pivot's root: the hosts's rank test (pivot_floor)
+    double m = r2[0];                                             // smallest pivot's root: the host's rank test (pivot_floor)
+#pragma unroll
+    for (int q = 1; q < 4; ++q) m = (r2[q] < m || r2[q] != r2[q]) ? r2[q] : m;
+    res[101] = m;
   }
 }
 static __global__ __launch_bounds__(256) void k_mll_terms(const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
@@ -376,12 +384,12 @@ static __global__ void k_copy2d(const double* __restrict__ src, int64_t lds, dou
 
 // pad-aware load of a caller-provided N x N lower factor into the padded [[L,0],[0,I]] layout
 static __global__ void k_load_padded_lower(const double* __restrict__ src, int64_t n, double* __restrict__ dst, int64_t ld,
-                                    int64_t np) {
+                                    int64_t np, int whole = 0) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = blockIdx.y;
   if (i >= np || j >= np) return;
   double v;
-  if (i < n && j < n) v = (j <= i) ? src[i * n + j] : 0.0;
+  if (i < n && j < n) v = (j <= i || whole) ? src[i * n + j] : 0.0;
   else v = (i == j) ? 1.0 : 0.0;
   dst[i * ld + j] = v;
 }

@@ -32,7 +32,73 @@ def _tofloat(x) -> float:
 
 
 # ---- module-level helpers of the reference's gp.py, same names and arguments --------------------------------
+DummyDistribution = P.Dummy                      # gp.py:22-25
+make_distribution = P.make_distribution          # gp.py:27-55 (numpyro's names and keywords, priors.py)
+
+
+def saas_prior_logprob(lengthscales, kernel_variance, tausq):
+    """gp.py:57-78: the SAAS prior's log-density (O(d) host arithmetic, priors.py)."""
+    return P.saas_logprob_and_grad(np.asarray(lengthscales, dtype=np.float64), float(kernel_variance), float(tausq))[0]
+
+
 _KERNEL_HANDLES: dict = {}
+
+
+def _free_handle(kernel_id: int, d: int, device: int = 0):
+    """The cached data-less handle per (kernel, d, device) behind the module-level functions."""
+    lib = _lib.load()
+    key = (kernel_id, d, device)
+    if key not in _KERNEL_HANDLES:
+        h = C.c_void_p(0)
+        _lib.check(lib.bobe_gp_create(C.byref(h), device, kernel_id, d), "bobe_gp_create")
+        _KERNEL_HANDLES[key] = h
+    return lib, _KERNEL_HANDLES[key]
+
+
+def dist_sq(x, y):
+    """gp.py:80-96: squared Euclidean distances (n1, n2) of the rows of ``x`` and ``y``, on the GPU (bobe_gp_dist_sq)."""
+    x = _lib.as_f64(np.atleast_2d(x))
+    y = _lib.as_f64(np.atleast_2d(y))
+    if x.shape[1] != y.shape[1]:
+        raise ValueError("x and y must have the same number of columns")
+    lib, h = _free_handle(KERNEL_IDS["rbf"], x.shape[1])
+    out = np.empty((x.shape[0], y.shape[0]))
+    _lib.check(lib.bobe_gp_dist_sq(h, _lib.ptr(x), x.shape[0], _lib.ptr(y), y.shape[0], _lib.ptr(out)), "bobe_gp_dist_sq")
+    return out
+
+
+def gp_mll(k, train_y, num_points):
+    """gp.py:170-178: the marginal log-likelihood of ``train_y`` under the kernel matrix ``k`` handed in (Cholesky, solves
+    and reductions on the GPU, bobe_gp_mll_from_k); NaN when ``k`` is not positive definite, as XLA's Cholesky gives."""
+    k = _lib.as_f64(k)
+    y = _lib.as_f64(train_y).reshape(-1)
+    n = int(num_points)
+    if k.shape != (n, n) or y.shape[0] != n:
+        raise ValueError(f"k must be ({n}, {n}) and train_y must hold {n} values")
+    lib, h = _free_handle(KERNEL_IDS["rbf"], 1)
+    mll = C.c_double(0.0)
+    _lib.check(lib.bobe_gp_mll_from_k(h, _lib.ptr(k), n, _lib.ptr(y), C.byref(mll)), "bobe_gp_mll_from_k")
+    return float(mll.value)
+
+
+def fast_update_cholesky(L, k, k_self):
+    """gp.py:181-197: the (n+1) x (n+1) factor after appending one point - last row ``[L^-1 k, sqrt(k_self - |L^-1 k|^2)]``,
+    the solve on the GPU (bobe_gp_chol_row_update)."""
+    L = _lib.as_f64(L)
+    n = L.shape[0]
+    k = _lib.as_f64(k).reshape(-1)
+    if L.shape != (n, n) or k.shape[0] != n:
+        raise ValueError("L must be (n, n) and k must hold n values")
+    lib, h = _free_handle(KERNEL_IDS["rbf"], 1)
+    v = np.empty(n)
+    diag = C.c_double(0.0)
+    _lib.check(lib.bobe_gp_chol_row_update(h, _lib.ptr(L), n, _lib.ptr(k), _tofloat(k_self), _lib.ptr(v), C.byref(diag)),
+               "bobe_gp_chol_row_update")
+    new_L = np.zeros((n + 1, n + 1))
+    new_L[:n, :n] = L
+    new_L[n, :n] = v
+    new_L[n, n] = diag.value
+    return new_L
 
 
 def _kernel_on_gpu(kernel_id: int, xa, xb, lengthscales, kernel_variance, noise, include_noise, device: int = 0):
@@ -40,17 +106,12 @@ def _kernel_on_gpu(kernel_id: int, xa, xb, lengthscales, kernel_variance, noise,
     xa = _lib.as_f64(np.atleast_2d(xa))
     xb = _lib.as_f64(np.atleast_2d(xb))
     d = xa.shape[1]
-    lib = _lib.load()
-    key = (kernel_id, d, device)
-    if key not in _KERNEL_HANDLES:
-        h = C.c_void_p(0)
-        _lib.check(lib.bobe_gp_create(C.byref(h), device, kernel_id, d), "bobe_gp_create")
-        _KERNEL_HANDLES[key] = h
+    lib, handle = _free_handle(kernel_id, d, device)
     ls = _lib.as_f64(lengthscales).reshape(-1)
     if ls.size == 1 and d > 1:
         ls = np.full(d, float(ls[0]))
     out = np.empty((xa.shape[0], xb.shape[0]))
-    _lib.check(lib.bobe_gp_kernel(_KERNEL_HANDLES[key], _lib.ptr(xa), xa.shape[0], _lib.ptr(xb), xb.shape[0],
+    _lib.check(lib.bobe_gp_kernel(handle, _lib.ptr(xa), xa.shape[0], _lib.ptr(xb), xb.shape[0],
                                   _lib.ptr(ls), float(kernel_variance), float(noise), 1 if include_noise else 0,
                                   _lib.ptr(out)), "bobe_gp_kernel")
     return out
@@ -119,6 +180,7 @@ class GP:
         self._chol_cache = self._alpha_cache = None
         self._pushed_hyper = None              # hyper-parameters of the factor on the device (set by _push_hyper)
         self.not_pd = False
+        self._rank_test_noted = False
         self._push_data()
         if _factor:
             self.recompute_cholesky()                                           # gp.py:257-260
@@ -346,6 +408,27 @@ class GP:
         self._chol_cache = None
         self._alpha_cache = None
         self.not_pd = (st == _lib.BOBE_NOT_PD)
+        if self.not_pd:
+            self._note_rank_test()
+
+    def _note_rank_test(self) -> None:
+        """Logged once per GP: a factorisation was refused by the rank test (a positive pivot below ``pivot_floor_ulp``
+        machine epsilons of k(x,x) + noise), i.e. where LAPACK's sign test - the reference's rule - may have passed."""
+        if not self._rank_test_noted and "rank test" in _lib.last_error():
+            self._rank_test_noted = True
+            log.warning(f"{_lib.last_error()} at kernel variance {self.kernel_variance:.3g}, noise {self.noise:.3g}: "
+                        "treated as not positive definite (NaN).  GP.pivot_floor_ulp = 0 (or BOBE_PIVOT_FLOOR_ULP=0) "
+                        "restores the reference's sign-only test.")
+
+    @property
+    def pivot_floor_ulp(self) -> float:
+        """The rank test's factor (include/bobe_gp.h, "Conventions"): 64 by default, 0 = the reference's rule (only a
+        pivot <= 0 fails, as LAPACK's dpotrf reports it).  Takes effect at the next factorisation / MLL evaluation."""
+        return float(self._lib.bobe_gp_get_pivot_floor_ulp(self._h))
+
+    @pivot_floor_ulp.setter
+    def pivot_floor_ulp(self, ulp: float) -> None:
+        _lib.check(self._lib.bobe_gp_set_pivot_floor_ulp(self._h, float(ulp)), "bobe_gp_set_pivot_floor_ulp")
 
     # ------------------------------------------------------------------ state on the host (lazy)
     @property
@@ -662,8 +745,10 @@ class GP:
         return gp
 
     @classmethod
-    def load(cls, filename, device: int = 0, **kwargs):
-        """BOBE/gp.py:679-721 (``device``: HIP device of the restored GP)."""
+    def load(cls, filename, **kwargs):
+        """BOBE/gp.py:679-721; further keywords override entries of the stored state, as there.  One keyword is this
+        build's own: ``device`` (HIP device of the restored GP, default 0)."""
+        device = int(kwargs.pop("device", 0))
         if not filename.endswith(".npz"):
             filename += ".npz"
         data = np.load(filename, allow_pickle=True)

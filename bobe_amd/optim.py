@@ -1,7 +1,11 @@
 """Multi-restart L-BFGS-B driver — counterpart of BOBE/optim.py:249-359 (``optimize_scipy``).
 
-The reference wraps ``jax.jit(jax.value_and_grad(fun))`` (optim.py:306-309); here the caller hands in
-a ``value_and_grad(x) -> (f, g)`` callable whose heavy part runs on the GPU through the C ABI.
+The three drivers keep the reference's call signature ``(fun, fun_args=(), fun_kwargs={}, num_params=1, bounds=None,
+x0=None, optimizer_options=..., maxiter=200, n_restarts=..., verbose=False)`` (optim.py:18-28, 166-177, 249-260;
+pinned by tests/golden/reference_signatures.json).  The reference wraps ``jax.jit(jax.value_and_grad(fun))``
+(optim.py:306-309); there is no autodiff here, so ``fun(x, *fun_args, **fun_kwargs)`` hands back ``(f, g)`` itself - the
+heavy part running on the GPU through the C ABI - and a ``fun`` that returns the value alone is differentiated by
+forward differences.  What this build adds (batched / slotted evaluation of the restarts) is keyword-only.
 """
 from __future__ import annotations
 
@@ -14,6 +18,30 @@ from scipy.optimize import minimize
 from .utils import get_logger
 
 log = get_logger("optim")
+
+
+def _bind(fun: Callable, fun_args, fun_kwargs) -> Callable:
+    """x -> (f, g | None) from the reference's ``fun, fun_args, fun_kwargs`` triple: ``fun`` returns ``(f, g)`` (what
+    ``jax.value_and_grad(fun)`` returns there, optim.py:306-309) or the value alone (g = None: finite differences)."""
+    args = tuple(fun_args) if fun_args else ()
+    kwargs = dict(fun_kwargs) if fun_kwargs else {}
+
+    def vg(x):
+        r = fun(x, *args, **kwargs)
+        if isinstance(r, (tuple, list)) and len(r) == 2:
+            return r[0], r[1]
+        return r, None
+    return vg
+
+
+def _with_fd_grad(vg: Callable) -> Callable:
+    """(f, g) for a value-only objective: forward differences, the step SciPy's '2-point' scheme takes."""
+    from scipy.optimize import approx_fprime
+
+    def full(x):
+        x = np.asarray(x, dtype=np.float64)
+        return float(vg(x)[0]), approx_fprime(x, lambda q: float(vg(q)[0]), np.sqrt(np.finfo(float).eps))
+    return full
 
 
 def _setup_bounds(bounds, num_params):
@@ -323,13 +351,13 @@ def _evaluate_in_slots(slot_fun: Callable, xs, n_slots: int) -> List:
     return out
 
 
-def optimize_scipy(value_and_grad: Callable, num_params: int = 1, bounds=None, x0=None,
+def optimize_scipy(fun: Callable, fun_args=(), fun_kwargs=None, num_params: int = 1, bounds=None, x0=None,
                    optimizer_options: Optional[dict] = None, maxiter: int = 200, n_restarts: int = 4,
-                   verbose: bool = False, batch_value_and_grad: Optional[Callable] = None,
+                   verbose: bool = False, *, batch_value_and_grad: Optional[Callable] = None,
                    slot_value_and_grad: Optional[Callable] = None, n_slots: int = 4) -> Tuple[np.ndarray, float]:
-    """Same restart / screening / acceptance logic as BOBE/optim.py:292-359.
+    """Same arguments and the same restart / screening / acceptance logic as BOBE/optim.py:249-359.
 
-    ``value_and_grad`` may return ``g=None``; SciPy then falls back to finite differences.
+    ``fun(x, *fun_args, **fun_kwargs) -> (f, g)``; with ``g`` None or a bare value SciPy falls back to finite differences.
     ``batch_value_and_grad(list of x) -> list of (f, g)`` (optional) lets the restarts — independent L-BFGS-B
     runs that the reference walks one after the other — advance in lock-step with their objective evaluations
     batched on the GPU; every restart follows the same trajectory and the acceptance order is unchanged.
@@ -350,9 +378,10 @@ def optimize_scipy(value_and_grad: Callable, num_params: int = 1, bounds=None, x
         raise ValueError(f"x0 provided with {x0.shape[0]} restarts but n_restarts={n_restarts}")
     x0 = x0[:n_restarts]
 
+    value_and_grad = _bind(fun, fun_args, fun_kwargs)
     probe = value_and_grad(x0[0])
     has_grad = probe[1] is not None
-    fun = value_and_grad if has_grad else (lambda x: value_and_grad(x)[0])
+    objective = value_and_grad if has_grad else (lambda x: value_and_grad(x)[0])
 
     slotted = slot_value_and_grad is not None and len(x0) > 1
     concurrent = batch_value_and_grad is not None and len(x0) > 1 and not slotted
@@ -389,7 +418,7 @@ def optimize_scipy(value_and_grad: Callable, num_params: int = 1, bounds=None, x
                 if isinstance(res, Exception):
                     raise res
             else:
-                res = minimize(fun, x_init, method=method, jac=has_grad, bounds=scipy_bounds, options=options)
+                res = minimize(objective, x_init, method=method, jac=has_grad, bounds=scipy_bounds, options=options)
         except Exception as e:
             if verbose:
                 log.warning(f"  Restart {i + 1}/{n_restarts}: failed with {e}")
@@ -463,15 +492,18 @@ def _first_order_setup(optimizer_options, num_params, bounds, x0, n_restarts, ex
     return opt, patience, x0[:n_restarts], bounds_arr, span, to_x
 
 
-def optimize_optax(value_and_grad: Callable, num_params: int = 1, bounds=None, x0=None,
+def optimize_optax(fun: Callable, fun_args=(), fun_kwargs=None, num_params: int = 1, bounds=None, x0=None,
                    optimizer_options: Optional[dict] = None, maxiter: int = 200, n_restarts: int = 1,
                    verbose: bool = False) -> Tuple[np.ndarray, float]:
-    """Restart-after-restart first-order minimisation, the loop of BOBE/optim.py:71-163 with ``value_and_grad(x) ->
-    (f, g)`` in place of ``jax.value_and_grad(fun)``: the iterate lives in unit coordinates of ``bounds`` and is
+    """Restart-after-restart first-order minimisation, the loop of BOBE/optim.py:71-163 with ``fun(x, *fun_args,
+    **fun_kwargs) -> (f, g)`` in place of ``jax.value_and_grad(fun)``: the iterate lives in unit coordinates of ``bounds`` and is
     clipped to [0, 1] after every step; a restart stops after ``early_stop_patience`` steps without a new best value;
     the value reported for a restart is the best value seen, the point its LAST iterate (optim.py:156-158).
     As in the reference, the rows of ``x0`` are taken as they are as the first iterates (optim.py:138)."""
     opt, patience0, x0, bounds_arr, span, to_x = _first_order_setup(optimizer_options, num_params, bounds, x0, n_restarts, False)
+    value_and_grad = _bind(fun, fun_args, fun_kwargs)
+    if value_and_grad(to_x(x0[0]))[1] is None:
+        value_and_grad = _with_fd_grad(value_and_grad)
 
     def vg_unit(u):
         f, g = value_and_grad(to_x(u))
@@ -507,14 +539,22 @@ def optimize_optax(value_and_grad: Callable, num_params: int = 1, bounds=None, x
     return np.asarray(to_x(best_u)), float(best_f)
 
 
-def optimize_optax_vmap(batch_value_and_grad: Callable, num_params: int = 1, bounds=None, x0=None,
+def optimize_optax_vmap(fun: Callable, fun_args=(), fun_kwargs=None, num_params: int = 1, bounds=None, x0=None,
                         optimizer_options: Optional[dict] = None, maxiter: int = 200, n_restarts: int = 1,
-                        verbose: bool = False) -> Tuple[np.ndarray, float]:
-    """All restarts step together (BOBE/optim.py:166-247, ``jax.vmap`` over restarts): one call of
+                        verbose: bool = False, *, batch_value_and_grad: Optional[Callable] = None
+                        ) -> Tuple[np.ndarray, float]:
+    """All restarts step together (BOBE/optim.py:166-247, ``jax.vmap`` of ``fun`` over the restarts): one call of
     ``batch_value_and_grad(list of x) -> list of (f, g)`` per iteration — on this engine one ``bobe_gp_mll_batch``
-    with every restart's evaluation in flight.  Per-restart best value / best iterate bookkeeping and the joint
-    early stop of optim.py:228-236."""
+    with every restart's evaluation in flight (without it: ``fun(x, *fun_args, **fun_kwargs) -> (f, g)`` restart by
+    restart).  Per-restart best value / best iterate bookkeeping and the joint early stop of optim.py:228-236."""
     opt, patience0, x0, bounds_arr, span, to_x = _first_order_setup(optimizer_options, num_params, bounds, x0, n_restarts, True)
+    if batch_value_and_grad is None:
+        single = _bind(fun, fun_args, fun_kwargs)
+        if single(to_x(x0[0]))[1] is None:
+            single = _with_fd_grad(single)
+
+        def batch_value_and_grad(xs):
+            return [single(x) for x in xs]
     U = np.array(x0)
     state = opt.init(U)
     best_vals = np.full(n_restarts, np.inf)

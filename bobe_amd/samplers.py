@@ -25,8 +25,10 @@ from .utils import get_logger, get_numpy_rng
 log = get_logger("sampler")
 
 
-def compute_integrals(logl, logvol, reweight=None, squared=False):
+def compute_integrals(logl=None, logvol=None, reweight=None, squared=False):
     """samplers.py:27-50 (dynesty utility): cumulative log-evidence by the trapezoid rule in prior volume."""
+    if logl is None or logvol is None:
+        raise ValueError("logl and logvol are required")                  # (the reference asserts, samplers.py:28-29)
     logl = np.asarray(logl, dtype=np.float64)
     logvol = np.asarray(logvol, dtype=np.float64)
     loglstar_pad = np.concatenate([[-1.0e300], logl])

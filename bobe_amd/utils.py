@@ -38,3 +38,22 @@ def get_threshold_for_nsigma(nsigma: float, d: int) -> float:
     from scipy.stats import chi2
     nstd = np.sqrt(chi2.isf(erfc(nsigma / np.sqrt(2.0)), d))
     return float(0.5 * nstd ** 2)
+
+
+def _kl_gaussian_single(mu1, cov1, mu2, cov2) -> float:
+    """KL(N(mu1, cov1) || N(mu2, cov2)) = 0.5 [tr(S2^-1 S1) + (mu2-mu1)^T S2^-1 (mu2-mu1) - d + ln det S2 - ln det S1]."""
+    mu1, mu2 = np.atleast_1d(mu1).astype(float), np.atleast_1d(mu2).astype(float)
+    cov1, cov2 = np.atleast_2d(cov1).astype(float), np.atleast_2d(cov2).astype(float)
+    d = mu1.shape[0]
+    sol = np.linalg.solve(cov2, np.column_stack([cov1, mu2 - mu1]))
+    _, ld1 = np.linalg.slogdet(cov1)
+    _, ld2 = np.linalg.slogdet(cov2)
+    return float(0.5 * (np.trace(sol[:, :d]) + (mu2 - mu1) @ sol[:, d] - d + ld2 - ld1))
+
+
+def kl_divergence_gaussian(mu1, Cov1, mu2, Cov2) -> dict:
+    """Forward, reverse and symmetric KL divergence between two multivariate normals (utils/core.py:132-145: the
+    bookkeeping ``check_convergence_logz`` keeps beside the logZ test, bo.py:896-911)."""
+    fwd = _kl_gaussian_single(mu1, Cov1, mu2, Cov2)
+    rev = _kl_gaussian_single(mu2, Cov2, mu1, Cov1)
+    return {"forward": fwd, "reverse": rev, "symmetric": 0.5 * (fwd + rev)}

@@ -26,7 +26,7 @@ def true_logz(bounds, n=2001):
 if __name__ == "__main__":
     bounds = np.array([[-1, 1], [-1, 2]]).T
     t0 = time.time()
-    bobe = BOBE(loglike, ["x1", "x2"], bounds, n_sobol_init=8, seed=42)
+    bobe = BOBE(loglike, ["x1", "x2"], bounds, n_sobol_init=8, seed=42, save=False)
     # the run settings of the reference's examples/Banana.py:53-68 (HMC integration points, logZ convergence on
     # the surrogate, final nested sampling); MAX_EVALS shortens the run
     max_evals = int(os.environ.get("MAX_EVALS", 250))

@@ -23,7 +23,7 @@ if __name__ == "__main__":
     # USE_CLF=1: GPwithClassifier, as the reference's cosmology examples run (examples/Planck_*.py: use_clf=True) - the GP on
     # the points within gp_threshold of the best value, an SVM gate (evaluated on the device) everywhere else
     bobe = BOBE(loglike, [f"x{i}" for i in range(D)], bounds, n_sobol_init=64, seed=int(os.environ.get("SEED", 7)),
-                use_clf=bool(int(os.environ.get("USE_CLF", 0))), minus_inf=-1e10)
+                use_clf=bool(int(os.environ.get("USE_CLF", 0))), minus_inf=-1e10, save=False)
     # to logZ convergence on the surrogate (bo.py:886-934): half-width of the GP's +-sigma logZ bounds below the threshold
     # in two consecutive nested-sampling runs; the reference's docs suggest thresholds of 0.5-1.0 in high dimensions
     # (docs/source/examples/detailed_usage.rst:158).  Converges after ~650-1000 evaluations, 6-8 s on one MI355X

@@ -18,7 +18,9 @@
  *   - BOBE_NOT_PD is raised by a pivot <= 0 (what LAPACK's dpotrf, the reference's Cholesky, reports) AND by a positive pivot
  *     below 64 ulp of the kernel matrix's diagonal k(x,x) + noise: such a pivot is the rounding of its column's update, the
  *     log-determinant built on it is too small, and a fit is drawn to exactly those hyper-parameters (dpotrf passes or fails
- *     on the last bit there).  With the reference's default noise of 1e-8 this bounds the usable kernel variance near 1e6;
+ *     on the last bit there).  With the reference's default noise of 1e-8 this bounds the usable kernel variance near 1e6.
+ *     The factor is a per-handle setting (bobe_gp_set_pivot_floor_ulp; process default: BOBE_PIVOT_FLOOR_ULP, else 64);
+ *     0 leaves the reference's rule alone (sign test only);
  *   - a handle is not thread-safe; distinct handles are independent (own stream).
  *   - limits: d <= 32.
  */
@@ -144,6 +146,27 @@ int bobe_gp_predict_grad(bobe_gp_t* gp, const double* Xq, int64_t C, double* mea
 int bobe_gp_kernel(bobe_gp_t* gp, const double* A, int64_t nA, const double* B, int64_t nB,
                    const double* lengthscales, double kernel_variance, double noise, int include_noise, double* out);
 
+/* dist_sq(x, y) (gp.py:80-96): out[a][b] = |A_a - B_b|^2 of the rows as they are; nA x nB, d = the handle's. */
+int bobe_gp_dist_sq(bobe_gp_t* gp, const double* A, int64_t nA, const double* B, int64_t nB, double* out);
+
+/* gp_mll(k, train_y, num_points) (gp.py:170-178) on a kernel matrix the CALLER assembled: Cholesky, alpha, and
+ *   mll = -0.5 y^T K^-1 y - sum_i log L_ii - 0.5 n log(2 pi).
+ * K: n x n symmetric, row-major; y: n.  The handle must hold no training data of another size (a data-less handle is
+ * sized on the fly and stays data-less).  BOBE_NOT_PD (mll = NaN) for a pivot <= 0 only: a bare matrix has no kernel
+ * variance to scale the rank test with. */
+int bobe_gp_mll_from_k(bobe_gp_t* gp, const double* K, int64_t n, const double* y, double* mll);
+
+/* fast_update_cholesky(L, k, k_self) (gp.py:181-197): v = L^-1 k (n entries: the new factor's last row) and
+ * diag = sqrt(k_self - v.v) (NaN when negative, as jnp.sqrt); L: n x n lower, row-major.  Same handle rule as above. */
+int bobe_gp_chol_row_update(bobe_gp_t* gp, const double* L, int64_t n, const double* k, double k_self, double* v,
+                            double* diag);
+
+/* The rank test's factor (see "Conventions"): a positive pivot below `ulp` machine epsilons of k(x,x) + noise counts as
+ * not positive definite.  0 = LAPACK's sign test alone (the reference's behaviour); applies to bobe_gp_factor, the
+ * bobe_gp_mll family and bobe_gp_append of this handle; copied by bobe_gp_clone_state.  get returns -1 for NULL. */
+int bobe_gp_set_pivot_floor_ulp(bobe_gp_t* gp, double ulp);
+double bobe_gp_get_pivot_floor_ulp(bobe_gp_t* gp);
+
 /* GP.cholesky / GP.alphas (gp.py:259-260; state_dict keys gp.py:626-627): L is N x N lower with
  * zeros above the diagonal, alpha has N entries.  Either may be NULL. */
 int bobe_gp_get_chol(bobe_gp_t* gp, double* L, double* alpha);
@@ -179,7 +202,8 @@ int bobe_gp_hmc_run(bobe_gp_t* g, int64_t P, double* state, double* adapt, const
  * launch.  step: d x d lower-triangular, row-major (scale x Cholesky factor of the live points' covariance).
  *   X [P][d]  in: start points (live points), out: end points     logl [P]  in / out: physical-unit mean at the point
  *   n_accepted [P], n_inside [P]: accepted steps / proposals inside the cube (= surrogate evaluations) per walker
- *   dbg [P][d]: every walker's LAST proposal (NULL: not recorded; tests replay it).  All pointers are HOST memory.
+ *   dbg [P][d]: every walker's LAST proposal (NULL: not recorded; tests replay it).  All pointers are HOST memory (a
+ *   device pointer is refused with BOBE_ERR_ARG; the same holds for bobe_gp_hmc_run).
  * Random numbers: a counter hash of (seed, walker, step, index). */
 int bobe_gp_rwalk(bobe_gp_t* gp, int64_t P, double* X, double* logl, const double* step, double lstar, int walks,
                   uint64_t seed, double y_std, double y_mean, int* n_accepted, int* n_inside, double* dbg);

@@ -16,7 +16,7 @@ def rosenbrock(x):
 def test_wipstd_uniform_loop_himmelblau():
     from bobe_amd.bo import BOBE
     bounds = np.array([[-4.0, 4.0], [-4.0, 4.0]]).T
-    bobe = BOBE(himmelblau, ["x", "y"], bounds, n_sobol_init=8, seed=1)
+    bobe = BOBE(himmelblau, ["x", "y"], bounds, n_sobol_init=8, seed=1, save=False)
     res = bobe.run(acq="wipstd", max_evals=36, fit_n_points=2, batch_size=2, mc_points_size=64, num_mc_samples=256,
                    mc_points_method="uniform")
     assert set(res) >= {"gp", "best_val", "best_x", "n_evals", "acq_history", "timing"}
@@ -29,7 +29,7 @@ def test_wipstd_uniform_loop_himmelblau():
 def test_ei_loop_rosenbrock_improves():
     from bobe_amd.bo import BOBE
     bounds = np.array([[-1.0, 4.0], [-1.0, 7.0]]).T      # reference examples/Rosenbrock.py:25-28
-    bobe = BOBE(rosenbrock, ["x", "y"], bounds, n_sobol_init=8, seed=3)
+    bobe = BOBE(rosenbrock, ["x", "y"], bounds, n_sobol_init=8, seed=3, save=False)
     start = float(np.max(bobe.gp.train_y * bobe.gp.y_std + bobe.gp.y_mean))
     res = bobe.run(acq="ei", max_evals=24)
     assert res["best_val"] >= start and res["best_val"] > -1000     # tests/test_bo_2d.py:69-97
@@ -59,6 +59,7 @@ def test_run_level_resume_continues_the_interrupted_run(tmp_path):
     (L and alpha restored without a factorisation) and the run state saved beside it.  The resumed run must CONTINUE
     the interrupted one: same kriging-believer picks as an uninterrupted run with the same seed (BASELINE config 1's
     likelihood and settings, shortened)."""
+    import json
     import math
     from bobe_amd.bo import BOBE
 
@@ -71,12 +72,21 @@ def test_run_level_resume_continues_the_interrupted_run(tmp_path):
 
     def make(**extra):
         return BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=123, likelihood_name="banana", **extra)
-    full = make().run(max_evals=20, **kw)                        # uninterrupted: 8 + 6 x 2 evaluations
+    full = make(save=False).run(max_evals=20, **kw)                        # uninterrupted: 8 + 6 x 2 evaluations
     d1 = str(tmp_path / "run")
     first = make(save=True, save_dir=d1, save_step=1).run(max_evals=18, **kw)     # cut after 5 iterations
     assert first["n_evals"] == 18 and (tmp_path / "run" / "banana_gp.npz").exists()
-    assert (tmp_path / "run" / "banana_run.json").exists() and (tmp_path / "run" / "banana_mc.npz").exists()
+    run_state = json.load(open(tmp_path / "run" / "banana_run.json"))
+    # the run state names ONE complete generation of files; older generations are pruned once it is in place
+    assert (tmp_path / "run" / run_state["gp_file"]).exists() and (tmp_path / "run" / run_state["mc_file"]).exists()
+    assert sorted(f.name for f in (tmp_path / "run").iterdir()) == sorted(
+        ["banana_gp.npz", "banana_run.json", run_state["gp_file"], run_state["mc_file"]])
     assert np.array_equal(first["gp"].train_x, full["gp"].train_x[:18])             # (saving does not disturb the run)
+    # a kill between the files of the NEXT generation and its run state: a newer, unrelated <name>_gp.npz and a half-written
+    # generation lie beside a run state that still names the old one - the resumed run must come up from the generation its
+    # run state names, not from a mixture
+    make(save=False).gp.save(str(tmp_path / "run" / "banana_gp"))                    # (an 8-point GP under the shared name)
+    (tmp_path / "run" / "banana_gp.999.npz").write_bytes(b"half written")
     calls = []
 
     def counting(x):
@@ -102,15 +112,15 @@ def test_run_level_resume_continues_the_interrupted_run(tmp_path):
     assert math.isclose(res["kernel_variance"], full["kernel_variance"], rel_tol=1e-5)
     assert math.isclose(res["best_val"], full["best_val"], rel_tol=1e-9)
     more = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=1, likelihood_name="banana", resume=True,
-                resume_file=str(tmp_path / "run" / "banana")).run(max_evals=28, **kw)
+                resume_file=str(tmp_path / "run" / "banana"), save=False).run(max_evals=28, **kw)
     assert more["n_evals"] == 28 and len(more["acq_history"]) == 10                 # 6 iterations on file + 4 more
     # a GP file without run state resumes at iteration 0 with that training set; an unreadable one starts afresh
     (tmp_path / "run" / "banana_run.json").unlink()
     bare = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=5, likelihood_name="banana", resume=True,
-                resume_file=str(tmp_path / "run" / "banana"))
+                resume_file=str(tmp_path / "run" / "banana"), save=False)
     assert not bare.fresh_start and bare.gp.npoints == 20 and bare._resume_state is None
     fresh = BOBE(banana, ["x1", "x2"], bounds, n_sobol_init=8, seed=5, likelihood_name="banana", resume=True,
-                 resume_file=str(tmp_path / "nothing_here" / "banana"))
+                 resume_file=str(tmp_path / "nothing_here" / "banana"), save=False)
     assert fresh.fresh_start and fresh.gp.npoints == 8
 
 

@@ -145,7 +145,7 @@ def test_config5_rosenbrock_10d_full_loop_to_logz_convergence():
     from bobe_amd import samplers
     from bobe_amd.bo import BOBE
     D = 10
-    b = BOBE(_rosen10, [f"x{i}" for i in range(D)], np.array([[-2.0, 2.0]] * D).T, n_sobol_init=64, seed=7)
+    b = BOBE(_rosen10, [f"x{i}" for i in range(D)], np.array([[-2.0, 2.0]] * D).T, n_sobol_init=64, seed=7, save=False)
     res = b.run(acq="wipstd", min_evals=400, max_evals=3200, max_gp_size=4096, logz_threshold=1.0, convergence_n_iters=2,
                 fit_n_points=10, ns_n_points=50, batch_size=5, mc_points_size=256, num_hmc_warmup=256, num_hmc_samples=512,
                 do_final_ns=True)

@@ -132,12 +132,12 @@ def test_classifier_is_retrained_as_the_best_value_moves():
         return -300.0 * float(np.sum((np.asarray(x) - 0.6) ** 2))
 
     b = BOBE(like, ["a", "b"], np.array([[0.0, 1.0], [0.0, 1.0]]).T, n_sobol_init=24, use_clf=True,
-             clf_nsigma_threshold=5, seed=5)
+             clf_nsigma_threshold=5, seed=5, save=False)
     gp = b.gp
     thr = gp.clf_threshold
     before = np.where(gp.train_y_clf.flatten() < gp.train_y_clf.max() - thr, 0, 1).copy()
     # a much better point moves the maximum: points that were feasible fall out of the band
-    b.update_gp(np.array([[0.6, 0.6]]), np.array([[like([0.6, 0.6]) + 150.0]]), fit_n_points=10)
+    b.update_gp(np.array([[0.6, 0.6]]), np.array([[like([0.6, 0.6]) + 150.0]]))
     after = np.where(gp.train_y_clf.flatten() < gp.train_y_clf.max() - thr, 0, 1)
     assert after[:-1].sum() < before.sum()
     if gp.use_clf:

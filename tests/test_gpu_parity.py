@@ -853,9 +853,9 @@ def test_first_order_fit_paths():
     r = gp.fit(x0=u0, maxiter=60)
     assert np.isfinite(r["mll"]) and -r["mll"] < f0                          # improved on the best start
     opts = {"name": "adam", "lr": 0.02, "early_stop_patience": 30}
-    xs, fs = optimize_optax(gp.neg_mll_value_and_grad, gp.num_hyperparams, gp.hyperparam_bounds, u0, dict(opts), 60, 3)
-    xv, fv = optimize_optax_vmap(gp.neg_mll_value_and_grad_batch, gp.num_hyperparams, gp.hyperparam_bounds, u0,
-                                 dict(opts), 60, 3)
+    xs, fs = optimize_optax(gp.neg_mll_value_and_grad, (), {}, gp.num_hyperparams, gp.hyperparam_bounds, u0, dict(opts), 60, 3)
+    xv, fv = optimize_optax_vmap(gp.neg_mll_value_and_grad, (), {}, gp.num_hyperparams, gp.hyperparam_bounds, u0,
+                                 dict(opts), 60, 3, batch_value_and_grad=gp.neg_mll_value_and_grad_batch)
     assert fv == pytest.approx(fs, rel=1e-12)                                # same arithmetic, batched evaluations
     assert -r["mll"] == pytest.approx(fs, rel=1e-12)
 

@@ -24,7 +24,7 @@ def himmelblau(x):
 def _notebook_bobe(seed):
     from bobe_amd.bo import BOBE
     return BOBE(banana, NB["param_list"], np.array(NB["param_bounds"]).T, likelihood_name="banana",
-                n_sobol_init=NB["constructor"]["n_sobol_init"], seed=seed)
+                n_sobol_init=NB["constructor"]["n_sobol_init"], seed=seed, save=False)
 
 
 def test_first_fit_of_the_notebook_run_digit_for_digit():
@@ -72,7 +72,7 @@ def test_himmelblau_tutorial_logz_is_around_minus_3_2():
     """docs/source/examples/detailed_usage.rst:118-135, 197: 'should produce LogZ around -3.2' (quadrature: -3.1834)."""
     from bobe_amd.bo import BOBE
     h = HELD["docs_himmelblau"]
-    b = BOBE(himmelblau, ["x1", "x2"], np.array(h["param_bounds"]).T, n_sobol_init=8, seed=42)
+    b = BOBE(himmelblau, ["x1", "x2"], np.array(h["param_bounds"]).T, n_sobol_init=8, seed=42, save=False)
     res = b.run(acq="wipstd", min_evals=25, max_evals=250, logz_threshold=0.01, fit_n_points=4, batch_size=2,
                 ns_n_points=4, num_hmc_warmup=256, num_hmc_samples=512, mc_points_size=128, convergence_n_iters=1)
     assert res["logz"], res["termination_reason"]

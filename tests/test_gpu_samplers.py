@@ -38,7 +38,7 @@ def test_bo_loop_with_logz_convergence():
     from bobe_amd.bo import BOBE
     sig = 0.2
     bounds = np.array([[0.0, 1.0], [0.0, 1.0]]).T
-    bobe = BOBE(lambda x: -0.5 * float(np.sum(((x - 0.5) / sig) ** 2)), ["a", "b"], bounds, n_sobol_init=16, seed=5)
+    bobe = BOBE(lambda x: -0.5 * float(np.sum(((x - 0.5) / sig) ** 2)), ["a", "b"], bounds, n_sobol_init=16, seed=5, save=False)
     res = bobe.run(acq="wipstd", max_evals=80, fit_n_points=4, batch_size=2, mc_points_size=64, mc_points_method="NS",
                    logz_threshold=0.05, min_evals=24, ns_n_points=8)
     assert "logz" in res and res["logz"]["mean"] == pytest.approx(2 * 0.5 * math.log(2 * math.pi * sig ** 2), abs=0.25)

@@ -147,7 +147,7 @@ def test_concurrent_restart_drivers_equal_the_sequential_loop():
         return f, g
 
     x0 = np.random.default_rng(0).uniform(-2, 2, size=(7, 4))
-    seq = optimize_scipy(vg, 4, [-3, 3], x0, n_restarts=7)
+    seq = optimize_scipy(vg, num_params=4, bounds=[-3, 3], x0=x0, n_restarts=7)
     slot_calls, batch_sizes = [], []
 
     def slot_vg(x, slot):
@@ -158,8 +158,8 @@ def test_concurrent_restart_drivers_equal_the_sequential_loop():
         batch_sizes.append(len(xs))
         return [vg(x) for x in xs]
 
-    slots = optimize_scipy(vg, 4, [-3, 3], x0, n_restarts=7, slot_value_and_grad=slot_vg, n_slots=3)
-    batch = optimize_scipy(vg, 4, [-3, 3], x0, n_restarts=7, batch_value_and_grad=batch_vg)
+    slots = optimize_scipy(vg, num_params=4, bounds=[-3, 3], x0=x0, n_restarts=7, slot_value_and_grad=slot_vg, n_slots=3)
+    batch = optimize_scipy(vg, num_params=4, bounds=[-3, 3], x0=x0, n_restarts=7, batch_value_and_grad=batch_vg)
     assert np.array_equal(seq[0], slots[0]) and seq[1] == slots[1]
     assert np.array_equal(seq[0], batch[0]) and seq[1] == batch[1]
     assert set(slot_calls) == {0, 1, 2}                      # never more workers than slots
@@ -283,7 +283,7 @@ def test_an_exception_in_one_restart_ends_that_restart_only():
         assert isinstance(out[1], FloatingPointError)
         for r, o in zip(ref, (out[0], out[2])):
             assert np.array_equal(o.x, r.x) and o.fun == r.fun and o.nit == r.nit and o.nfev == r.nfev
-    best_x, best_f = optim.optimize_scipy(vg, 3, [-2, 2], starts, n_restarts=3, batch_value_and_grad=batch)
+    best_x, best_f = optim.optimize_scipy(vg, num_params=3, bounds=[-2, 2], x0=starts, n_restarts=3, batch_value_and_grad=batch)
     # (optimize_scipy's own options differ from `kw`: same optimum, not the same last digits)
     assert np.allclose(best_x, ref[0].x, atol=1e-3) and best_f == pytest.approx(min(r.fun for r in ref), rel=1e-4)
     assert optim.lbfgs_driver() == "stepped"

@@ -298,11 +298,13 @@ def test_first_order_optimisers_follow_torch(name, kw):
     x, f = optimize_optax(vg, num_params=3, bounds=[0.0, 1.0], x0=x0, optimizer_options=dict(options), maxiter=steps,
                           n_restarts=2)
     assert f == pytest.approx(bests[i], rel=1e-12) and np.allclose(x, finals[i], atol=1e-12)
-    xv, fv = optimize_optax_vmap(lambda xs: [vg(q) for q in xs], num_params=3, bounds=[0.0, 1.0], x0=x0,
-                                 optimizer_options=dict(options), maxiter=steps, n_restarts=2)
+    xv, fv = optimize_optax_vmap(vg, num_params=3, bounds=[0.0, 1.0], x0=x0, optimizer_options=dict(options),
+                                 maxiter=steps, n_restarts=2, batch_value_and_grad=lambda xs: [vg(q) for q in xs])
     assert fv == pytest.approx(bests[i], rel=1e-12)
+    xw, fw = optimize_optax_vmap(vg, (), {}, 3, [0.0, 1.0], x0, dict(options), steps, 2)     # the reference's positional order
+    assert fw == fv and np.array_equal(xw, xv)
     with pytest.raises(ValueError):
-        optimize_optax(vg, 3, [0.0, 1.0], x0, {"name": "lbfgs"}, 5, 2)
+        optimize_optax(vg, (), {}, 3, [0.0, 1.0], x0, {"name": "lbfgs"}, 5, 2)
 
 
 def test_svm_decision_restatement_against_sklearn():

@@ -17,7 +17,7 @@ def banana(x):
 
 def run_case():
     bounds = np.array([[-4.0, 4.0], [-2.0, 6.0]]).T
-    bobe = BOBE(banana, ["x", "y"], bounds, n_sobol_init=12, seed=11)
+    bobe = BOBE(banana, ["x", "y"], bounds, n_sobol_init=12, seed=11, save=False)
     res = bobe.run(acq="wipv", max_evals=22, mc_points_size=96, num_mc_samples=512, fit_n_points=2,
                    mc_points_method="uniform")
     gp = res["gp"]

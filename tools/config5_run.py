@@ -107,7 +107,7 @@ def traced_update(self, new_u, new_vals, fit_n_points):
 
 BOBE.update_gp = traced_update
 bobe = BOBE(rosen10, [f"x{i}" for i in range(D)], np.array([[LO, HI]] * D).T, n_sobol_init=opt["sobol"], seed=opt["seed"],
-            use_clf=bool(opt["clf"]), minus_inf=-1e10)
+            use_clf=bool(opt["clf"]), minus_inf=-1e10, save=False)
 res = bobe.run(acq="wipstd", min_evals=opt["min_evals"], max_evals=opt["max_evals"], max_gp_size=opt["max_gp"],
                logz_threshold=opt["thr"], convergence_n_iters=opt["n_iters"], fit_n_points=opt["fit_every"],
                ns_n_points=opt["ns_every"], batch_size=opt["batch"], mc_points_size=opt["mc"], num_hmc_warmup=opt["warmup"],

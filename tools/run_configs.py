@@ -34,7 +34,7 @@ if "banana" in which:
     h = HELD["notebook_banana"]
     for seed in (h["seed"], 1, 2):
         t0 = time.time()
-        b = BOBE(banana, h["param_list"], np.array(h["param_bounds"]).T, n_sobol_init=2, seed=seed)
+        b = BOBE(banana, h["param_list"], np.array(h["param_bounds"]).T, n_sobol_init=2, seed=seed, save=False)
         hp0 = b.gp.hyperparams_dict()
         r = b.run(**h["run"])
         print(f"banana seed {seed}: first fit {hp0} | {r['termination_reason']} after {r['n_evals']} evals, logZ "
@@ -42,7 +42,7 @@ if "banana" in which:
               f" in {time.time() - t0:.1f}s; samples x range {r['samples']['x'].min(0)} .. {r['samples']['x'].max(0)}", flush=True)
 if "himmelblau" in which:
     t0 = time.time()
-    b = BOBE(himmelblau, ["x1", "x2"], np.array([[-4, 4], [-4, 4]]).T, n_sobol_init=8, seed=42)
+    b = BOBE(himmelblau, ["x1", "x2"], np.array([[-4, 4], [-4, 4]]).T, n_sobol_init=8, seed=42, save=False)
     r = b.run(acq="wipstd", min_evals=25, max_evals=250, logz_threshold=0.01, fit_n_points=4, batch_size=2, ns_n_points=4,
               num_hmc_warmup=256, num_hmc_samples=512, mc_points_size=128, convergence_n_iters=1)
     print(f"himmelblau (detailed_usage.rst settings): {r['termination_reason']} after {r['n_evals']} evals, logZ "
@@ -51,7 +51,7 @@ if "himmelblau" in which:
 if "rosen10" in which:
     t0 = time.time()
     D = 10
-    b = BOBE(rosen10, [f"x{i}" for i in range(D)], np.array([[-2.0, 2.0]] * D).T, n_sobol_init=64, seed=SEED)
+    b = BOBE(rosen10, [f"x{i}" for i in range(D)], np.array([[-2.0, 2.0]] * D).T, n_sobol_init=64, seed=SEED, save=False)
     r = b.run(acq="wipstd", min_evals=150, max_evals=int(os.environ.get("MAX_EVALS", 600)), logz_threshold=0.5, fit_n_points=10,
               ns_n_points=10, batch_size=5, mc_points_size=256, num_hmc_warmup=256, num_hmc_samples=512, do_final_ns=True,
               verbose=True)
