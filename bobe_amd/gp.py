@@ -666,6 +666,8 @@ class GP:
         unit cube above ``lstar`` (and inside the classifier's region when a gate is set).
         Returns (x', logl', n_accepted, n_inside[, last proposals])."""
         x = _lib.as_f64(np.atleast_2d(x)).copy()
+        if x.shape[1] != self.ndim:
+            raise ValueError(f"walkers have {x.shape[1]} coordinates, the GP has {self.ndim}")
         lg = _lib.as_f64(logl).reshape(-1).copy()
         st = _lib.as_f64(step).reshape(self.ndim, self.ndim)
         P = x.shape[0]

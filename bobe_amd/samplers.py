@@ -112,7 +112,7 @@ def _rwalk_pool(loglike, live, live_logl, worst, lstar, rng, n_walkers, walks, s
     A = np.linalg.cholesky(cov)
     start = rng.choice(np.flatnonzero(ok), size=n_walkers)
     x, lx = live[start].copy(), live_logl[start].copy()
-    if gp is not None and hasattr(gp, "rwalk"):
+    if gp is not None and hasattr(gp, "rwalk") and d == gp.ndim:       # (a caller-chosen ``ndim`` walks on the host)
         x, lx, nacc, nin = gp.rwalk(x, lx, scale * A, lstar, walks, int(rng.integers(0, 2 ** 62)))
         moved = nacc > 0
         perm = rng.permutation(np.flatnonzero(moved))
@@ -209,6 +209,7 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
         found = False
         tries = 0
         out_of_calls = False
+        gave_up = False                                       # (per replacement search: a hit on the last refill is a hit)
         while not found:
             while pool_pos < len(pool_l):
                 if pool_l[pool_pos] > lstar:
@@ -243,6 +244,8 @@ def nested_sampling(gp, ndim: Optional[int] = None, mode: str = "convergence", d
             tries += 1
             gave_up = tries > 200                             # plateau / degenerate surrogate
             out_of_calls = ncall >= maxcall                   # (the refreshed pool is still scanned once)
+        if found:
+            gave_up = False                                   # (the flag describes the search that ENDED the run)
         if not found:
             # No replacement: the point just retired is still a live point.  Take the retirement back (it is counted once,
             # among the final live points) and end the run as TRUNCATED - its evidence is not a converged one.

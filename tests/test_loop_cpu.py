@@ -147,3 +147,31 @@ def test_nested_sampler_terminations_count_every_point_once(method):
                                            nlive=100, batch=512)
     assert not ok and lz["truncated"]
     assert len(np.unique(smp["x"], axis=0)) == len(smp["x"]) == lz["niter"] + 100
+
+
+class _BlackoutSurface(_GaussSurface):
+    """the Gaussian well, except that 200 consecutive proposal batches score nothing above any threshold: the replacement
+    search that meets them succeeds on its 201st refill"""
+
+    def __init__(self, d, s, first, length=200):
+        super().__init__(d, s)
+        self.calls, self.first, self.length = 0, first, length
+
+    def predict_mean_batched(self, u):
+        self.calls += 1
+        if self.first <= self.calls < self.first + self.length:
+            return np.full(np.atleast_2d(u).shape[0], -1e300)
+        return super().predict_mean_batched(u)
+
+
+def test_replacement_found_on_the_last_refill_is_not_a_give_up():
+    """A search that needs 201 refills and then finds its replacement has NOT given up: the run goes on, and when it later
+    converges by dlogz it is a successful run (the give-up flag used to stay set for the rest of the run, so the next empty
+    pool ended it as 'no acceptable replacement' and a converged logZ was thrown away)."""
+    import math
+    from bobe_amd import samplers
+    surf = _BlackoutSurface(2, 0.05, first=4)
+    smp, lz, ok = samplers.nested_sampling(surf, ndim=2, rng=np.random.default_rng(3), sample_method="ellipsoid", batch=256)
+    assert surf.calls > 4 + 200                                    # the blackout was met and outlasted
+    assert ok and not lz["truncated"]
+    assert abs(lz["mean"] - 2 * math.log(0.05 * math.sqrt(2 * math.pi))) < 3 * lz["dlogz_sampler"] + 0.05
