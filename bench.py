@@ -398,6 +398,18 @@ def main():
 
         key = "sequential" if R_total == 1 else (f"slots_{R_total}" if args.fit_mode == "slots" else f"lockstep_{R_total}")
         sub_ms = {"fit": fit_ms[key], "refactor": timed(refactor), "sweep": timed(lambda: local_sweep(work))}
+        # kernel classes beside the dominant one, HIP events on the handle's stream over one cycle each: the two assembly
+        # kernels (HBM-bound in principle: roofline_assembly) and the sweep's cross-covariance GEMM
+        class_ms = {}
+        for cls in ("kxc", "kxx", "crossvv"):
+            lib.bobe_gp_profile_select(h, _lib.PROF[cls])
+            fit_evals(all_r, fit_mode)                        # (rank 0 alone: no collective in this loop)
+            refactor()
+            local_sweep(work)
+            t_ms, n_l = C.c_double(), C.c_int64()
+            lib.bobe_gp_profile_read(h, C.byref(t_ms), C.byref(n_l))
+            class_ms[cls] = (t_ms.value, int(n_l.value))
+        lib.bobe_gp_profile_select(h, 0)
         gpu_check = {"mll0": float(mll_b[0]), "grad0": grad_b[0].copy(), "wipstd": out_wipstd.cpu().numpy()}
         if args.config not in ("tiny",):
             # GP.fit as the BO loop calls it for N >= 750 (bo.py:651-653): 4 restarts (pool.py:277-286 recipe), maxiter 200
@@ -427,9 +439,9 @@ def main():
                      "driver": lbfgs_driver(), "scipy": scipy.__version__}
     if rank == 0:
         chunk = args.chunk or 8192
-        # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 per candidate, triangular) fused with
-        # the cross-covariance rows W_Z^T K(X,C) (2 N M per candidate)
-        flops_per_launch = {"trimul": (float(N) * N + 2.0 * N * M) * min(chunk, Cn),
+        # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 flops per candidate: the triangular count) with the
+        # column sums of squares in the epilogue; k_cross_vv = the cross-covariance GEMM V_Z^T V (2 N M per candidate)
+        flops_per_launch = {"trimul": float(N) * N * min(chunk, Cn), "crossvv": 2.0 * N * M * min(chunk, Cn),
                             "syrk": None, "lauum": 2.0 * N ** 3 / 3.0}.get(args.profile_class)
         traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_k_%s.json" % args.profile_class)
@@ -452,6 +464,39 @@ def main():
                     "launches": int(launches.value),
                     "flops_per_launch": flops_per_launch,
                     "note": "largest single kernel of the cycle by time (the sweep's GEMM); the fit phase is priced in roofline_fit"}
+        roof_asm, roof_cross = None, None
+        if secondary:
+            Np_ = (N + 127) // 128 * 128
+            nb_ = Np_ // 128
+            t_kxc, n_kxc = class_ms["kxc"]
+            t_kxx, n_kxx = class_ms["kxx"]
+            # algorithmic bytes = what an assembly must write: 8 N chunk for a K(X,C) chunk; for K(X,X) the lower
+            # 128-tiles the factorisation reads, 8 * 128^2 * nb (nb + 1) / 2 per matrix (a lock-step launch assembles B of them)
+            if n_kxc:
+                b_kxc = 8.0 * N * min(chunk, Cn)
+                roof_asm = {"bound": "hbm", "kernel": "k_kernel_matrix<.,false,.> K(X,C) chunk", "unit": "GB/s", "peak": 8000.0,
+                            "achieved": b_kxc / (t_kxc * 1e-3 / n_kxc) / 1e9, "bytes_per_launch": b_kxc,
+                            "avg_launch_ms": t_kxc / n_kxc, "launches": n_kxc}
+                roof_asm["frac"] = roof_asm["achieved"] / roof_asm["peak"]
+            if n_kxx:
+                n_mat = len(thetas) + 1                                       # per cycle: the fit's evaluations + the refactor
+                b_kxx = 8.0 * 128 * 128 * nb_ * (nb_ + 1) / 2
+                roof_asm = dict(roof_asm or {}, kxx={"kernel": "k_kernel_matrix<.,true,.> K(X,X) lower tiles",
+                                                     "achieved": n_mat * b_kxx / (t_kxx * 1e-3) / 1e9, "unit": "GB/s",
+                                                     "bytes_per_matrix": b_kxx, "matrices": n_mat, "launches": n_kxx,
+                                                     "total_ms": t_kxx,
+                                                     "frac": n_mat * b_kxx / (t_kxx * 1e-3) / 1e9 / 8000.0})
+            if roof_asm:
+                roof_asm["note"] = ("HIP events on the handle's stream (BOBE_PROF_KXC / _KXX) over one cycle; fp64-VALU-bound "
+                                    "in practice (~55 fp64 instructions per element incl. exp), DESIGN.md 4; PMC traffic: "
+                                    "profiles/r05_traffic_k_kernel_matrix_*.json")
+            t_cv, n_cv = class_ms["crossvv"]
+            if n_cv:
+                f_cv = 2.0 * N * M * min(chunk, Cn)
+                roof_cross = {"bound": "mfma", "kernel": "k_cross_vv", "achieved": f_cv / (t_cv * 1e-3 / n_cv) / 1e12,
+                              "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "avg_launch_ms": t_cv / n_cv, "launches": n_cv,
+                              "flops_per_launch": f_cv}
+                roof_cross["frac"] = roof_cross["achieved"] / FP64_MFMA_PEAK_TFLOPS
         chol, potrf_ms, roof_fit = {}, None, None
         flops_potrf = N ** 3 / 3.0
         if secondary:
@@ -502,6 +547,8 @@ def main():
             "check": last if shard_rec is None else weak_check,
             "roofline": roof,
             "roofline_fit": roof_fit,
+            "roofline_assembly": roof_asm,
+            "roofline_cross": roof_cross,
             # what rank 0 saw of the job: ranks, who carried the collectives
             "world_size": (dist.get_world_size() if world > 1 else 1),
             "backend": (str(dist.get_backend()) if world > 1 else None),

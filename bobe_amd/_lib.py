@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libbobe_gp.so")
 BOBE_OK = 0
 BOBE_NOT_PD = 1
 MAX_MLL_SLOTS = 8
-PROF = {"potf2": 1, "trsm": 2, "syrk": 3, "trtri": 4, "lauum": 5, "trimul": 6, "cross": 7, "kxx": 8}
+PROF = {"potf2": 1, "trsm": 2, "syrk": 3, "trtri": 4, "lauum": 5, "trimul": 6, "cross": 7, "kxx": 8, "crossvv": 9, "kxc": 10}
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
@@ -72,6 +72,8 @@ SIGNATURES = [
                                           c_double_p]),
     ("bobe_gp_set_pivot_floor_ulp", C.c_int, [C.c_void_p, C.c_double]),
     ("bobe_gp_get_pivot_floor_ulp", C.c_double, [C.c_void_p]),
+    ("bobe_gp_set_refine_kappa", C.c_int, [C.c_void_p, C.c_double]),
+    ("bobe_gp_get_refine", C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_int)]),
     ("bobe_gp_get_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_set_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_clone_state", C.c_int, [C.c_void_p, C.c_void_p]),

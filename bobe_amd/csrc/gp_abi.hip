@@ -380,6 +380,24 @@ int bobe_gp_set_pivot_floor_ulp(bobe_gp_t* g, double ulp) {
 
 double bobe_gp_get_pivot_floor_ulp(bobe_gp_t* g) { return g ? g->pivot_ulp : -1.0; }
 
+int bobe_gp_set_refine_kappa(bobe_gp_t* g, double kappa) {
+  API_BEGIN
+  NEED(g, "gp is NULL");
+  NEED(kappa == kappa, "kappa is NaN");
+  g->refine_kappa = kappa;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_get_refine(bobe_gp_t* g, double* kappa, int* active) {
+  API_BEGIN
+  NEED(g, "gp is NULL");
+  if (kappa) *kappa = g->refine_kappa;
+  if (active) *active = (g->factored && g->refine_v) ? 1 : 0;
+  return BOBE_OK;
+  API_END
+}
+
 int bobe_gp_get_chol(bobe_gp_t* g, double* L, double* alpha) {
   API_BEGIN
   NEED(g, "gp is NULL");

@@ -74,6 +74,14 @@ const Tuning& tuning() {
   return t;
 }
 
+double default_refine_kappa() {
+  static const double v = [] {
+    const char* e = std::getenv("BOBE_REFINE_KAPPA");
+    return e ? std::atof(e) : 1e7;
+  }();
+  return v;
+}
+
 double default_pivot_floor_ulp() {
   static const double v = [] {
     const char* e = std::getenv("BOBE_PIVOT_FLOOR_ULP");
@@ -853,8 +861,10 @@ int bobe_gp::factor_state() {
     LAUNCH_CHECK();
     sync();
     g_err = not_pd_text(inf, min_diag);
+    refine_v = false;
     return BOBE_NOT_PD;
   }
+  decide_refinement(min_diag);
   return BOBE_OK;
 }
 
@@ -1025,10 +1035,16 @@ void bobe_gp::set_chol(const double* L, const double* alpha_in) {
                        static_cast<int*>(info.p));
   LAUNCH_CHECK();
   trtri(A.d(), Linv.d(), Tmp.d());
+  // the restored factor's smallest pivot decides about the refinement of the products with Linv, as after a factorisation
+  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w.d(), (const double*)A.d(), Np, Np, res.d(),
+                     (int64_t)0, (int64_t)0, (int64_t)0, (const int*)nullptr);
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(h_res, res.p, 102 * sizeof(double), hipMemcpyDeviceToHost, stream));
   sync();
   factored = true;
   forget_z();
   not_pd = false;
+  decide_refinement(h_res[101]);
 }
 
 // ---- the reference's free functions on caller-supplied matrices (gp.py:170-197), on a handle that holds no training data

@@ -93,6 +93,7 @@ inline double pivot_floor(const Hyper& h, double ulp) {
 // min_diag: the smallest L_jj of a factor (k_mll_terms, res[101]); NaN counts as failed
 inline bool pivots_resolved(double min_diag, double floor) { return min_diag * min_diag >= floor; }
 double default_pivot_floor_ulp();                    // BOBE_PIVOT_FLOOR_ULP, else 64
+double default_refine_kappa();                       // BOBE_REFINE_KAPPA, else 1e7
 
 template <typename K>
 void allow_big_lds(K kernel, int bytes) {
@@ -154,11 +155,21 @@ struct bobe_gp {
   double pivot_ulp = bobe::default_pivot_floor_ulp();     // the rank test's factor (0: sign test only, as dpotrf)
   double pivot_floor(const Hyper& h) const { return bobe::pivot_floor(h, pivot_ulp); }
   bool have_data = false, factored = false, not_pd = false;
+  // One step of iterative refinement of every V = L^-1 K(X, .) (sweep_kernels.hpp, k_trimul_resid): on when the factor's
+  // (kvar + noise) / smallest pivot exceeds refine_kappa (bobe_gp_set_refine_kappa; default BOBE_REFINE_KAPPA, else 1e7;
+  // 0: always, negative: never).  Decided when a factor is installed: the same bits on every rank.
+  double refine_kappa = bobe::default_refine_kappa();
+  bool refine_v = false;
+  void decide_refinement(double min_diag);
+  // V = L^-1 B for ncp (a multiple of 128) columns, refined when refine_v: B [Np x ldb] is then overwritten by the residual;
+  // V may be NULL only without refinement (callers pass a buffer whenever refine_v is set); qp: k_trimul's column sums
+  void solve_v(double* B, int64_t ldb, int64_t ncp, double* V, int64_t ldv, double* qp, int64_t ldq);
   // prepare_z() keeps its results (ZsT, W_Z, base_z) while the same host Z arrives again and nothing they depend on
   // changed: an L-BFGS refinement of one acquisition point calls bobe_gp_wip_grad dozens of times with one Z
   std::vector<double> z_seen;
   int64_t z_seen_m = -1;
-  void forget_z() { z_seen_m = -1; }
+  bool wz_ready = false;        // W_Z = K^-1 K(X,Z) (the score GRADIENTS need it; the sweep itself does not)
+  void forget_z() { z_seen_m = -1; wz_ready = false; }
   int64_t chunk = 8192;
 
   DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs, flags, diag;
@@ -166,7 +177,7 @@ struct bobe_gp {
   // sweep / predict workspace
   DBuf wg_ws;     // workspace of bobe_gp_wip_grad's few-candidates path
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
-      o_misc, kin_a, kin_b, kout;
+      o_misc, kin_a, kin_b, kout, vxc;
   std::vector<bobe::Depth> depths;
   double* h_res = nullptr;  // pinned, 128 doubles
 
@@ -366,7 +377,7 @@ struct bobe_gp {
   void fill(double* p, int64_t n, double v);
 
   // ---- gp_sweep.hip
-  void prepare_z(const double* Z, int64_t M, int64_t Mp);
+  void prepare_z(const double* Z, int64_t M, int64_t Mp, bool need_w);
   // gated: apply the classifier gate (when one is set) to the mean / var outputs (the predict family, not the sweep)
   void sweep(const double* cand, int64_t C, const double* Z, int64_t M, double y_std, double* wipv, double* wipstd,
              double* mean, double* var, int policy, int64_t* argmin_v, double* min_v, int64_t* argmin_s, double* min_s,

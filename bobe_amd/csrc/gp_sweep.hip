@@ -16,14 +16,59 @@ void configure_sweep_kernels() {
   allow_big_lds(k_trimul_t, GEMM_SMEM_BYTES);
   allow_big_lds(k_trimul_v64, GEMM64_SMEM_BYTES);
   allow_big_lds(k_trimul_t64, GEMM64_SMEM_BYTES);
+  allow_big_lds(k_trimul_resid, GEMM_SMEM_BYTES);
+  allow_big_lds(k_trimul_add, GEMM_SMEM_BYTES);
+  allow_big_lds(k_cross_vv<128>, GEMM_SMEM_BYTES);
+  allow_big_lds(k_cross_vv<64>, GEMM64_SMEM_BYTES);
   done[dev] = true;
 }
 }  // namespace bobe
 
-// Z-side quantities of the sweep: ZsT, kXZ, V_Z = Linv kXZ, base_z = kself - |V_Z[:,z]|^2, W_Z = Linv^T V_Z
-void bobe_gp::prepare_z(const double* Z, int64_t M, int64_t Mp) {
+void bobe_gp::decide_refinement(double min_diag) {
+  const double piv = min_diag * min_diag;
+  refine_v = refine_kappa >= 0.0 && piv > 0.0 && (hyp.kvar + hyp.noise) / piv > refine_kappa;
+  if (refine_v) {                       // (k_trimul_resid multiplies with L's diagonal blocks as they lie in A)
+    hipLaunchKernelGGL(k_zero_upper_diag, dim3((unsigned)nb), dim3(256), 0, stream, A.d(), Np);
+    LAUNCH_CHECK();
+  }
+}
+
+void bobe_gp::solve_v(double* B, int64_t ldb, int64_t ncp, double* V, int64_t ldv, double* qp, int64_t ldq) {
+  const dim3 grid((unsigned)(ncp / TILE), (unsigned)nb);
+  if (!refine_v) {
+    hipLaunchKernelGGL(k_trimul, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)Linv.d(), Np, nb, (const double*)B,
+                       ldb, V, ldv, qp, ldq, (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+    return;
+  }
+  if (!V) throw Err(BOBE_ERR_STATE, "solve_v: the refined product needs a buffer for V");
+  hipLaunchKernelGGL(k_trimul, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)Linv.d(), Np, nb, (const double*)B,
+                     ldb, V, ldv, (double*)nullptr, (int64_t)0, (const double*)nullptr, (int64_t)0, 0, (double*)nullptr,
+                     (int64_t)0);
+  hipLaunchKernelGGL(k_trimul_resid, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)A.d(), Np, nb, (const double*)V,
+                     ldv, B, ldb);
+  hipLaunchKernelGGL(k_trimul_add, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)Linv.d(), Np, nb, (const double*)B,
+                     ldb, V, ldv, qp, ldq);
+}
+
+// Z-side quantities of the sweep: ZsT, kXZ, V_Z = Linv kXZ, base_z = kself - |V_Z[:,z]|^2 and - for the score gradients
+// only (need_w) - W_Z = Linv^T V_Z
+void bobe_gp::prepare_z(const double* Z, int64_t M, int64_t Mp, bool need_w) {
   const bool host_z = !is_device_ptr(Z);
-  if (host_z && z_seen_m == M && std::memcmp(z_seen.data(), Z, (size_t)M * d * sizeof(double)) == 0) return;
+  const bool few = (Mp / TILE) * nb < 2 * std::max(num_cus, 1);
+  auto make_w = [&]() {
+    if (few)
+      hipLaunchKernelGGL(k_trimul_t64, dim3((unsigned)(Mp / 64), (unsigned)(2 * nb)), dim3(256), GEMM64_SMEM_BYTES, stream,
+                         (const double*)Linv.d(), Np, 2 * nb, (const double*)VZ.d(), Mp, WZ.d(), Mp);
+    else
+      hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
+                         (const double*)Linv.d(), Np, nb, (const double*)VZ.d(), Mp, WZ.d(), Mp);
+    LAUNCH_CHECK();
+    wz_ready = true;
+  };
+  if (host_z && z_seen_m == M && std::memcmp(z_seen.data(), Z, (size_t)M * d * sizeof(double)) == 0) {
+    if (need_w && !wz_ready) make_w();
+    return;
+  }
   forget_z();
   if (host_z) z_seen.assign(Z, Z + (size_t)M * d);
   const double* zin = fetch(Z, (size_t)M * d, z_stage);
@@ -36,24 +81,25 @@ void bobe_gp::prepare_z(const double* Z, int64_t M, int64_t Mp) {
   scale(zin, M, Mp, hyp, ZsT.d(), Mp);
   kernel_matrix_cross(XsT.d(), Np, N, Np, ZsT.d(), Mp, M, Mp, hyp, kXZ.d(), Mp);
   // few integration points: 64 x 64 tiles (8 x 2 nb of them at M = 512) fill the chip where 4 x nb tiles of 128 x 128 do not
-  if ((Mp / TILE) * nb < 2 * std::max(num_cus, 1)) {
+  if (refine_v) {
+    solve_v(kXZ.d(), Mp, Mp, VZ.d(), Mp, qpart.d(), Mp);
+    hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, stream,
+                       (const double*)qpart.d(), Mp, nb, Mp, hyp.kvar + hyp.noise, 0, basez.d(), (double*)nullptr);
+  } else if (few) {
     const int nt = 2 * nb;
     hipLaunchKernelGGL(k_trimul_v64, dim3((unsigned)(Mp / 64), (unsigned)nt), dim3(256), GEMM64_SMEM_BYTES, stream,
                        (const double*)Linv.d(), Np, nt, (const double*)kXZ.d(), Mp, VZ.d(), Mp, qpart.d(), Mp);
     hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, stream,
                        (const double*)qpart.d(), Mp, nt, Mp, hyp.kvar + hyp.noise, 0, basez.d(), (double*)nullptr);
-    hipLaunchKernelGGL(k_trimul_t64, dim3((unsigned)(Mp / 64), (unsigned)nt), dim3(256), GEMM64_SMEM_BYTES, stream,
-                       (const double*)Linv.d(), Np, nt, (const double*)VZ.d(), Mp, WZ.d(), Mp);
   } else {
     hipLaunchKernelGGL(k_trimul, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
                        (const double*)Linv.d(), Np, nb, (const double*)kXZ.d(), Mp, VZ.d(), Mp, qpart.d(), Mp,
                        (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
     hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, stream,
                        (const double*)qpart.d(), Mp, nb, Mp, hyp.kvar + hyp.noise, 0, basez.d(), (double*)nullptr);
-    hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(Mp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
-                       (const double*)Linv.d(), Np, nb, (const double*)VZ.d(), Mp, WZ.d(), Mp);
   }
   LAUNCH_CHECK();
+  if (need_w) make_w();
   if (host_z) z_seen_m = M;
 }
 
@@ -70,7 +116,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   const bool need_v = wipv || argmin_v || min_v;
   const bool need_s = wipstd || argmin_s || min_s;
   const double* cin = fetch(cand, (size_t)C * d, in_stage);
-  if (do_wip) prepare_z(Z, M, Mp);
+  if (do_wip) prepare_z(Z, M, Mp, false);
   const int64_t CH = chunk;
   // scoring runs once per super-chunk of SC candidates (bounded crossT workspace: Mp x SC doubles)
   const int64_t SC = round_up(std::min<int64_t>(C, std::max<int64_t>(CH, 65536)), CH);
@@ -79,7 +125,8 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   sc.ensure((size_t)SC * sizeof(double));
   qpart.ensure((size_t)nb * (Mp > CH ? Mp : CH) * sizeof(double));
   part.ensure((size_t)nb * (Np > CH ? Np : CH) * sizeof(double));
-  if (do_wip) pv.ensure((size_t)Mp * SC * sizeof(double));   // crossT
+  if (do_wip) pv.ensure((size_t)Mp * SC * sizeof(double));                   // crossT
+  if (do_wip || refine_v) vxc.ensure((size_t)Np * CH * sizeof(double));      // V = Linv K(X, chunk)
   double* d_mean = out_dev(mean, C, o_mean);
   double* d_var = out_dev(var, C, o_var);
   double* d_wipv = nullptr;
@@ -107,18 +154,29 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
       const int64_t nc = (ns - c0 < CH) ? (ns - c0) : CH;
       const int64_t ncp = round_up(nc, TILE);
       // (posterior mean: the assembly leaves K(X, chunk)^T alpha per row tile on the way, k_gemv_t_part's partial sums)
+      prof_begin(BOBE_PROF_KXC);
       kernel_matrix_cross(XsT.d(), Np, N, Np, CsT.d() + c0, SC, nc, ncp, hyp, kXC.d(), CH,
                           d_mean ? (const double*)alpha.d() : nullptr, d_mean ? part.d() : nullptr, CH);
+      prof_end(BOBE_PROF_KXC);
       if (d_mean) {
         hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                            (const double*)part.d(), CH, nb, 0, nc, d_mean + s0 + c0);
       }
       if (do_wip || d_var) {       // (a mean-only prediction - nested sampling's likelihood calls - needs no triangular product)
         prof_begin(BOBE_PROF_TRIMUL);
-        hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)(nb + nzt)), dim3(256), GEMM_SMEM_BYTES,
-                           stream, (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, (double*)nullptr,
-                           (int64_t)0, qpart.d(), CH, (const double*)WZ.d(), Mp, nzt, do_wip ? pv.d() + c0 : nullptr, SC);
+        solve_v(kXC.d(), CH, ncp, (do_wip || refine_v) ? vxc.d() : nullptr, CH, qpart.d(), CH);
         prof_end(BOBE_PROF_TRIMUL);
+        if (do_wip) {
+          // cross-covariances from the two solved factors (sweep_kernels.hpp, k_cross_vv): crossT[z][c] = VZ[:, z] . V[:, c]
+          prof_begin(BOBE_PROF_CROSSVV);
+          if ((int64_t)nzt * (ncp / TILE) >= 2 * std::max(num_cus, 1))
+            hipLaunchKernelGGL(k_cross_vv<128>, dim3((unsigned)(ncp / TILE), (unsigned)nzt), dim3(256), GEMM_SMEM_BYTES, stream,
+                               (const double*)VZ.d(), Mp, (const double*)vxc.d(), CH, Np, pv.d() + c0, SC);
+          else
+            hipLaunchKernelGGL(k_cross_vv<64>, dim3((unsigned)(ncp / 64), (unsigned)(Mp / 64)), dim3(256), GEMM64_SMEM_BYTES,
+                               stream, (const double*)VZ.d(), Mp, (const double*)vxc.d(), CH, Np, pv.d() + c0, SC);
+          prof_end(BOBE_PROF_CROSSVV);
+        }
         // s_c for the scorer, var for the caller
         hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                            (const double*)qpart.d(), CH, nb, nc, kself, policy, sc.d() + c0,
@@ -190,7 +248,7 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
   const int64_t Mp = round_up(M, TILE), CH = std::min<int64_t>(chunk, 1024);
   const double kself = hyp.kvar + hyp.noise;
   const double* cin = fetch(cand, (size_t)C * d, in_stage);
-  prepare_z(Z, M, Mp);                                   // ZsT, W_Z = K^-1 K(X,Z), base_z
+  prepare_z(Z, M, Mp, true);                             // ZsT, V_Z, W_Z = K^-1 K(X,Z), base_z
   CsT.ensure((size_t)d * std::max<int64_t>(CH, chunk) * sizeof(double));
   kXC.ensure((size_t)Np * std::max<int64_t>(CH, chunk) * sizeof(double));
   pv.ensure((size_t)Np * CH * sizeof(double));           // V = Linv k_c
@@ -207,7 +265,7 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
     // 128-column tile passes and one workgroup per candidate (kernels.hpp, "the same for a HANDFUL of candidates").
     const int nzw = (int)(Mp / 64), nnw = (int)((N + WG_ROWS - 1) / WG_ROWS);
     const size_t n_vec = (size_t)C * Np, n_a = (size_t)C * Mp;
-    wg_ws.ensure((3 * n_vec + 2 * n_a + (size_t)C * nzw * WG_ZS + (size_t)C * nnw * WG_NS) * sizeof(double));
+    wg_ws.ensure((6 * n_vec + 2 * n_a + (size_t)C * nzw * WG_ZS + (size_t)C * nnw * WG_NS) * sizeof(double));
     part.ensure((size_t)C * nb * Np * sizeof(double));
     double* kc = wg_ws.d();
     double* vv = kc + n_vec;
@@ -216,6 +274,9 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
     double* b1 = a1 + n_a;
     double* pz = b1 + n_a;
     double* pn = pz + (size_t)C * nzw * WG_ZS;
+    double* t1 = pn + (size_t)C * nnw * WG_NS;     // three more vectors per candidate: the refinement step's temporaries
+    double* t2 = t1 + n_vec;
+    double* t3 = t2 + n_vec;
     const Hyper& h = hyp;
     const double* li = Linv.d();
 #define FEW(KE, DC)                                                                                                      \
@@ -223,8 +284,20 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
     hipLaunchKernelGGL((k_wg_col<KE, DC>), dim3((unsigned)(Np / 256 + 1), (unsigned)C), dim3(256), 0, stream,           \
                        (const double*)XsT.d(), Np, N, Np, cin, h, kc);                                                 \
     solve_alpha(li, vv, uu, part.d(), (int)C, 0, Np, (int64_t)nb * Np, (const double*)kc, Np);                             \
+    if (refine_v) {   /* v += Linv (k - L v), u += Linv^T of the same correction (sweep_kernels.hpp, k_trimul_resid) */   \
+      const unsigned gv_ = (unsigned)((n_vec + 255) / 256);                                                              \
+      hipLaunchKernelGGL(k_gemv_lower, dim3((unsigned)(Np / 4), (unsigned)C), dim3(256), 0, stream, (const double*)A.d(), \
+                         Np, Np, (const double*)vv, t1, (int64_t)0, Np, Np);                                             \
+      hipLaunchKernelGGL(k_vec_axpy, dim3(gv_), dim3(256), 0, stream, t1, (const double*)kc, (const double*)t1, -1.0,    \
+                         (int64_t)n_vec);                                                                                \
+      solve_alpha(li, t2, t3, part.d(), (int)C, 0, Np, (int64_t)nb * Np, (const double*)t1, Np);                         \
+      hipLaunchKernelGGL(k_vec_axpy, dim3(gv_), dim3(256), 0, stream, vv, (const double*)vv, (const double*)t2, 1.0,     \
+                         (int64_t)n_vec);                                                                                \
+      hipLaunchKernelGGL(k_vec_axpy, dim3(gv_), dim3(256), 0, stream, uu, (const double*)uu, (const double*)t3, 1.0,     \
+                         (int64_t)n_vec);                                                                                \
+    }                                                                                                                    \
     hipLaunchKernelGGL((k_wg_cross<KE, DC>), dim3((unsigned)nzw, (unsigned)C), dim3(256), (size_t)N * sizeof(double),     \
-                       stream, (const double*)ZsT.d(), Mp, M, (const double*)WZ.d(), Mp, N, Np,                  \
+                       stream, (const double*)ZsT.d(), Mp, M, (const double*)VZ.d(), Mp, N, Np,                  \
                        (const double*)kc, (const double*)vv, cin, h, kself, (const double*)basez.d(), y_std * y_std,   \
                        a1, b1, Mp, pz);                                                                                  \
     hipLaunchKernelGGL((k_wg_rows<KE, DC>), dim3((unsigned)nnw, (unsigned)C), dim3(256), 0, stream,                    \
@@ -269,9 +342,7 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
     const int64_t nc = std::min<int64_t>(CH, C - c0), ncp = round_up(nc, TILE);
     scale(cin + c0 * d, nc, ncp, hyp, CsT.d(), CH);
     kernel_matrix_cross(XsT.d(), Np, N, Np, CsT.d(), CH, nc, ncp, hyp, kXC.d(), CH);
-    hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
-                       (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, pv.d(), CH, qpart.d(), CH,
-                       (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+    solve_v(kXC.d(), CH, ncp, pv.d(), CH, qpart.d(), CH);
     hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                        (const double*)qpart.d(), CH, nb, nc, kself, 1, sc.d(), (double*)nullptr);
     hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
@@ -279,7 +350,8 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
 #define WG(KE, DC)                                                                                                   \
   hipLaunchKernelGGL((k_wip_grad<KE, DC>), dim3((unsigned)nc), dim3(256), 0, stream, (const double*)XsT.d(), Np,  \
                      N, (const double*)CsT.d(), CH, (const double*)ZsT.d(), Mp, M, (const double*)WZ.d(),  \
-                     Mp, (const double*)ps.d(), CH, (const double*)sc.d(), (const double*)basez.d(), hyp,  \
+                     Mp, (const double*)ps.d(), CH, (const double*)VZ.d(), (const double*)pv.d(), CH,         \
+                     (const double*)sc.d(), (const double*)basez.d(), hyp,                                        \
                      y_std * y_std, d_v ? d_v + c0 : nullptr, d_s ? d_s + c0 : nullptr, d_dv ? d_dv + c0 * d : nullptr, \
                      d_ds ? d_ds + c0 * d : nullptr)
     if (hyp.kern == 0) {
@@ -358,9 +430,7 @@ void bobe_gp::predict_grad(const double* Xq, int64_t C, double* mean, double* va
       hipLaunchKernelGGL(k_colsum_parts, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                          (const double*)part.d(), CH, nb, 0, nc, d_mean + c0);
     }
-    hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
-                       (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, VZ.d(), CH, qpart.d(), CH,
-                       (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+    solve_v(kXC.d(), CH, ncp, VZ.d(), CH, qpart.d(), CH);
     hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                        (const double*)qpart.d(), CH, nb, nc, kself, 1, sc.d(), d_var ? d_var + c0 : nullptr);
     hipLaunchKernelGGL(k_trimul_t, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
@@ -446,9 +516,7 @@ int bobe_gp::append(const double* X_new, int64_t b, const double* y_all) {
   scale(X.d(), N0, Np, hyp, XsT.d(), Np);                                    // old points only (rest 0)
   scale(X.d() + N0 * d, b, bp, hyp, kin_a.d(), bp);
   kernel_matrix_cross(XsT.d(), Np, N0, Np, kin_a.d(), bp, b, bp, hyp, kXC.d(), bp);
-  hipLaunchKernelGGL(k_trimul, dim3(1, (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream, (const double*)Linv.d(), Np,
-                     nb, (const double*)kXC.d(), bp, VZ.d(), bp, (double*)nullptr, (int64_t)0, (const double*)nullptr,
-                     (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+  solve_v(kXC.d(), bp, bp, VZ.d(), bp, nullptr, 0);
   hipLaunchKernelGGL(k_trimul_t, dim3(1, (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream, (const double*)Linv.d(), Np,
                      nb, (const double*)VZ.d(), bp, WZ.d(), bp);
   double* G = o_misc.d();                                                             // b*b Gram matrix V^T V
@@ -512,7 +580,12 @@ int bobe_gp::append(const double* X_new, int64_t b, const double* y_all) {
   LAUNCH_CHECK();
   scale(X.d(), N1, Np, hyp, XsT.d(), Np);                                    // all points again
   solve_alpha(Linv.d(), w.d(), alpha.d(), part.d());                     // alpha = Linv^T Linv y
+  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w.d(), (const double*)A.d(), Np, Np, res.d(),
+                     (int64_t)0, (int64_t)0, (int64_t)0, (const int*)nullptr);     // (the grown factor's smallest pivot)
+  LAUNCH_CHECK();
+  HIPCHK(hipMemcpyAsync(h_res, res.p, 102 * sizeof(double), hipMemcpyDeviceToHost, stream));
   sync();                               // (s22 / hG are host temporaries of this call)
+  decide_refinement(h_res[101]);
   } catch (...) {
     nx.release();
     oa.release();

@@ -9,7 +9,8 @@ namespace bobe {
 //   y <  nzt : cross tile   G[z][c]  = sum_n  WZ[n][z] B[n][c]      (full K)   -> crossT (optional, nzt may be 0)
 //   y >= nzt : V tile       V[i][c]  = sum_{k<=i} Linv[i][k] B[k][c] (lower-triangular K range), row tile
 //              ti = nb-1-(y-nzt); optional store to V, optional qpart[ti*ldq + c] = sum over the tile's rows of V^2
-// B is [Np x ncols] row-major (RC).
+// B is [Np x ncols] row-major (RC).  (The sweep launches it with nzt = 0 and V stored: its cross-covariances come from
+// k_cross_vv below, the product of two SOLVED factors, not from K^-1 K(X,Z) - see there.)
 __global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Linv, int64_t ldi, int nb,
                                                    const double* __restrict__ B, int64_t ldb, double* __restrict__ V,
                                                    int64_t ldv, double* __restrict__ qpart, int64_t ldq,
@@ -47,6 +48,115 @@ __global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Li
     }
     __syncthreads();
     if (t < TILE) qpart[(int64_t)ti * ldq + (int64_t)tc * TILE + t] = red[t] + red[TILE + t];
+  }
+}
+
+// ---- one step of iterative refinement of V = L^-1 B with the factor itself --------------------------------------------
+// The product Linv * B is not a backward-stable solve: its error is eps |Linv| |B|, far above eps |V| when K(X, .) lies in
+// the span of K's large eigenvectors - which it does for a smooth kernel.  The posterior variance tolerates that, the
+// fantasy variance base_z - cross^2 / s_c does not: it is a difference of quantities that are each exact only for a
+// CONSISTENTLY perturbed factor.  Measured at the reference's default noise of 1e-8 on a BO design of 1800 points
+// (profiles/r05_conditioning.txt): kernel variance 4.67e4 (cond K ~3e14) WIPV 1.3e-2 off the extended-precision value,
+// 3.5e5 1.0 off; a triangular solve with the same L: 6e-5 / 2e-3; ONE refinement step V += Linv (B - L V): 6e-5 / 7e-4.
+// Two more triangular GEMMs per chunk, so the step runs only where it is needed (bobe_gp::refine_v: (kvar + noise) /
+// smallest pivot above BOBE_REFINE_KAPPA, default 1e7 - never at noise >= 1e-6 with unit kernel variance).
+//   k_trimul_resid : B[i][c] <- B[i][c] - sum_{k<=i} L[i][k] V[k][c]     (row tile ti = nb-1-y, in place over B)
+//   k_trimul_add   : V[i][c] <- V[i][c] + sum_{k<=i} Linv[i][k] R[k][c], qpart[ti*ldq + c] = column sums of squares of
+//                    the new V over the tile's rows (k_trimul's epilogue)
+// L's diagonal 128-blocks must hold zeros above the diagonal (k_zero_upper_diag; the factorisation leaves them alone).
+__global__ __launch_bounds__(256, 2) void k_trimul_resid(const double* __restrict__ L, int64_t ldl, int nb,
+                                                         const double* __restrict__ V, int64_t ldv,
+                                                         double* __restrict__ B, int64_t ldb) {
+  extern __shared__ double smem[];
+  const int tc = blockIdx.x;
+  const int ti = nb - 1 - (int)blockIdx.y;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<KC, RC, TILE, TILE, BK128, false, WgSync, true>(acc, L, ldl, (int64_t)ti * TILE, V, ldv, (int64_t)tc * TILE, 0,
+                                                            (int64_t)(ti + 1) * TILE, smem);
+  store_tile(acc, B, ldb, (int64_t)ti * TILE, (int64_t)tc * TILE, -1.0, 1.0);
+}
+
+__global__ __launch_bounds__(256, 2) void k_trimul_add(const double* __restrict__ Linv, int64_t ldi, int nb,
+                                                       const double* __restrict__ Rm, int64_t ldr, double* __restrict__ V,
+                                                       int64_t ldv, double* __restrict__ qpart, int64_t ldq) {
+  extern __shared__ double smem[];
+  const int tc = blockIdx.x;
+  const int ti = nb - 1 - (int)blockIdx.y;
+  v4d acc[4][4];
+  acc_zero(acc);
+  gemm_tile<KC, RC, TILE, TILE, BK128, false, WgSync, true>(acc, Linv, ldi, (int64_t)ti * TILE, Rm, ldr, (int64_t)tc * TILE, 0,
+                                                            (int64_t)(ti + 1) * TILE, smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* q = V + ((int64_t)ti * TILE + acc_row(i, r)) * ldv + (int64_t)tc * TILE + acc_col(j);
+        acc[i][j][r] += *q;
+        *q = acc[i][j][r];
+      }
+  if (qpart) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __syncthreads();                 // (the K loop's last LDS reads are behind every wave before the image is reused)
+    double* red = smem;  // [2][128]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 16) red[(wave >> 1) * TILE + (wave & 1) * 64 + 16 * j + lane] = s;
+    }
+    __syncthreads();
+    if (t < TILE) qpart[(int64_t)ti * ldq + (int64_t)tc * TILE + t] = red[t] + red[TILE + t];
+  }
+}
+
+// zeros above the diagonal of every diagonal 128-block of a lower factor (grid = nb)
+__global__ __launch_bounds__(256) void k_zero_upper_diag(double* __restrict__ A, int64_t ld) {
+  double* blk = A + ((int64_t)blockIdx.x * TILE) * ld + (int64_t)blockIdx.x * TILE;
+  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+    const int r = e / TILE, c = e % TILE;
+    if (c > r) blk[(int64_t)r * ld + c] = 0.0;
+  }
+}
+
+// v[c*ldv + i] += dv[c*ldv + i]  /  r[c*ldv + i] = k[c*ldv + i] - lv[c*ldv + i]   (the vector forms of the same step)
+__global__ void k_vec_axpy(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, double sb,
+                           int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a[i] + sb * b[i];
+}
+
+// ---- the sweep's cross-covariance product: G[z][c] = sum_n VZ[n][z] V[n][c], VZ = L^-1 K(X,Z), V = L^-1 K(X,C) -------
+// cross(c, z) = k(x_c, z) - G[z][c] is the reference's own form: fantasy_var solves with the (N+1)-row factor
+// (gp.py:552-576), whose last row is L^-1 k_c, so the cross term is an inner product of two triangular-solve results.
+// Algebraically G = K(X,Z)^T K^-1 K(X,C) as well, and until round 5 the sweep formed it that way (W_Z = K^-1 K(X,Z) once per
+// sweep, then W_Z^T K(X,C) as extra row tiles of k_trimul, V never stored) - but K^-1 K(X,Z) carries cond(K) eps where the
+// solved factors carry sqrt(cond(K)) eps: at the reference's default noise of 1e-8 and kernel variances from ~5e4 the WIPV
+// scores came out 1e-2 ... 1 (relative) off an extended-precision evaluation where the triangular-solve form is 1e-4 ...
+// 1e-1 off (profiles/r05_conditioning.txt, tests/test_gpu_conditioning.py).  Same 2 N M flops per candidate.
+// T = 128: grid (ncols / 128, Mp / 128); T = 64: grid (ncols / 64, Mp / 64) - few integration points fill the chip only
+// with the small tile.
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_cross_vv(const double* __restrict__ VZ, int64_t ldz,
+                                                     const double* __restrict__ V, int64_t ldv, int64_t kend,
+                                                     double* __restrict__ crossT, int64_t ldx) {
+  extern __shared__ double smem[];
+  const int tc = blockIdx.x, tz = blockIdx.y;
+  v4d acc[T / 32][T / 32];
+  acc_zero(acc);
+  if constexpr (T == 128) {
+    gemm_tile<RC, RC>(acc, VZ, ldz, (int64_t)tz * TILE, V, ldv, (int64_t)tc * TILE, 0, kend, smem);
+    store_tile(acc, crossT, ldx, (int64_t)tz * TILE, (int64_t)tc * TILE, 1.0, 0.0);
+  } else {
+    gemm_tile<RC, RC, 64, 64, BK64>(acc, VZ, ldz, (int64_t)tz * 64, V, ldv, (int64_t)tc * 64, 0, kend, smem);
+    store_tile<64, 64>(acc, crossT, ldx, (int64_t)tz * 64, (int64_t)tc * 64, 1.0, 0.0);
   }
 }
 
@@ -108,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_trimul_t64(const double* __restrict_
 }
 
 // ---- WIPV / WIPStd scoring of every candidate (BOBE/gp.py:552-576, acquisition.py:438-465) -------
-// crossT[z*ldx + c] = sum_n WZ[n][z] kXC[n][c] (from k_trimul).  For candidate c and integration point z:
+// crossT[z*ldx + c] = sum_n VZ[n][z] V[n][c] (from k_cross_vv).  For candidate c and integration point z:
 //   cross = k(x_c, z) - crossT;  var+ = base_z - cross^2 / s_c  -> NaN / < 1e-12 -> 1e-12 -> * ystd2
 // wipv[c] = mean_z var+, wipstd[c] = mean_z sqrt(var+).  One workgroup = 64 candidates x 4 interleaved
 // z-slices; per-candidate sums are combined in a fixed order, so results do not depend on chunking.
@@ -384,8 +494,8 @@ __global__ __launch_bounds__(256) void k_predict_grad(const double* __restrict__
 
 // ---- WIPV / WIPStd and their gradients w.r.t. the candidate coordinates ---------------------------------------
 // (what the reference gets from jax.grad of WIPV.fun / WIPStd.fun in the local refinement, acquisition.py:403-412)
-// One workgroup per candidate c.  With s = kself - k_c^T K^-1 k_c, u = K^-1 k_c, W = K^-1 K(X,Z):
-//   cross_z      = k(z,x) - sum_n W[n][z] k(x_n,x)
+// One workgroup per candidate c.  With s = kself - k_c^T K^-1 k_c, u = K^-1 k_c, W = K^-1 K(X,Z), v = L^-1 k_c, VZ = L^-1 K(X,Z):
+//   cross_z      = k(z,x) - sum_n VZ[n][z] v_n       (the VALUE from the solved factors, as in the sweep: k_cross_vv)
 //   var+_z       = base_z - cross_z^2 / s                       (floors of gp.py:574-575; floored terms have zero gradient)
 //   d cross_z/dx_j = [G_z (s_zj - s_xj) - sum_n W[n][z] G_n (s_nj - s_xj)] / ls_j,   d s/dx_j = -2 sum_n u_n G_n (s_nj - s_xj) / ls_j
 //   d var+_z/dx_j = -2 cross_z/s * d cross_z/dx_j + cross_z^2/s^2 * d s/dx_j
@@ -396,12 +506,13 @@ __global__ __launch_bounds__(256) void k_wip_grad(const double* __restrict__ XsT
                                                   const double* __restrict__ ZsT, int64_t ldz, int64_t m,
                                                   const double* __restrict__ W, int64_t ldw,
                                                   const double* __restrict__ U, int64_t ldu,
+                                                  const double* __restrict__ VZ, const double* __restrict__ Vc, int64_t ldv,
                                                   const double* __restrict__ sc, const double* __restrict__ basez, Hyper h,
                                                   double ystd2, double* __restrict__ wipv, double* __restrict__ wipstd,
                                                   double* __restrict__ dwipv, double* __restrict__ dwipstd) {
   constexpr int NT = 128;
   __shared__ double T[DCAP][NT];      // G_n (s_nj - s_xj) of the staged training points
-  __shared__ double kcv[NT];          // k(x_n, x)
+  __shared__ double kcv[NT];          // v_n = (L^-1 k_c)_n of the staged training points
   __shared__ double dsred[NT];
   __shared__ double ds[DCAP];         // sum_n u_n T[j][n]
   __shared__ double red[4];
@@ -429,7 +540,7 @@ __global__ __launch_bounds__(256) void k_wip_grad(const double* __restrict__ XsT
       const double g = (nn < n) ? kern_grad_factor<KERN>(r2, h.kvar, kv) : 0.0;
 #pragma unroll
       for (int j = 0; j < DCAP; ++j) T[j][t] = g * df[j];
-      kcv[t] = kv;
+      kcv[t] = (nn < n) ? Vc[nn * ldv + c] : 0.0;
       un = (nn < n) ? U[nn * ldu + c] : 0.0;
     }
     return un;
@@ -481,21 +592,25 @@ __global__ __launch_bounds__(256) void k_wip_grad(const double* __restrict__ XsT
         // (eight rows of W in flight per thread: one load per iteration left the loop waiting on memory, ~1000 cycles
         // per training point; the sums keep their order)
         const double* wp = W + n0 * ldw + z;
+        const double* vp = VZ + n0 * ldw + z;          // (VZ has W's shape and leading dimension)
         int nn = 0;
         for (; nn + 8 <= nn_end; nn += 8) {
-          double w8[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) w8[q] = wp[(int64_t)(nn + q) * ldw];
+          double w8[8], v8[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            acck = __builtin_fma(w8[q], kcv[nn + q], acck);
+            w8[q] = wp[(int64_t)(nn + q) * ldw];
+            v8[q] = vp[(int64_t)(nn + q) * ldw];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            acck = __builtin_fma(v8[q], kcv[nn + q], acck);
 #pragma unroll
             for (int j = 0; j < DCAP; ++j) accw[j] = __builtin_fma(w8[q], T[j][nn + q], accw[j]);
           }
         }
         for (; nn < nn_end; ++nn) {
           const double w = wp[(int64_t)nn * ldw];
-          acck = __builtin_fma(w, kcv[nn], acck);
+          acck = __builtin_fma(vp[(int64_t)nn * ldw], kcv[nn], acck);
 #pragma unroll
           for (int j = 0; j < DCAP; ++j) accw[j] = __builtin_fma(w, T[j][nn], accw[j]);
         }
@@ -590,22 +705,21 @@ constexpr int WG_NS = 3 * MAX_D;         // doubles per k_wg_rows partial: Qv[j]
 // one workgroup = 64 integration points (lane) x 4 interleaved quarters of the training points (wave)
 template <int KERN, int DCAP>
 __global__ __launch_bounds__(256) void k_wg_cross(const double* __restrict__ ZsT, int64_t ldz, int64_t m,
-                                                  const double* __restrict__ W, int64_t ldw, int64_t n, int64_t np,
+                                                  const double* __restrict__ VZ, int64_t ldw, int64_t n, int64_t np,
                                                   const double* __restrict__ kc, const double* __restrict__ v,
                                                   const double* __restrict__ cand, Hyper h, double kself,
                                                   const double* __restrict__ basez, double ystd2,
                                                   double* __restrict__ a1, double* __restrict__ b1, int64_t lda,
                                                   double* __restrict__ partZ) {
-  extern __shared__ double kcs[];                 // [n]
+  extern __shared__ double kcs[];                 // [n]: v = L^-1 k_c (the cross term is VZ^T v, as in the sweep)
   __shared__ double red[4], redz[4][64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t c = blockIdx.y;
-  kc += c * np;
   v += c * np;
   double sq = 0.0;
   for (int64_t i = t; i < n; i += 256) {
-    kcs[i] = kc[i];
     const double vi = v[i];
+    kcs[i] = vi;
     sq += vi * vi;
   }
   sq = wave_sum(sq);
@@ -616,7 +730,7 @@ __global__ __launch_bounds__(256) void k_wg_cross(const double* __restrict__ ZsT
   const int64_t z = (int64_t)blockIdx.x * 64 + lane;
   double acc = 0.0;
   {
-    const double* wp = W + z;
+    const double* wp = VZ + z;
     int64_t i = wave;
     for (; i + 28 < n; i += 32) {                 // eight rows in flight per thread
       double w8[8];

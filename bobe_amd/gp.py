@@ -421,6 +421,26 @@ class GP:
                         "restores the reference's sign-only test.")
 
     @property
+    def refine_kappa(self) -> float:
+        """Threshold of the refined products with the inverse factor (include/bobe_gp.h, bobe_gp_set_refine_kappa): one
+        step of iterative refinement where (kernel_variance + noise) / smallest pivot exceeds it.  1e7 by default, 0 =
+        always, negative = never; takes effect at the next factorisation."""
+        k = C.c_double()
+        _lib.check(self._lib.bobe_gp_get_refine(self._h, C.byref(k), None), "bobe_gp_get_refine")
+        return float(k.value)
+
+    @refine_kappa.setter
+    def refine_kappa(self, kappa: float) -> None:
+        _lib.check(self._lib.bobe_gp_set_refine_kappa(self._h, float(kappa)), "bobe_gp_set_refine_kappa")
+
+    @property
+    def refining(self) -> bool:
+        """Whether the current factor's products with the inverse factor take the refinement step."""
+        a = C.c_int()
+        _lib.check(self._lib.bobe_gp_get_refine(self._h, None, C.byref(a)), "bobe_gp_get_refine")
+        return bool(a.value)
+
+    @property
     def pivot_floor_ulp(self) -> float:
         """The rank test's factor (include/bobe_gp.h, "Conventions"): 64 by default, 0 = the reference's rule (only a
         pivot <= 0 fails, as LAPACK's dpotrf reports it).  Takes effect at the next factorisation / MLL evaluation."""

@@ -167,6 +167,17 @@ int bobe_gp_chol_row_update(bobe_gp_t* gp, const double* L, int64_t n, const dou
 int bobe_gp_set_pivot_floor_ulp(bobe_gp_t* gp, double ulp);
 double bobe_gp_get_pivot_floor_ulp(bobe_gp_t* gp);
 
+/* Products with the explicit inverse factor (v = Linv k in bobe_gp_predict, _wip_sweep, _fantasy_var, _wip_grad,
+ * _predict_grad, _append) take ONE step of iterative refinement with the factor itself, v += Linv (k - L v), when the
+ * installed factor's (kernel_variance + noise) / smallest pivot exceeds `kappa`: that restores the accuracy of the
+ * reference's triangular solve (gp.py:462, 571) where the plain product loses it - the fantasy variance at the default noise
+ * of 1e-8 from kernel variances of ~1e4 (profiles/r05_conditioning.txt) - at three times the GEMM work of those calls.
+ * Default: BOBE_REFINE_KAPPA, else 1e7; 0 = always, negative = never.  The decision is taken when a factor is installed
+ * (bobe_gp_factor, _set_chol, _append, _clone_state) - set kappa before.  get: either output may be NULL; *active = 1
+ * while the current factor's products are refined. */
+int bobe_gp_set_refine_kappa(bobe_gp_t* gp, double kappa);
+int bobe_gp_get_refine(bobe_gp_t* gp, double* kappa, int* active);
+
 /* GP.cholesky / GP.alphas (gp.py:259-260; state_dict keys gp.py:626-627): L is N x N lower with
  * zeros above the diagonal, alpha has N entries.  Either may be NULL. */
 int bobe_gp_get_chol(bobe_gp_t* gp, double* L, double* alpha);
@@ -295,8 +306,10 @@ int bobe_debug_time_potrf_lockstep(bobe_gp_t* gp, int B, int reps, double* ms);
 #define BOBE_PROF_TRTRI 4  /* one level of the recursive triangular inverse (two launches) */
 #define BOBE_PROF_LAUUM 5  /* K^-1 = Linv^T Linv fused with the gradient reduction */
 #define BOBE_PROF_TRIMUL 6 /* sweep: V = Linv * K(X, C_chunk) with column sum of squares */
-#define BOBE_PROF_CROSS 7  /* sweep: cross-covariance GEMM + WIPV / WIPStd scoring */
+#define BOBE_PROF_CROSS 7  /* sweep: WIPV / WIPStd scoring */
 #define BOBE_PROF_KXX 8    /* K(X,X) assembly */
+#define BOBE_PROF_CROSSVV 9 /* sweep: cross-covariance GEMM V_Z^T V of the two solved factors */
+#define BOBE_PROF_KXC 10   /* sweep: K(X, C_chunk) assembly */
 int bobe_gp_profile_select(bobe_gp_t* gp, int kernel_class);
 int bobe_gp_profile_read(bobe_gp_t* gp, double* total_ms, int64_t* launches);
 /* back-to-back v_mfma_f64_16x16x4_f64 issue rate on all CUs (1 or 2 waves per SIMD), in TFLOP/s */

@@ -71,3 +71,44 @@ def fantasy_var(kern, X, L, ls, kvar, noise, xnew, Z, y_std):
                           C.c_double(noise), xnew.ctypes.data_as(C.c_void_p), Z.ctypes.data_as(C.c_void_p),
                           C.c_int(Z.shape[0]), C.c_double(y_std), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+# ---- extended-precision truth (oracle/bobe_oracle_xp.c): long double ("xp") or __float128 ("xq") --------------------
+_xlibs = {}
+
+
+def load_xp(kind: str = "xp"):
+    if kind not in _xlibs:
+        path = os.path.join(_HERE, f"libbobe_oracle_{kind}.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", _HERE, os.path.basename(path)], check=True)
+        lib = C.CDLL(path)
+        lib.xp_gp_truth.restype = C.c_int
+        lib.xp_digits.restype = C.c_int
+        _xlibs[kind] = lib
+    return _xlibs[kind]
+
+
+def gp_truth(kern, X, y, ls, kvar, noise, Xq=None, Z=None, want_grad=True, kind: str = "xp"):
+    """The hot path's quantities in extended precision from fp64 inputs (y: standardised targets).  Returns a dict:
+    info (0, or 1 + the column of the first non-positive pivot), mll, grad, mean, var, var_z, fantasy (c x m), min_pivot,
+    digits - variances in standardised units, noise included, no floors."""
+    lib = load_xp(kind)
+    X, y, ls = _f(X), _f(y).reshape(-1), _f(ls)
+    n, d = X.shape
+    Xq = _f(np.atleast_2d(Xq)) if Xq is not None else np.empty((0, d))
+    Z = _f(np.atleast_2d(Z)) if Z is not None else np.empty((0, d))
+    c, m = Xq.shape[0], Z.shape[0]
+    mll, mp = C.c_double(), C.c_double()
+    grad = np.empty(d + 1) if want_grad else None
+    mean, var, var_z, fant, cross = np.empty(c), np.empty(c), np.empty(m), np.empty((c, m)), np.empty((c, m))
+
+    def p(a):
+        return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    info = lib.xp_gp_truth(C.c_int(kern), p(X), p(y), C.c_int(n), C.c_int(d), p(ls), C.c_double(kvar), C.c_double(noise),
+                           p(Xq), C.c_int(c), p(Z), C.c_int(m), C.byref(mll), p(grad), p(mean), p(var), p(var_z),
+                           p(fant) if c and m else None, C.byref(mp), p(cross) if c and m else None)
+    if info != 0:
+        return {"info": int(info), "digits": int(lib.xp_digits())}
+    return {"info": 0, "mll": mll.value, "grad": grad, "mean": mean, "var": var, "var_z": var_z, "fantasy": fant, "cross": cross,
+            "min_pivot": mp.value, "digits": int(lib.xp_digits())}
