@@ -63,15 +63,31 @@ def _worker(rank, world, port, q):
         mll, par = merge_best_fit(-3.0 + 5 * rank, np.array([rank, 2.0 * rank]))
         top = world - 1                                  # the largest mll sits on the last rank
         ok = ok and mll == -3.0 + 5 * top and np.array_equal(par, [top, 2.0 * top])
+        # the 8-GPU shape of the strong mode (bench.py --gpus 8): the fit has 4 restarts, so ranks 4.. hold none and hand in
+        # (-inf, theta_0) - it must never win, not even against a restart whose mll is NaN or very negative
+        from bobe_amd.dist_sweep import shard_bounds as sb
+        lo, hi = sb(4, world, rank)
+        mine = (-1e300 if rank == 0 else -50.0 - rank, np.array([float(rank), 1.0])) if hi > lo else \
+            (-np.inf, np.array([99.0, 99.0]))
+        mll, par = merge_best_fit(*mine)
+        holders = [r for r in range(world) if sb(4, world, r)[1] > sb(4, world, r)[0]]
+        best = max(holders, key=lambda r: (-1e300 if r == 0 else -50.0 - r))
+        ok = ok and par[0] == float(best) and par[0] != 99.0 and np.isfinite(mll)
+        # ... and a rank without candidates (5 candidates over 8 ranks) hands in (+inf, 2^52): never the argmin
+        lo, hi = sb(5, world, rank)
+        loc = (10.0 + rank, lo) if hi > lo else (float("inf"), 2 ** 52)
+        smin, sidx = merge_argmin(*loc)
+        ok = ok and smin == 10.0 and sidx == 0
         q.put((rank, bool(ok), int(gidx), int(full["argmin_s"])))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_sweep_gloo(world):
-    """two ranks, and three (uneven shards of the 101 candidates: 34 / 34 / 33, np.array_split's bounds)"""
+    """two ranks, three (uneven shards of the 101 candidates: 34 / 34 / 33, np.array_split's bounds) and eight - the shape
+    of the driver's 8-GPU run: more ranks than restarts, ranks without a restart or without a candidate in the merges"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

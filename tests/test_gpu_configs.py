@@ -97,6 +97,43 @@ def test_bench_gpus_2_really_runs_two_ranks_weak_and_strong():
     assert sh["check"]["min_wipstd"] == pytest.approx(full["min_s"], rel=1e-10)
 
 
+def test_bench_more_ranks_than_restarts_and_uneven_shards():
+    """The shape of the driver's 8-GPU run that one GPU can rehearse: MORE RANKS THAN RESTARTS (eight ranks, four restarts
+    there; four ranks, two restarts here: ranks 2 and 3 hold none, ``fit_evals([])`` hands (-inf, theta_0) to
+    ``merge_best_fit`` and must never win) and UNEVEN candidate shards (8201 = 2051 + 3 x 2050).  Four ranks, not eight:
+    the pool lets at most six processes have the card open, and the test runner and the launcher are two of them (the
+    eight-rank merges themselves run on the CPU: tests/test_dist_cpu.py, world 8).  Same pick and same best restart as one
+    rank doing everything; in the weak mode the strong sub-record reports all four phases."""
+    common = ["--fit-concurrency", "2"]
+    one = _run_bench(["--gpus", "1", "--config", "shard", "--shard-candidates", "8201"] + common)
+    many = _run_bench(["--gpus", "4", "--backend", "gloo", "--config", "shard", "--shard-candidates", "8201"] + common,
+                      timeout=900)
+    assert many["n_gpus"] == 4 and many["world_size"] == 4 and many["scaling"] == "strong"
+    assert many["config"]["candidates_total"] == 8201 and many["config"]["candidates_per_gpu"] == 2051
+    assert "2 restarts" in many["config"]["fit"]
+    assert many["check"]["argmin"] == one["check"]["argmin"]
+    assert many["check"]["min_wipstd"] == pytest.approx(one["check"]["min_wipstd"], rel=1e-10)
+    assert np.isfinite(many["check"]["best_mll"])
+    assert many["check"]["best_mll"] == pytest.approx(one["check"]["best_mll"], rel=1e-10)
+    weak = _run_bench(["--gpus", "4", "--backend", "gloo", "--config", "tiny", "--shard-candidates", "4101"] + common,
+                      timeout=900)
+    sh = weak["shard"]
+    assert weak["n_gpus"] == 4 and weak["scaling"] == "weak" and sh["scaling"] == "strong"
+    assert sh["candidates_total"] == 4101 and sh["candidates_per_gpu"] == 1026          # rank 0 of 1026 + 3 x 1025
+    assert sh["restarts_rank0"] == [0]
+    assert all(np.isfinite(sh[k]) and sh[k] >= 0 for k in ("fit_ms", "refactor_ms", "sweep_ms", "exchange_ms"))
+    assert np.isfinite(sh["check"]["best_mll"])
+    from bobe_amd import GP
+    from bobe_amd.synthetic import CONFIGS, sobol_candidates, synthetic_problem, theta_schedule
+    N, d, _, M = CONFIGS["tiny"]
+    X, y, _, Z = synthetic_problem(N, d, 8, M, noise=1e-6)
+    th = theta_schedule(d)
+    gp = GP(X, y, noise=1e-6, lengthscales=np.exp(th[-1, :d]), kernel_variance=float(np.exp(th[-1, d])))
+    full = gp.wip_sweep(sobol_candidates(d, 4101), Z)
+    assert sh["check"]["argmin"] == full["argmin_s"]
+    assert sh["check"]["min_wipstd"] == pytest.approx(full["min_s"], rel=1e-10)
+
+
 def test_bench_exchange_rccl_goes_through_the_shipped_entry_points():
     """--exchange rccl: the cycle's sweep is bobe_mgpu_wip_sweep itself (shard sweep + ncclAllGather + merge inside the
     library) and the fit merge bobe_mgpu_best_fit - one rank here (RCCL refuses two ranks on one device), same pick."""

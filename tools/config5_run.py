@@ -95,9 +95,9 @@ samplers.nested_sampling = traced
 orig_update = BOBE.update_gp
 
 
-def traced_update(self, new_u, new_vals, fit_n_points):
+def traced_update(self, new_u, new_vals, step=0, verbose=True):
     before = self.gp.npoints
-    orig_update(self, new_u, new_vals, fit_n_points)
+    orig_update(self, new_u, new_vals, step=step, verbose=verbose)
     for c in checkpoints:
         if before < c <= self.gp.npoints:
             print(f"== checkpoint N={self.gp.npoints} at {time.time() - t_start:.1f}s: timing "
