@@ -440,8 +440,12 @@ def main():
     if rank == 0:
         chunk = args.chunk or 8192
         # k_trimul = one launch per candidate chunk: V = Linv K(X,C) (N^2 flops per candidate: the triangular count) with the
-        # column sums of squares in the epilogue; k_cross_vv = the cross-covariance GEMM V_Z^T V (2 N M per candidate)
-        flops_per_launch = {"trimul": float(N) * N * min(chunk, Cn), "crossvv": 2.0 * N * M * min(chunk, Cn),
+        # column sums of squares in the epilogue, plus - from the second chunk of a sweep on - the cross-covariance tiles
+        # V_Z^T V of the PREVIOUS chunk (2 N M per candidate); the last chunk's cross tiles are a launch of their own
+        # (k_cross_vv).  Average over a sweep's launches:
+        n_ch = -(-Cn // chunk)
+        flops_per_launch = {"trimul": (float(N) * N + (2.0 * N * M * (n_ch - 1) / n_ch if n_ch > 1 else 0.0)) * min(chunk, Cn),
+                            "crossvv": 2.0 * N * M * min(chunk, Cn),
                             "syrk": None, "lauum": 2.0 * N ** 3 / 3.0}.get(args.profile_class)
         traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_k_%s.json" % args.profile_class)

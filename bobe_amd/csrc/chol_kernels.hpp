@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int6
 // (A fused form - panel k side by side with the rest of the update by panel k-1 in one 1024-thread launch, k_chol_step -
 // served the lone factorisation until the panel below made the separate launches as fast: 1.58 ms either way at
 // N = 4096, 0.63 vs 0.66 ms at 2048; removed.  Its update half ran at 33-36 TFLOP/s against 48 for four 256-thread
-// workgroups per CU, tools/ubench_upd.hip.)
+// workgroups per CU, profiles/r02_a_ubench_update_variants.txt.)
 // The panel as its own launch: EIGHT waves.  Wave 0 is the factor's leaf wave; wave 4 (same SIMD) does nothing while the
 // leaf runs; waves 1, 2, 3, 5, 6, 7 are the helpers of the factor (deferred tile updates, shared out by panel_tile_range),
 // and 1, 2, 3 (and 5 with four strips) each own 16 of the workgroup's 48 (64) rows below the block.  The

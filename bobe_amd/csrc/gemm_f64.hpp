@@ -135,37 +135,13 @@ __device__ __forceinline__ void acc_zero(v4d (&acc)[FM][FN]) {
 // acc += A(m0.., k) * B(n0.., k) for k in [kbeg, kend); (kend - kbeg) must be a multiple of BK
 // (K ranges are multiples of 128 for the 128x128 callers and of 64 for the 64x64 callers).
 // smem: gemm_smem_doubles<TM,TN,BK>() doubles.  All 256 threads must call.  `tid` (0..255) is the thread's index
-// inside its 256-thread tile group: threadIdx.x for the one-tile-per-workgroup kernels; tools/ubench_upd.hip runs four tile
-// groups in one 1024-thread workgroup (each with its own smem slice; the barriers inside are workgroup-wide, so
-// every group must run the same number of K-steps).
+// inside its 256-thread tile group: threadIdx.x for the one-tile-per-workgroup kernels; the filler groups of the panel
+// launch (k_chol_panel<true, .>) are two tile groups in one 512-thread workgroup, each with its own smem slice - the
+// barriers inside are workgroup-wide, so both groups must run the same number of K-steps.
 // NEGA: accumulate -A*B (the A fragment is negated on the way into the MFMA).
-// Barrier policies of gemm_tile.  WgSync: the whole workgroup computes one tile.  GroupSync: the workgroup holds
-// several independent 256-thread tile groups (tools/ubench_upd.hip); a group synchronises its four waves on a counter in
-// LDS (release-add, acquire-spin by lane 0 of each wave), so the groups drift apart like separate workgroups do and
-// one group's loads hide behind another's MFMAs.  The spin is bounded; on timeout *failed is set and the caller's
-// results are invalid (reported through the factorisation's info word).
+// SYNC: the barrier between K-steps; WgSync (a workgroup barrier) is the only policy in use.
 struct WgSync {
   __device__ __forceinline__ void sync() { __syncthreads(); }
-};
-struct GroupSync {
-  int* ctr;      // LDS, zero-initialised, one per group
-  int gen;       // barriers passed
-  int* failed;   // LDS flag
-  __device__ __forceinline__ void sync() {
-    ++gen;
-    if ((threadIdx.x & 63) == 0) {
-      __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      int spins = 0;
-      while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * gen) {
-        if (++spins > (1 << 22)) {
-          *failed = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
 };
 
 // TRIL: the A operand is LOWER TRIANGULAR in its last TM columns of K (A(m0 + r, kend - TM + c) = 0 for c > r: the

@@ -306,7 +306,7 @@ void bobe_gp::release_all() {
   if (stream) (void)hipStreamSynchronize(stream);
   DBuf* bufs[] = {&X, &y, &XsT, &XsT2, &A, &Linv, &A2, &Linv2, &Tmp, &alpha, &w, &alpha2, &w2, &part, &gpart, &res, &info,
                   &probs, &flags, &diag, &in_stage, &z_stage, &CsT, &ZsT, &kXC, &kXZ, &VZ, &WZ, &basez, &sc, &qpart, &pv,
-                  &ps, &o_mean, &o_var, &o_wipv, &o_wipstd, &o_misc, &kin_a, &kin_b, &kout, &wg_ws, &gate_sv, &gate_dual, &vxc};
+                  &ps, &o_mean, &o_var, &o_wipv, &o_wipstd, &o_misc, &kin_a, &kin_b, &kout, &wg_ws, &gate_sv, &gate_dual, &vxc, &vxc2};
   for (DBuf* b : bufs) b->release();
   for (auto& pr : prof_events) {
     (void)hipEventDestroy(pr.first);

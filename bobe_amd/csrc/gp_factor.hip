@@ -225,7 +225,7 @@ void bobe_gp::syrk(double* a, int k0, int k1, int first, int colmode, int B, int
   const int t64 = colmode == 2 ? nc64 * n64 - nc64 * (nc64 - 1) / 2 : (colmode ? 2 * n64 - 1 : n64 * (n64 + 1) / 2);
   const int t32 = colmode ? 4 * n32 - 6 : n32 * (n32 + 1) / 2;
   // 64x64 tiles with BK = 16 (36 KB of LDS, four workgroups per CU) have the best saturated throughput of all
-  // variants at every K (tools/ubench_syrk.hip); when they would leave most of the chip idle, a single-panel
+  // variants at every K (profiles/r02_a_ubench_update_variants.txt); when they would leave most of the chip idle, a single-panel
   // update takes 32x32 tiles, which stage the whole K = 128 panel in one LDS buffer
   if (kb == 1 && !colk0 && colmode != 2 && B * t64 < tu.syrk32_below) {
     hipLaunchKernelGGL((k_syrk_trail<32, SYRK32_BK>), dim3(t32, B), dim3(256), SYRK32_SMEM, stream, a, Np, k0, k1, first,

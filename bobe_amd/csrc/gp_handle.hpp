@@ -177,7 +177,7 @@ struct bobe_gp {
   // sweep / predict workspace
   DBuf wg_ws;     // workspace of bobe_gp_wip_grad's few-candidates path
   DBuf in_stage, z_stage, CsT, ZsT, kXC, kXZ, VZ, WZ, basez, sc, qpart, pv, ps, o_mean, o_var, o_wipv, o_wipstd,
-      o_misc, kin_a, kin_b, kout, vxc;
+      o_misc, kin_a, kin_b, kout, vxc, vxc2;
   std::vector<bobe::Depth> depths;
   double* h_res = nullptr;  // pinned, 128 doubles
 

@@ -127,6 +127,25 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   part.ensure((size_t)nb * (Np > CH ? Np : CH) * sizeof(double));
   if (do_wip) pv.ensure((size_t)Mp * SC * sizeof(double));                   // crossT
   if (do_wip || refine_v) vxc.ensure((size_t)Np * CH * sizeof(double));      // V = Linv K(X, chunk)
+  // The cross-covariance tiles of a chunk ride in the launch that solves the NEXT chunk (k_trimul), so V alternates
+  // between two buffers; the last chunk of a super-chunk gets a launch of its own (k_cross_vv).  The refined path keeps
+  // its three launches per chunk and a separate cross launch.
+  const bool fuse_cross = do_wip && !refine_v && C > CH;
+  if (fuse_cross) vxc2.ensure((size_t)Np * CH * sizeof(double));
+  double* vbuf[2] = {vxc.d(), fuse_cross ? vxc2.d() : vxc.d()};
+  int vsel = 0;
+  struct { bool valid; const double* V; int64_t ncp; double* cross; } pend = {false, nullptr, 0, nullptr};
+  auto cross_alone = [&](const double* Vc, int64_t ncp_, double* cross_out) {
+    // cross-covariances from the two solved factors (sweep_kernels.hpp, k_cross_vv): crossT[z][c] = VZ[:, z] . V[:, c]
+    prof_begin(BOBE_PROF_CROSSVV);
+    if ((int64_t)nzt * (ncp_ / TILE) >= 2 * std::max(num_cus, 1))
+      hipLaunchKernelGGL(k_cross_vv<128>, dim3((unsigned)(ncp_ / TILE), (unsigned)nzt), dim3(256), GEMM_SMEM_BYTES, stream,
+                         (const double*)VZ.d(), Mp, Vc, CH, Np, cross_out, SC);
+    else
+      hipLaunchKernelGGL(k_cross_vv<64>, dim3((unsigned)(ncp_ / 64), (unsigned)(Mp / 64)), dim3(256), GEMM64_SMEM_BYTES,
+                         stream, (const double*)VZ.d(), Mp, Vc, CH, Np, cross_out, SC);
+    prof_end(BOBE_PROF_CROSSVV);
+  };
   double* d_mean = out_dev(mean, C, o_mean);
   double* d_var = out_dev(var, C, o_var);
   double* d_wipv = nullptr;
@@ -163,26 +182,31 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
                            (const double*)part.d(), CH, nb, 0, nc, d_mean + s0 + c0);
       }
       if (do_wip || d_var) {       // (a mean-only prediction - nested sampling's likelihood calls - needs no triangular product)
+        double* vcur = vbuf[vsel];
         prof_begin(BOBE_PROF_TRIMUL);
-        solve_v(kXC.d(), CH, ncp, (do_wip || refine_v) ? vxc.d() : nullptr, CH, qpart.d(), CH);
-        prof_end(BOBE_PROF_TRIMUL);
-        if (do_wip) {
-          // cross-covariances from the two solved factors (sweep_kernels.hpp, k_cross_vv): crossT[z][c] = VZ[:, z] . V[:, c]
-          prof_begin(BOBE_PROF_CROSSVV);
-          if ((int64_t)nzt * (ncp / TILE) >= 2 * std::max(num_cus, 1))
-            hipLaunchKernelGGL(k_cross_vv<128>, dim3((unsigned)(ncp / TILE), (unsigned)nzt), dim3(256), GEMM_SMEM_BYTES, stream,
-                               (const double*)VZ.d(), Mp, (const double*)vxc.d(), CH, Np, pv.d() + c0, SC);
-          else
-            hipLaunchKernelGGL(k_cross_vv<64>, dim3((unsigned)(ncp / 64), (unsigned)(Mp / 64)), dim3(256), GEMM64_SMEM_BYTES,
-                               stream, (const double*)VZ.d(), Mp, (const double*)vxc.d(), CH, Np, pv.d() + c0, SC);
-          prof_end(BOBE_PROF_CROSSVV);
+        if (fuse_cross) {
+          const int ncv = (int)(ncp / TILE), ncx = pend.valid ? (int)(pend.ncp / TILE) : 0;
+          const int nz = pend.valid ? nzt : 0;
+          hipLaunchKernelGGL(k_trimul, dim3((unsigned)std::max(ncv, ncx), (unsigned)(nb + nz)), dim3(256), GEMM_SMEM_BYTES,
+                             stream, (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, vcur, CH, qpart.d(), CH,
+                             (const double*)VZ.d(), Mp, nz, pend.cross, SC, pend.V, CH, ncx, ncv);
+          pend = {true, vcur, ncp, pv.d() + c0};
+          vsel ^= 1;
+        } else {
+          solve_v(kXC.d(), CH, ncp, (do_wip || refine_v) ? vcur : nullptr, CH, qpart.d(), CH);
         }
+        prof_end(BOBE_PROF_TRIMUL);
+        if (do_wip && !fuse_cross) cross_alone(vcur, ncp, pv.d() + c0);
         // s_c for the scorer, var for the caller
         hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                            (const double*)qpart.d(), CH, nb, nc, kself, policy, sc.d() + c0,
                            d_var ? d_var + s0 + c0 : nullptr);
       }
       LAUNCH_CHECK();
+    }
+    if (pend.valid) {                 // the super-chunk's last chunk: no next launch to ride in
+      cross_alone(pend.V, pend.ncp, pend.cross);
+      pend.valid = false;
     }
     if (do_wip) {
       const dim3 grid((unsigned)((ns + 63) / 64));

@@ -6,26 +6,33 @@ namespace bobe {
 
 // ---- the sweep's one big GEMM launch ------------------------------------------------------------
 // grid.x = column (candidate) tile; grid.y enumerates row tiles, heaviest first:
-//   y <  nzt : cross tile   G[z][c]  = sum_n  WZ[n][z] B[n][c]      (full K)   -> crossT (optional, nzt may be 0)
+//   y <  nzt : cross tile   G[z][c]  = sum_n  VZ[n][z] Bx[n][c]     (full K)   -> crossT (optional, nzt may be 0)
 //   y >= nzt : V tile       V[i][c]  = sum_{k<=i} Linv[i][k] B[k][c] (lower-triangular K range), row tile
 //              ti = nb-1-(y-nzt); optional store to V, optional qpart[ti*ldq + c] = sum over the tile's rows of V^2
-// B is [Np x ncols] row-major (RC).  (The sweep launches it with nzt = 0 and V stored: its cross-covariances come from
-// k_cross_vv below, the product of two SOLVED factors, not from K^-1 K(X,Z) - see there.)
+// B is [Np x ncols] row-major (RC).  The cross tiles are k_cross_vv's product (see there: both factors are SOLVED ones,
+// VZ = L^-1 K(X,Z) and Bx = the V this kernel stored for the PREVIOUS candidate chunk): they ride in the launch that
+// solves the next chunk, where their full-K tiles fill the tails of the triangular ones, instead of a launch of their own
+// (2.62 ms per chunk of 8192 candidates at N = 4096, M = 512 against 2.17 + 0.59).  ncv / ncx: column tiles of the two
+// parts (the grid spans the larger; a chunk's last tiles may be missing in one of them).
 __global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Linv, int64_t ldi, int nb,
                                                    const double* __restrict__ B, int64_t ldb, double* __restrict__ V,
                                                    int64_t ldv, double* __restrict__ qpart, int64_t ldq,
-                                                   const double* __restrict__ WZ, int64_t ldw, int nzt,
-                                                   double* __restrict__ crossT, int64_t ldx) {
+                                                   const double* __restrict__ VZ, int64_t ldw, int nzt,
+                                                   double* __restrict__ crossT, int64_t ldx,
+                                                   const double* __restrict__ Bx = nullptr, int64_t ldbx = 0, int ncx = 0,
+                                                   int ncv = 1 << 30) {
   extern __shared__ double smem[];
   const int tc = blockIdx.x;
   v4d acc[4][4];
   acc_zero(acc);
   if ((int)blockIdx.y < nzt) {
+    if (tc >= ncx) return;
     const int tz = blockIdx.y;
-    gemm_tile<RC, RC>(acc, WZ, ldw, (int64_t)tz * TILE, B, ldb, (int64_t)tc * TILE, 0, (int64_t)nb * TILE, smem);
+    gemm_tile<RC, RC>(acc, VZ, ldw, (int64_t)tz * TILE, Bx, ldbx, (int64_t)tc * TILE, 0, (int64_t)nb * TILE, smem);
     store_tile(acc, crossT, ldx, (int64_t)tz * TILE, (int64_t)tc * TILE, 1.0, 0.0);
     return;
   }
+  if (tc >= ncv) return;
   const int ti = nb - 1 - ((int)blockIdx.y - nzt);
   // (the K range of a row tile ends with its diagonal block of the lower-triangular Linv: the zeros above the diagonal are
   // skipped, 1.2 % of the launch)
