@@ -178,6 +178,12 @@ def test_conditioning_ladder(rung):
         fant_h = gp.fantasy_var(cand, Z) / og.y_std ** 2
         H = {"mll": -f - lp_const, "grad": -np.asarray(g)[:D + 1], "mean": sw["mean"], "var": sw["var"],
              "fantasy": fant_h, "wipv": sw["wipv"], "wipstd": sw["wipstd"]}
+        # the score VALUES of the gradient entry point (acquisition.py:403-412 refines with them): the few-candidate
+        # matrix-vector path (<= 16 candidates) and the batched one must be as close to the truth as the sweep's
+        for label, idx in (("few", np.arange(3)), ("batched", np.arange(20))):
+            wv, ws, _, _ = gp.wip_grad(cand[idx], Z)
+            row["hip_wipv_grad_" + label] = _err(wv, T["wipv"][idx], np.max(np.abs(T["wipv"])))
+            row["hip_wipstd_grad_" + label] = _err(ws, T["wipstd"][idx], np.max(np.abs(T["wipstd"])))
     scales = {"mll": None, "grad": None, "mean": None, "var": kvar + NOISE, "fantasy": kvar + NOISE, "wipv": None,
               "wipstd": None}
     for q in ("fantasy", "wipv", "wipstd"):
@@ -202,6 +208,9 @@ def test_conditioning_ladder(rung):
         assert row["hip_" + q] <= 4.0 * row["lap_" + q] + TOL[q], (q, row["hip_" + q], row["lap_" + q])
     for key, name in (("wipv", "argmin_v"), ("wipstd", "argmin_s")):
         assert row["hip_" + name] or row["gap_" + name] <= 4.0 * row["lap_" + key] + TOL[key], (name, row)
+    for label in ("few", "batched"):
+        for key in ("wipv", "wipstd"):
+            assert row[f"hip_{key}_grad_{label}"] <= 4.0 * row["lap_" + key] + TOL[key], (label, key, row)
 
 
 def _write_table():
