@@ -181,9 +181,17 @@ class BOBE:
                                          "True Objective Evaluations": 0.0}
         self.n_points_since_last_fit = 0
         self.n_points_since_last_ns = 0
-        self.fit_n_points = 10                                              # (run() stores its own, bo.py:1083)
+        # run()'s settings at their defaults, so that the helper methods can be called before (or without) run()
+        self.fit_n_points, self.ns_n_points, self.batch_size = 10, 10, 4      # (run() stores its own, bo.py:1082-1084)
+        self.min_evals, self.max_evals, self.max_gp_size, self.logz_threshold = 200, 1500, 1200, 0.01
+        self.convergence_n_iters, self.ei_goal_log, self.do_final_ns = 1, float(np.log(1e-10)), False
+        self.num_hmc_warmup, self.num_hmc_samples, self.mc_points_size = 512, 512, 64
+        self.hmc_thinning, self.hmc_num_chains, self.mc_points_method, self.zeta_ei = 4, 4, "NUTS", 0.01
+        self.num_mc_samples, self.acq_threshold, self.verbose = 1024, None, False
+        self.min_delta_seen = np.inf
+        self.current_iteration = 0
         self.start_iteration = 0
-        self.acquisition = None
+        self.acquisition = _ACQ.get(str(acq).lower(), WIPV)(optimizer=optimizer)   # (run() installs its own, bo.py:1147)
         self.acquisition_history: List[float] = []
         self.gp_hyperparam_history: List[dict] = []
         self.kl_history: List[dict] = []
@@ -198,6 +206,7 @@ class BOBE:
         self.termination_reason = "Max evaluation budget reached"
         self.save_path = os.path.join(self.save_dir, self.likelihood_name)
         self._ckpt_gen = 0
+        self._current_evals = 0
         self.fresh_start, self._resume_state = True, None
         if resume and resume_file is not None:
             self._handle_resume(str(resume_file), use_clf)

@@ -20,7 +20,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 from scipy.special import expit
 
-from .utils import get_logger, get_numpy_rng
+from .utils import get_logger, get_numpy_rng, renormalise_log_weights  # noqa: F401 (re-exported)
 
 log = get_logger("sampler")
 
@@ -41,14 +41,6 @@ def compute_integrals(logl=None, logvol=None, reweight=None, squared=False):
     if reweight is not None:
         saved_logwt = saved_logwt + reweight
     return np.logaddexp.accumulate(saved_logwt)
-
-
-def renormalise_log_weights(logw):
-    """utils/core.py counterpart: exp(logw - logsumexp(logw))."""
-    logw = np.asarray(logw, dtype=np.float64)
-    m = np.max(logw)
-    w = np.exp(logw - m)
-    return w / np.sum(w)
 
 
 def resample_equal(samples, logl, weights, rng=None):

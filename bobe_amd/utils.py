@@ -32,6 +32,13 @@ def scale_from_unit(x, param_bounds):
     return x * (param_bounds[1] - param_bounds[0]) + param_bounds[0]
 
 
+def renormalise_log_weights(logw):
+    """BOBE/utils/core.py counterpart (the reference's examples import it from there): exp(logw - logsumexp(logw))."""
+    logw = np.asarray(logw, dtype=np.float64)
+    w = np.exp(logw - np.max(logw))
+    return w / np.sum(w)
+
+
 def get_threshold_for_nsigma(nsigma: float, d: int) -> float:
     """Log-probability drop from the peak of a d-dimensional Gaussian to its n-sigma contour (utils/core.py:150-167)."""
     from scipy.special import erfc
