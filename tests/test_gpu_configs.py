@@ -177,8 +177,7 @@ def test_config5_rosenbrock_10d_full_loop_to_logz_convergence():
     bounds from the GP's +-sigma within (upper - lower) / 2 < 1.0 (the threshold its docs suggest in high dimensions,
     docs/source/examples/detailed_usage.rst:158) in TWO consecutive nested-sampling runs (convergence_n_iters = 2, so that
     one lucky draw of the bounds does not end the run), with the budget this engine makes affordable (max_evals 3200,
-    max_gp_size 4096 - never reached: seeds 1-5 and 7 converge after 664 ... 1014 evaluations in 6-8 s each,
-    profiles/r04_config5.txt).  Cross-check: nested sampling of the TRUE likelihood with the same sampler."""
+    max_gp_size 4096 - never reached: the six seeds on record converge well below it, profiles/r05_config5.txt).  Cross-check: nested sampling of the TRUE likelihood with the same sampler."""
     from bobe_amd import samplers
     from bobe_amd.bo import BOBE
     D = 10
