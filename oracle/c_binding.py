@@ -79,7 +79,8 @@ _xlibs = {}
 
 def load_xp(kind: str = "xp"):
     if kind not in _xlibs:
-        path = os.path.join(_HERE, f"libbobe_oracle_{kind}.so")
+        # BOBE_ORACLE_XP_LIB selects another build of the long-double library (the sanitizer build of `make -C oracle asan`)
+        path = (kind == "xp" and os.environ.get("BOBE_ORACLE_XP_LIB")) or os.path.join(_HERE, f"libbobe_oracle_{kind}.so")
         if not os.path.exists(path):
             subprocess.run(["make", "-C", _HERE, os.path.basename(path)], check=True)
         lib = C.CDLL(path)

@@ -247,9 +247,10 @@ def test_c_restatement_under_address_sanitizer():
     if not os.path.isabs(asan):
         pytest.skip("no libasan in this toolchain")
     env = dict(os.environ, LD_PRELOAD=asan, BOBE_ORACLE_C_LIB=os.path.join(odir, "libbobe_oracle_c_asan.so"),
+               BOBE_ORACLE_XP_LIB=os.path.join(odir, "libbobe_oracle_xp_asan.so"), BOBE_XP_SKIP_QUAD="1",
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
-                        "c_restatement_agrees or c_restatement_not_positive"], env=env, capture_output=True, text=True,
+                        "c_restatement_agrees or c_restatement_not_positive or extended_precision_truth"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
@@ -373,3 +374,42 @@ def test_oracle_against_sklearn_gpr(case):
     assert np.allclose(var_or, np.maximum(var_sk, 1e-12 * og.y_std ** 2), rtol=1e-6, atol=2e-7 * (kvar + noise) * og.y_std ** 2)
     # the frozen fixture says the same
     assert np.allclose(g["pred_mean"], mu * og.y_std + og.y_mean, rtol=0, atol=1e-8 * np.max(np.abs(y)))
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern"])
+def test_extended_precision_truth_agrees_with_the_oracle(kernel):
+    """oracle/bobe_oracle_xp.c (the same quantities in x87 long double and in __float128: the reference point of
+    tests/test_gpu_conditioning.py) on a WELL-conditioned case, where fp64 is accurate too: LML, gradient, posterior mean and
+    variance, the variance at the integration points, the fantasy variance and its cross term must be the NumPy oracle's to
+    fp64 rounding, and the two extended types must agree with each other far below that; a matrix that is not positive
+    definite is reported, not factorised."""
+    import os
+    from oracle import c_binding as OC
+    rng = np.random.default_rng(5)
+    n, d = 90, 3
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X[:, 0]) + X[:, 1] ** 2 - X[:, 2]
+    ls, kvar, noise = np.array([0.4, 0.6, 0.5]), 1.3, 1e-6
+    og = O.OracleGP(X, y, noise=noise, kernel=kernel, lengthscales=ls, kernel_variance=kvar)
+    ys = np.asarray(og.train_y).reshape(-1)
+    cand, Z = rng.uniform(size=(7, d)), rng.uniform(size=(5, d))
+    kid = 0 if kernel == "rbf" else 1
+    tr = OC.gp_truth(kid, X, ys, ls, kvar, noise, cand, Z)
+    assert tr["info"] == 0 and tr["digits"] >= 64
+    mll, g = O.mll_value_and_grad(kernel, X, ys, ls, kvar, noise)
+    assert tr["mll"] == pytest.approx(mll, rel=1e-11) and np.allclose(tr["grad"], g, rtol=1e-8, atol=1e-9 * np.max(np.abs(g)))
+    assert np.allclose(tr["mean"] * og.y_std + og.y_mean, og.predict_mean_batched(cand), rtol=0, atol=1e-10)
+    assert np.allclose(tr["var"] * og.y_std ** 2, np.asarray(og.predict_var_batched(cand)).ravel(), rtol=1e-7, atol=1e-12)
+    f = np.array([og.fantasy_var(c, Z, og._k12(Z)) for c in cand])
+    assert np.allclose(tr["fantasy"] * og.y_std ** 2, f, rtol=1e-6, atol=1e-12)
+    assert np.allclose(tr["var_z"] * og.y_std ** 2, np.asarray(og.predict_var_batched(Z)).ravel(), rtol=1e-7, atol=1e-12)
+    assert np.allclose(tr["var_z"][None, :] - tr["cross"] ** 2 / tr["var"][:, None], tr["fantasy"], rtol=1e-9, atol=1e-13)
+    assert 0 < tr["min_pivot"] <= kvar + noise
+    if not os.environ.get("BOBE_XP_SKIP_QUAD"):           # (the sanitizer run has the long-double build only)
+        tq = OC.gp_truth(kid, X, ys, ls, kvar, noise, cand, Z, kind="xq")
+        assert tq["digits"] == 113 and abs(tq["mll"] - tr["mll"]) <= 1e-14 * abs(tq["mll"])
+        assert np.allclose(tq["grad"], tr["grad"], rtol=1e-12, atol=0) and np.allclose(tq["fantasy"], tr["fantasy"], rtol=1e-11)
+    Xd = X.copy()
+    Xd[1] = Xd[0]                                           # a duplicated point without noise: singular
+    bad = OC.gp_truth(kid, Xd, ys, ls, kvar, 0.0, want_grad=False)
+    assert bad["info"] > 0
