@@ -77,7 +77,7 @@ const Tuning& tuning() {
 double default_refine_kappa() {
   static const double v = [] {
     const char* e = std::getenv("BOBE_REFINE_KAPPA");
-    return e ? std::atof(e) : 1e7;
+    return e ? std::atof(e) : 1e6;
   }();
   return v;
 }

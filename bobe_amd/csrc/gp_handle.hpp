@@ -93,7 +93,7 @@ inline double pivot_floor(const Hyper& h, double ulp) {
 // min_diag: the smallest L_jj of a factor (k_mll_terms, res[101]); NaN counts as failed
 inline bool pivots_resolved(double min_diag, double floor) { return min_diag * min_diag >= floor; }
 double default_pivot_floor_ulp();                    // BOBE_PIVOT_FLOOR_ULP, else 64
-double default_refine_kappa();                       // BOBE_REFINE_KAPPA, else 1e7
+double default_refine_kappa();                       // BOBE_REFINE_KAPPA, else 1e6
 
 template <typename K>
 void allow_big_lds(K kernel, int bytes) {
@@ -156,7 +156,7 @@ struct bobe_gp {
   double pivot_floor(const Hyper& h) const { return bobe::pivot_floor(h, pivot_ulp); }
   bool have_data = false, factored = false, not_pd = false;
   // One step of iterative refinement of every V = L^-1 K(X, .) (sweep_kernels.hpp, k_trimul_resid): on when the factor's
-  // (kvar + noise) / smallest pivot exceeds refine_kappa (bobe_gp_set_refine_kappa; default BOBE_REFINE_KAPPA, else 1e7;
+  // (kvar + noise) / smallest pivot exceeds refine_kappa (bobe_gp_set_refine_kappa; default BOBE_REFINE_KAPPA, else 1e6;
   // 0: always, negative: never).  Decided when a factor is installed: the same bits on every rank.
   double refine_kappa = bobe::default_refine_kappa();
   bool refine_v = false;

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Li
 // (profiles/r05_conditioning.txt): kernel variance 4.67e4 (cond K ~3e14) WIPV 1.3e-2 off the extended-precision value,
 // 3.5e5 1.0 off; a triangular solve with the same L: 6e-5 / 2e-3; ONE refinement step V += Linv (B - L V): 6e-5 / 7e-4.
 // Two more triangular GEMMs per chunk, so the step runs only where it is needed (bobe_gp::refine_v: (kvar + noise) /
-// smallest pivot above BOBE_REFINE_KAPPA, default 1e7 - never at noise >= 1e-6 with unit kernel variance).
+// smallest pivot above BOBE_REFINE_KAPPA, default 1e6 - where the plain product's error in the scores, ~8e-14 x that ratio,
+// reaches the 1e-7 of the stated fp64 tolerance; the benchmark configurations sit at 7 ... 3e5).
 //   k_trimul_resid : B[i][c] <- B[i][c] - sum_{k<=i} L[i][k] V[k][c]     (row tile ti = nb-1-y, in place over B)
 //   k_trimul_add   : V[i][c] <- V[i][c] + sum_{k<=i} Linv[i][k] R[k][c], qpart[ti*ldq + c] = column sums of squares of
 //                    the new V over the tile's rows (k_trimul's epilogue)

@@ -423,7 +423,7 @@ class GP:
     @property
     def refine_kappa(self) -> float:
         """Threshold of the refined products with the inverse factor (include/bobe_gp.h, bobe_gp_set_refine_kappa): one
-        step of iterative refinement where (kernel_variance + noise) / smallest pivot exceeds it.  1e7 by default, 0 =
+        step of iterative refinement where (kernel_variance + noise) / smallest pivot exceeds it.  1e6 by default, 0 =
         always, negative = never; takes effect at the next factorisation."""
         k = C.c_double()
         _lib.check(self._lib.bobe_gp_get_refine(self._h, C.byref(k), None), "bobe_gp_get_refine")

@@ -172,7 +172,7 @@ double bobe_gp_get_pivot_floor_ulp(bobe_gp_t* gp);
  * installed factor's (kernel_variance + noise) / smallest pivot exceeds `kappa`: that restores the accuracy of the
  * reference's triangular solve (gp.py:462, 571) where the plain product loses it - the fantasy variance at the default noise
  * of 1e-8 from kernel variances of ~1e4 (profiles/r05_conditioning.txt) - at three times the GEMM work of those calls.
- * Default: BOBE_REFINE_KAPPA, else 1e7; 0 = always, negative = never.  The decision is taken when a factor is installed
+ * Default: BOBE_REFINE_KAPPA, else 1e6; 0 = always, negative = never.  The decision is taken when a factor is installed
  * (bobe_gp_factor, _set_chol, _append, _clone_state) - set kappa before.  get: either output may be NULL; *active = 1
  * while the current factor's products are refined. */
 int bobe_gp_set_refine_kappa(bobe_gp_t* gp, double kappa);

@@ -8,7 +8,7 @@ implementations are compared on identical inputs:
 
   (i)   the HIP path - which forms v = L^-1 k with an EXPLICIT inverse factor (k_trtri_* -> k_trimul) where the reference
         does a triangular solve (gp.py:462, 571), plus ONE step of iterative refinement with the factor where the
-        factor's (kvar + noise) / smallest pivot exceeds 1e7 (bobe_gp_set_refine_kappa) - the plain product, recorded
+        factor's (kvar + noise) / smallest pivot exceeds 1e6 (bobe_gp_set_refine_kappa) - the plain product, recorded
         beside it as 'raw', loses the fantasy variance from kernel variances of ~5e4 on (WIPV 1e-2 ... 1 off);
   (ii)  the oracle's LAPACK / TRSM form (oracle/bobe_oracle.py: dpotrf + dtrsm, what jax.scipy lowers to on CPU);
   (iii) an extended-precision truth (oracle/bobe_oracle_xp.c: x87 long double, 64-bit significand, cross-checked against
@@ -163,7 +163,7 @@ def test_conditioning_ladder(rung):
         assert not gp.refining
         sw_raw = gp.wip_sweep(cand, Z, want_mean_var=True)
         raw = {"wipv": sw_raw["wipv"], "wipstd": sw_raw["wipstd"], "fantasy": gp.fantasy_var(cand, Z) / og.y_std ** 2}
-    gp.refine_kappa = 1e7                                      # the default
+    gp.refine_kappa = 1e6                                      # the default
     gp.recompute_cholesky()
     hip_ok = not gp.not_pd
     row = {"rung": rung, "N": n, "kernel": kernel, "kvar": kvar, "ls0": float(ls[0]), "kappa": kappa,
@@ -227,7 +227,7 @@ def _write_table():
              "# mll / grad / mean / wipv / wipstd: max |delta| / max |truth|;  var / fantasy: max |delta| / (kvar + noise)",
              "# kappa = N kvar / smallest pivot (a lower bound of cond K);  rank64 = the default rank test (64 ulp) refuses the "
              "rung;  argmin columns: picks the truth's candidate (gap = relative score excess of the pick)",
-             "# refine = the HIP path took the refinement step v += Linv (k - L v) (default threshold 1e7); raw_* = the same "
+             "# refine = the HIP path took the refinement step v += Linv (k - L v) (default threshold 1e6); raw_* = the same "
              "quantity WITHOUT it (bobe_gp_set_refine_kappa(-1))", ""]
     hdr = f"{'rung':<28}{'kappa':>9}{'minpiv':>9} {'lapack':>6} {'rank64':>6} {'refine':>6} " + " ".join(f"{'hip_' + q:>11}{'lap_' + q:>11}" for q in qs) \
         + f" {'raw_fantasy':>11} {'raw_wipv':>9} {'raw_wipstd':>10} {'argv h/l':>9} {'args h/l':>9} {'gap_v':>8} {'gap_s':>8}"

@@ -27,7 +27,10 @@ def test_forced_refinement_changes_nothing_beyond_rounding(n, d, kernel):
     rng, X, y = _problem(n, d, n)
     ls = np.full(d, 0.45)
     plain = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.4)
-    assert plain.refine_kappa == 1e7 and not plain.refining            # (kvar + noise) / smallest pivot is ~1e6 here
+    assert plain.refine_kappa == 1e6                                    # the default
+    plain.refine_kappa = -1.0                                           # never: the plain product with the inverse factor
+    plain.recompute_cholesky()
+    assert not plain.refining
     forced = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.4)
     forced.refine_kappa = 0.0
     forced.recompute_cholesky()
@@ -86,7 +89,7 @@ def test_refinement_through_update_append_and_copy():
 
 
 def test_default_threshold_switches_on_where_the_factor_is_ill_conditioned():
-    """noise 1e-8 with a long length scale: (kvar + noise) / smallest pivot passes 1e7 and the step is on by itself; at
+    """noise 1e-8 with a long length scale: (kvar + noise) / smallest pivot passes 1e6 and the step is on by itself; at
     noise 1e-6 with unit kernel variance (the headline configuration) it never is."""
     from bobe_amd import GP
     _, X, y = _problem(400, 2, 4)
