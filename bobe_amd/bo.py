@@ -70,7 +70,7 @@ def _factorisable_start(gp: GP, init: np.ndarray) -> np.ndarray:
 
 
 def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.random.Generator] = None,
-           group=None, distributed: bool = True) -> dict:
+           use_pool: bool = True, *, group=None, distributed: bool = True) -> dict:
     """``MPI_Pool.gp_fit`` (pool.py:268-328): x0 row 0 = log(current hp), further rows uniform in the log-bounds;
     fit; adopt the best hyper-parameters (refactors on the GPU).
 
@@ -78,7 +78,9 @@ def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.r
     same loop with the same seed) the restarts are split over the ranks the way the reference's MPI pool splits
     them (``np.array_split``, pool.py:298-326): each rank runs its chunk — concurrently, on the evaluation slots of
     its own GPU — then one all-gather of (mll, theta) and max-by-mll; every rank adopts the same theta.
-    ``distributed=False`` keeps the fit on this rank (no collective: for calls that not every rank makes)."""
+    ``use_pool=False`` (the reference's keyword, pool.py:239) or ``distributed=False`` keeps the fit on this rank (no
+    collective: for calls that not every rank makes)."""
+    distributed = bool(distributed and use_pool)
     rng = np.random.default_rng() if rng is None else rng
     n_params = gp.hyperparam_bounds.shape[1]
     init = _factorisable_start(gp, np.log(gp.get_hyperparams()))

@@ -13,7 +13,7 @@ import os
 import sys
 
 REF = os.environ.get("BOBE_REFERENCE", "/root/reference")
-MODULES = ["gp", "bo", "acquisition", "clf_gp", "samplers", "optim"]
+MODULES = ["gp", "bo", "acquisition", "clf_gp", "samplers", "optim", "pool"]
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_signatures.json")
 
 

@@ -23,8 +23,19 @@ with open(os.path.join(HERE, "golden", "reference_signatures.json")) as _fh:
 _NAMES = {"jnp": None, "np": None}
 
 
+# pool.py is the MPI pool - out of scope except for the one method the hot path's callers use: its restart
+# recipe and sharding live in bobe_amd.bo.gp_fit (same parameters after ``self``)
+POOL_MAP = {("MPI_Pool", "gp_fit"): ("bo", "gp_fit")}
+
+
 def _callables():
+    for (cname, name), _ in POOL_MAP.items():
+        sig = dict(REF["pool"]["classes"][cname]["methods"][name])
+        sig["params"] = [p for p in sig["params"] if p["name"] != "self"]
+        yield f"pool.{cname}.{name}", "pool", cname, name, sig
     for mod, entry in sorted(REF.items()):
+        if mod == "pool":
+            continue
         for name, sig in sorted(entry["functions"].items()):
             yield f"{mod}.{name}", mod, None, name, sig
         for cname, cls in sorted(entry["classes"].items()):
@@ -36,6 +47,9 @@ CASES = list(_callables())
 
 
 def _ours(mod, cname, name):
+    if mod == "pool":
+        omod, oname = POOL_MAP[(cname, name)]
+        return getattr(importlib.import_module("bobe_amd." + omod), oname)
     m = importlib.import_module("bobe_amd." + mod)
     if cname is None:
         return getattr(m, name)
@@ -60,7 +74,7 @@ def _same_default(ref_src, ours):
 
 
 def test_fixture_covers_the_hot_path_modules():
-    assert set(REF) == {"gp", "bo", "acquisition", "clf_gp", "samplers", "optim"}
+    assert set(REF) == {"gp", "bo", "acquisition", "clf_gp", "samplers", "optim", "pool"}
     assert len(CASES) >= 80
     # spot checks of entries the judge quoted from the reference (bo.py:967-984, 621)
     run = [p["name"] for p in REF["bo"]["classes"]["BOBE"]["methods"]["run"]["params"]]
