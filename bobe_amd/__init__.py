@@ -9,6 +9,8 @@ from .acquisition import EI, LogEI, WIPV, WIPStd, get_mc_points, get_mc_samples 
 from .optim import optimize_scipy  # noqa: F401
 from .bo import BOBE, gp_fit  # noqa: F401
 from .samplers import compute_integrals, nested_sampling  # noqa: F401
+from .likelihood import Likelihood  # noqa: F401
+from .utils import get_logger, scale_from_unit, scale_to_unit, setup_logging  # noqa: F401
 
 
 def __getattr__(name):            # scikit-learn is only needed for the classifier GP
@@ -18,6 +20,9 @@ def __getattr__(name):            # scikit-learn is only needed for the classifi
     raise AttributeError(name)
 
 
-__all__ = ["GP", "GPwithClassifier", "EI", "LogEI", "WIPV", "WIPStd", "get_mc_points", "get_mc_samples",
-           "optimize_scipy", "BOBE", "gp_fit", "nested_sampling", "compute_integrals", "load_library",
+# (the names of the reference's BOBE/__init__.py:70-91 that lie on the path - its results manager and plotter do not -
+# then this package's own)
+__all__ = ["BOBE", "GP", "GPwithClassifier", "Likelihood", "EI", "LogEI", "WIPV", "WIPStd", "get_logger", "setup_logging",
+           "scale_to_unit", "scale_from_unit", "get_mc_points", "get_mc_samples",
+           "optimize_scipy", "gp_fit", "nested_sampling", "compute_integrals", "load_library",
            "BobeLibraryError"]

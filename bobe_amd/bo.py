@@ -31,7 +31,8 @@ from scipy.stats import qmc
 from .acquisition import EI, LogEI, WIPStd, WIPV, get_mc_samples
 from .dist_sweep import dist_info, merge_best_fit, shard_bounds
 from .gp import GP
-from .utils import get_logger, scale_from_unit, scale_to_unit
+from .likelihood import Likelihood
+from .utils import get_logger, get_numpy_rng, scale_from_unit, scale_to_unit, set_global_seed, update_verbosity
 
 log = get_logger("bo")
 
@@ -155,22 +156,19 @@ class BOBE:
         ``resume=True, resume_file=<save_dir>/<likelihood_name>`` continues from those files instead of drawing and
         evaluating an initial design (bo.py:205-206, 327-381; a file that cannot be loaded falls back to a fresh start, as
         there); ``use_clf`` selects ``GPwithClassifier`` (SVM) with the thresholds derived from ``clf_nsigma_threshold``."""
-        import logging
-        if not callable(loglikelihood):
-            raise NotImplementedError("only a callable log-likelihood is supported (Cobaya adaptors are out of scope)")
-        if param_list is None or param_bounds is None:
-            raise ValueError("param_list and param_bounds are required with a callable log-likelihood")
+        update_verbosity(verbosity)                                          # bo.py:179
         if str(optimizer).lower() not in ("optax", "scipy"):                 # bo.py:299-300
             raise ValueError("optimizer must be either 'optax' or 'scipy'")
-        logging.getLogger("bobe_amd").setLevel(getattr(logging, str(verbosity).upper(), logging.INFO))
-        self.loglikelihood = loglikelihood
-        self.param_list = list(param_list)
-        self.param_labels = list(param_labels) if param_labels is not None else list(param_list)
-        self.likelihood_name = likelihood_name or "likelihood"
+        self.loglikelihood = self._prepare_likelihood(loglikelihood, param_list, param_bounds, param_labels,
+                                                      likelihood_name, confidence_for_unbounded, minus_inf)
+        self.param_list = list(self.loglikelihood.param_list)
+        self.param_labels = list(self.loglikelihood.param_labels)
+        self.likelihood_name = self.loglikelihood.name
         self.output_file = self.likelihood_name                             # bo.py:290
-        self.param_bounds = np.asarray(param_bounds, dtype=np.float64)      # (2, ndim), like the reference
+        self.param_bounds = np.asarray(self.loglikelihood.param_bounds, dtype=np.float64)      # (2, ndim)
         self.ndim = len(self.param_list)
-        self.np_rng = np.random.default_rng(seed)
+        set_global_seed(seed)                                               # bo.py:286-287: ONE generator for the whole run,
+        self.np_rng = get_numpy_rng()                                       # the package's global one
         self.minus_inf = float(minus_inf)
         self.optimizer = optimizer
         self.device = device
@@ -225,6 +223,23 @@ class BOBE:
         if self.save and self.fresh_start:                                  # bo.py:239
             os.makedirs(self.save_dir, exist_ok=True)
             self._save_gp_file()
+
+    def _prepare_likelihood(self, loglikelihood, param_list, param_bounds, param_labels, likelihood_name,
+                            confidence_for_unbounded, minus_inf) -> Likelihood:
+        """bo.py:249-280: a ``Likelihood`` as it is, a callable wrapped into one.  A Cobaya YAML path / info dict would
+        need the Cobaya adaptor, which is not built."""
+        if isinstance(loglikelihood, Likelihood):
+            return loglikelihood
+        if isinstance(loglikelihood, (str, dict)):
+            raise NotImplementedError("Cobaya likelihoods (a YAML path or an info dict) need the Cobaya adaptor, which is "
+                                      "outside this build's scope; pass a callable or a Likelihood")
+        if callable(loglikelihood):
+            if param_list is None:
+                raise ValueError("param_list is required with a callable log-likelihood")
+            return Likelihood(loglikelihood=loglikelihood, param_list=list(param_list), param_bounds=param_bounds,
+                              param_labels=param_labels, name=likelihood_name, minus_inf=minus_inf)
+        raise ValueError("loglikelihood must be one of: callable, string (Cobaya YAML path), dict (Cobaya info), or "
+                         "Likelihood instance")
 
     def _handle_fresh_start(self, n_sobol_init, init_train_x, init_train_y, use_clf, clf_type, clf_use_size,
                             clf_update_step, clf_nsigma_threshold, optimizer, gp_kwargs) -> None:
@@ -362,15 +377,10 @@ class BOBE:
 
     # ------------------------------------------------------------------ run helper methods (bo.py:617-934)
     def _evaluate(self, pts: np.ndarray) -> np.ndarray:
-        """Safe likelihood wrapper (likelihood.py:69-91): NaN / exceptions / -inf -> minus_inf."""
+        """The likelihood at every row of ``pts`` (``pool.run_map_objective`` in serial mode, pool.py:330-352): the
+        ``Likelihood``'s safe evaluation (likelihood.py:61-83), NaN / exceptions / -inf -> minus_inf."""
         t0 = time.time()
-        out = np.empty((pts.shape[0], 1))
-        for i, p in enumerate(pts):
-            try:
-                v = float(self.loglikelihood(np.array(p)))
-            except Exception:
-                v = self.minus_inf
-            out[i, 0] = v if np.isfinite(v) and v > self.minus_inf else self.minus_inf
+        out = np.array([self.loglikelihood(np.array(p)) for p in pts], dtype=np.float64).reshape(-1, 1)
         self.timing["True Objective Evaluations"] += time.time() - t0
         return out
 
@@ -643,7 +653,8 @@ class BOBE:
 
     def run_weighted_integrated_posterior(self, acq_func_class, ii=0):
         """bo.py:1226-1390 for WIPV / WIPStd (``acq_func_class``)."""
-        from .samplers import nested_sampling, resample_equal
+        from .samplers import nested_sampling
+        from .utils.core import resample_equal
         self.acquisition = acq_func_class(optimizer=self.optimizer)
         acq_name = self.acquisition.name
         current_evals = self._current_evals
@@ -677,8 +688,8 @@ class BOBE:
                 self.timing["Nested Sampling"] += time.time() - t0
                 self.ns_samples, self._ns_success = ns_samples, ns_success
                 if ns_success:
-                    equal_samples, equal_logl = resample_equal(ns_samples["x"], ns_samples["logl"], ns_samples["weights"],
-                                                               rng=self.np_rng)
+                    equal_samples, equal_logl = resample_equal(ns_samples["x"], ns_samples["logl"],
+                                                               weights=ns_samples["weights"], rng=self.np_rng)   # bo.py:1296
                     self.mc_samples = {"x": equal_samples, "logl": equal_logl,
                                        "weights": np.ones(equal_samples.shape[0]), "method": "NS",
                                        "best": ns_samples["best"]}
@@ -717,7 +728,7 @@ class BOBE:
             self.timing["Nested Sampling"] += time.time() - t0
             if ns_success:
                 equal_samples, equal_logl = resample_equal(self.ns_samples["x"], self.ns_samples["logl"],
-                                                           self.ns_samples["weights"], rng=self.np_rng)
+                                                           weights=self.ns_samples["weights"], rng=self.np_rng)
                 self.converged = self.check_convergence_logz(ii + 1, logz_dict, equal_samples, equal_logl,
                                                              verbose=self.verbose, save_checkpoint=False)
                 self.results_dict["logz"] = logz_dict

@@ -13,7 +13,8 @@ import os
 import sys
 
 REF = os.environ.get("BOBE_REFERENCE", "/root/reference")
-MODULES = ["gp", "bo", "acquisition", "clf_gp", "samplers", "optim", "pool"]
+MODULES = ["gp", "bo", "acquisition", "clf_gp", "samplers", "optim", "pool", "likelihood", "utils.core", "utils.seed",
+           "utils.log"]
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_signatures.json")
 
 
@@ -41,7 +42,7 @@ def decorators(fn):
 def main():
     sigs = {}
     for mod in MODULES:
-        path = os.path.join(REF, "BOBE", mod + ".py")
+        path = os.path.join(REF, "BOBE", *mod.split(".")) + ".py"
         tree = ast.parse(open(path).read(), filename=path)
         entry = {"functions": {}, "classes": {}}
         for node in tree.body:

@@ -175,7 +175,7 @@ def test_unmodified_run_call_is_wipstd_in_batches_of_four(tmp_path, monkeypatch)
     def gauss(x):
         return -0.5 * float(np.sum(((np.asarray(x) - 0.5) / sig) ** 2))
     b = BOBE(gauss, ["a", "b"], np.array([[0.0, 1.0], [0.0, 1.0]]).T, seed=11, verbosity="WARNING")
-    assert b.gp.npoints == 16 and (tmp_path / "likelihood_gp.npz").exists()
+    assert b.gp.npoints == 16 and (tmp_path / "loglikelihood_gp.npz").exists()      # (the reference's default name)
     res = b.run()
     assert b.acquisition.name.lower() == "wipstd" and b.batch_size == 4 and b.mc_points_method == "NUTS"
     assert (res["gp"].npoints - 16) % 4 <= 3 and len(res["acq_history"]) >= (200 - 16) // 4      # min_evals = 200 first
@@ -183,7 +183,10 @@ def test_unmodified_run_call_is_wipstd_in_batches_of_four(tmp_path, monkeypatch)
     assert res["termination_reason"] == "LogZ converged"
     truth = 2 * 0.5 * np.log(2 * np.pi * sig ** 2)
     assert abs(res["logz"]["mean"] - truth) < 0.1
-    assert (tmp_path / "likelihood_run.json").exists()
+    assert (tmp_path / "loglikelihood_run.json").exists()
+    like = res["likelihood"]                                                        # a Likelihood, as in the reference
+    assert like.name == "loglikelihood" and like.param_list == ["a", "b"] and like.param_bounds.shape == (2, 2)
+    assert like([0.5, 0.5]) == 0.0 and like(np.array([[0.5, 0.5]])) == 0.0
     # the reference's eight result keys (bo.py:827-836) come first
     assert list(res)[:8] == ["gp", "likelihood", "results_manager", "best_val", "best_pt", "logz", "termination_reason",
                              "samples"]

@@ -28,6 +28,17 @@ _NAMES = {"jnp": None, "np": None}
 POOL_MAP = {("MPI_Pool", "gp_fit"): ("bo", "gp_fit")}
 
 
+# names of the parsed modules that have no counterpart, with the reason (everything else must exist)
+OUT_OF_SCOPE = {
+    ("likelihood", "CobayaLikelihood"): "adaptor to the Cobaya framework (SURVEY section 2: out of scope)",
+    ("utils.core", "split_vmap"): "chunked jax.vmap helper: the library batches on the device instead",
+    ("utils.seed", "get_jax_key"): "JAX PRNG keys: there is no JAX here, the device samplers take integer seeds",
+    ("utils.seed", "split_jax_key"): "JAX PRNG keys",
+    ("utils.seed", "get_new_jax_key"): "JAX PRNG keys",
+    ("utils.log", "LevelFilter"): "implementation detail of the reference's handlers (a lambda filter here)",
+}
+
+
 def _callables():
     for (cname, name), _ in POOL_MAP.items():
         sig = dict(REF["pool"]["classes"][cname]["methods"][name])
@@ -37,8 +48,11 @@ def _callables():
         if mod == "pool":
             continue
         for name, sig in sorted(entry["functions"].items()):
-            yield f"{mod}.{name}", mod, None, name, sig
+            if (mod, name) not in OUT_OF_SCOPE:
+                yield f"{mod}.{name}", mod, None, name, sig
         for cname, cls in sorted(entry["classes"].items()):
+            if (mod, cname) in OUT_OF_SCOPE:
+                continue
             for name, sig in sorted(cls["methods"].items()):
                 yield f"{mod}.{cname}.{name}", mod, cname, name, sig
 
@@ -74,7 +88,11 @@ def _same_default(ref_src, ours):
 
 
 def test_fixture_covers_the_hot_path_modules():
-    assert set(REF) == {"gp", "bo", "acquisition", "clf_gp", "samplers", "optim", "pool"}
+    assert set(REF) == {"gp", "bo", "acquisition", "clf_gp", "samplers", "optim", "pool", "likelihood", "utils.core",
+                        "utils.seed", "utils.log"}
+    for (mod, name), why in OUT_OF_SCOPE.items():                 # every exclusion names something the reference has
+        assert name in REF[mod]["functions"] or name in REF[mod]["classes"], (mod, name)
+        assert why
     assert len(CASES) >= 80
     # spot checks of entries the judge quoted from the reference (bo.py:967-984, 621)
     run = [p["name"] for p in REF["bo"]["classes"]["BOBE"]["methods"]["run"]["params"]]
