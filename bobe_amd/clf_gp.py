@@ -17,81 +17,12 @@ from typing import Callable, Optional
 
 import numpy as np
 
+from .clf import (CLASSIFIER_REGISTRY, _DeviceSVM, gate_eval, get_svm_predict_proba_fn, install_gate,  # noqa: F401
+                  train_svm_classifier)
 from .gp import GP, safe_noise_floor
 from .utils import get_logger, get_numpy_rng
 
 log = get_logger("clf_gp")
-
-
-def train_svm_classifier(X, Y, settings=None):
-    """clf.py:36-69: SVC(kernel='rbf', gamma='scale', C=1e7); returns (params, metrics, None) - the prediction
-    function of the reference's triple is the library's gate here (``GPwithClassifier._sync_gate``,
-    ``get_svm_predict_proba_fn``)."""
-    from sklearn.svm import SVC
-    settings = settings or {}
-    C = settings.get("C", 1e7)
-    clf = SVC(kernel=settings.get("kernel", "rbf"), gamma=settings.get("gamma", "scale"), C=C)
-    clf.fit(np.asarray(X), np.asarray(Y))
-    params = {"support_vectors": np.array(clf.support_vectors_), "dual_coef": np.array(clf.dual_coef_[0]),
-              "intercept": float(clf.intercept_[0]), "gamma_eff": float(clf._gamma)}
-    metrics = {"n_support_vectors": len(params["support_vectors"]), "gamma": f"{params['gamma_eff']:.2e}",
-               "C": f"{C:.2e}", "intercept": f"{params['intercept']:.2e}"}
-    return params, metrics, None
-
-
-def get_svm_predict_proba_fn(params, device: int = 0) -> Callable[[np.ndarray], np.ndarray]:
-    """clf.py:71-78: the probability function of stored SVM parameters (``svm_predict_proba``, clf.py:210-213) — evaluated
-    by the library (``bobe_gp_gate_eval`` on a data-less handle that carries only the gate)."""
-    return _DeviceSVM(params, device).proba
-
-
-class _DeviceSVM:
-    """A library handle holding nothing but a classifier gate: decision values / probabilities of stored parameters."""
-
-    def __init__(self, params, device: int = 0):
-        import ctypes as C
-        from . import _lib
-        self._lib = _lib.load()
-        self._ndim = int(np.asarray(params["support_vectors"]).shape[1])
-        self._h = C.c_void_p(0)
-        _lib.check(self._lib.bobe_gp_create(C.byref(self._h), int(device), 0, self._ndim), "bobe_gp_create")
-        install_gate(self._lib, self._h, params, 0.5, 0.0)
-
-    def __del__(self):
-        try:
-            if self._h.value:
-                self._lib.bobe_gp_destroy(self._h)
-        except Exception:
-            pass
-
-    def decision(self, x):
-        return gate_eval(self._lib, self._h, x, self._ndim)[0]
-
-    def proba(self, x):
-        return gate_eval(self._lib, self._h, x, self._ndim)[1]
-
-
-def install_gate(lib, handle, params, probability_threshold: float, minus_inf: float) -> None:
-    """Hand the trained SVM to the library (``bobe_gp_set_gate``); ``params=None`` clears the gate."""
-    from . import _lib
-    if params is None:
-        _lib.check(lib.bobe_gp_set_gate(handle, None, 0, None, 0.0, 0.0, float(probability_threshold), float(minus_inf)),
-                   "bobe_gp_set_gate")
-        return
-    sv = _lib.as_f64(np.atleast_2d(np.asarray(params["support_vectors"])))
-    dual = _lib.as_f64(np.asarray(params["dual_coef"])).reshape(-1)
-    _lib.check(lib.bobe_gp_set_gate(handle, _lib.ptr(sv), sv.shape[0], _lib.ptr(dual), float(params["intercept"]),
-                                    float(params["gamma_eff"]), float(probability_threshold), float(minus_inf)),
-               "bobe_gp_set_gate")
-
-
-def gate_eval(lib, handle, x, ndim: int):
-    """(decision, feasible) of the points ``x`` from the gate held by ``handle`` (``bobe_gp_gate_eval``)."""
-    from . import _lib
-    x = _lib.as_f64(np.atleast_2d(np.asarray(x, dtype=np.float64)).reshape(-1, ndim))
-    dec, ok = np.empty(x.shape[0]), np.empty(x.shape[0])
-    _lib.check(lib.bobe_gp_gate_eval(handle, _lib.ptr(x), x.shape[0], _lib.ptr(dec), _lib.ptr(ok)), "bobe_gp_gate_eval")
-    return dec, ok
 
 
 class GPwithClassifier(GP):

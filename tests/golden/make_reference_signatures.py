@@ -13,8 +13,8 @@ import os
 import sys
 
 REF = os.environ.get("BOBE_REFERENCE", "/root/reference")
-MODULES = ["gp", "bo", "acquisition", "clf_gp", "samplers", "optim", "pool", "likelihood", "utils.core", "utils.seed",
-           "utils.log"]
+MODULES = ["gp", "bo", "acquisition", "clf_gp", "clf", "samplers", "optim", "pool", "likelihood", "utils.core",
+           "utils.seed", "utils.log"]
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_signatures.json")
 
 

@@ -256,3 +256,33 @@ def test_gate_entry_points_through_the_c_abi():
     # NULL clears
     assert lib.bobe_gp_set_gate(h, None, 0, None, 0.0, 0.0, 0.5, -1e5) == 0
     assert np.all(np.isfinite(gp.predict_batched(q)[0]))
+
+
+def test_clf_module_functions_of_the_reference():
+    """bobe_amd.clf mirrors the SVM half of BOBE/clf.py: ``train_svm_classifier`` returns the reference's triple (params,
+    metrics, predict_proba_fn), ``svm_predict`` / ``svm_predict_proba`` (clf.py:188-213) evaluate the decision function on
+    the device - against scikit-learn's own decision_function and the oracle's line-for-line restatement."""
+    from sklearn.svm import SVC
+    from bobe_amd import clf
+    from oracle import bobe_oracle_loop as OL
+    rng = np.random.default_rng(2)
+    X = rng.uniform(size=(200, 3))
+    Y = (np.sum((X - 0.5) ** 2, axis=1) < 0.2).astype(int)
+    params, metrics, proba_fn = clf.train_svm_classifier(X, Y, settings={})
+    assert set(params) >= {"support_vectors", "dual_coef", "intercept", "gamma_eff"} and metrics["n_support_vectors"] > 0
+    assert set(clf.CLASSIFIER_REGISTRY) == {"svm"} and clf.CLASSIFIER_REGISTRY["svm"]["train_fn"] is clf.train_svm_classifier
+    q = rng.uniform(size=(64, 3))
+    sk = SVC(kernel="rbf", gamma="scale", C=1e7).fit(X, Y)
+    dec = clf.svm_predict(q, params["support_vectors"], params["dual_coef"], params["intercept"], params["gamma_eff"])
+    ref = sk.decision_function(q)
+    mag = np.array([np.sum(np.abs(params["dual_coef"]) * np.exp(-params["gamma_eff"] * np.sum((params["support_vectors"] - p) ** 2, 1)))
+                    for p in q])
+    assert np.all(np.abs(dec - ref) <= 1e-9 * np.abs(ref) + 1e-13 * mag)
+    one = clf.svm_predict(q[0], params["support_vectors"], params["dual_coef"], params["intercept"], params["gamma_eff"])
+    assert isinstance(one, float) and one == dec[0]
+    want = OL.svm_predict(q[0], params["support_vectors"], params["dual_coef"], params["intercept"], params["gamma_eff"])
+    assert abs(one - want) <= 1e-9 * abs(want) + 1e-13 * mag[0]
+    pr = clf.svm_predict_proba(q, params["support_vectors"], params["dual_coef"], params["intercept"], params["gamma_eff"])
+    clear = np.abs(ref) > 1e-9 * mag                                  # (not within rounding of the boundary)
+    assert np.array_equal(pr[clear], (ref[clear] >= 0).astype(float))
+    assert np.array_equal(proba_fn(q), pr) and np.array_equal(clf.get_svm_predict_proba_fn(params)(q), pr)
