@@ -32,7 +32,8 @@ from .acquisition import EI, LogEI, WIPStd, WIPV, get_mc_samples
 from .dist_sweep import dist_info, merge_best_fit, shard_bounds
 from .gp import GP
 from .likelihood import Likelihood
-from .utils import get_logger, get_numpy_rng, scale_from_unit, scale_to_unit, set_global_seed, update_verbosity
+from .utils import (get_logger, get_numpy_rng, scale_from_unit, scale_to_unit, set_global_seed, setup_logging,
+                    update_verbosity)
 
 log = get_logger("bo")
 
@@ -156,7 +157,11 @@ class BOBE:
         ``resume=True, resume_file=<save_dir>/<likelihood_name>`` continues from those files instead of drawing and
         evaluating an initial design (bo.py:205-206, 327-381; a file that cannot be loaded falls back to a fresh start, as
         there); ``use_clf`` selects ``GPwithClassifier`` (SVM) with the thresholds derived from ``clf_nsigma_threshold``."""
-        update_verbosity(verbosity)                                          # bo.py:179
+        import logging
+        if not logging.getLogger("bobe_amd").handlers and not logging.getLogger().handlers:
+            setup_logging(verbosity)              # (the reference installs its handlers when the package is imported,
+        else:                                     # BOBE/__init__.py:37-39; here: on first use, unless the host program has
+            update_verbosity(verbosity)           # configured logging itself)                                    bo.py:179
         if str(optimizer).lower() not in ("optax", "scipy"):                 # bo.py:299-300
             raise ValueError("optimizer must be either 'optax' or 'scipy'")
         self.loglikelihood = self._prepare_likelihood(loglikelihood, param_list, param_bounds, param_labels,
