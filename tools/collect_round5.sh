@@ -10,6 +10,20 @@ out=gpurun_out/r05_$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p $out
 head=$(cat .git_head 2>/dev/null || echo "round 5")
 cmd="python3 bench.py --steps 2 --warmup 1 --no-secondary"
+if [ "$2" = "c5" ]; then
+  # usage: bash tools/collect_round5.sh <tag> c5  -> the config-5 runs of profiles/r05_config5.txt (six seeds, the gated run,
+  # thresholds 0.2 / 0.02, the 16-D run to the size cap) and the sampler kernels' time per step
+  o=$out/config5_runs.txt
+  python3 tools/config5_run.py steptime=1 > $out/sampler_step_times.txt 2>&1 || exit 1
+  : > $o
+  for s in 7 1 2 3 4 5; do python3 tools/config5_run.py seed=$s 2>&1 | tail -1 >> $o; done
+  python3 tools/config5_run.py seed=7 clf=1 2>&1 | tail -1 >> $o
+  python3 tools/config5_run.py seed=7 thr=0.2 ns_every=100 2>&1 | tail -1 >> $o
+  python3 tools/config5_run.py seed=7 thr=0.02 ns_every=200 max_evals=4200 2>&1 | tail -1 >> $o
+  python3 tools/config5_run.py dim=16 thr=0.5 max_evals=4400 max_gp=4096 ns_every=100 min_evals=800 seed=7 2>&1 | grep -v "^ " | cut -c1-420 >> $o
+  cut -c1-330 $o
+  exit 0
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cycle -- python3 bench.py --steps 5 --warmup 2 --no-secondary > $out/bench_cycle.json 2> $out/bench_cycle.err || exit 1
 cp "$(ls $out/prof_cycle/*/*kernel_stats.csv | head -1)" $out/cycle_kernel_stats.csv
 echo "kernel stats (headline) done" 
