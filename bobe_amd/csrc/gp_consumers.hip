@@ -283,7 +283,7 @@ void bobe_gp::clone_from(bobe_gp& src) {
     alloc_for_n();
   }
   const size_t mat = (size_t)src.Np * src.Np * sizeof(double), vec = (size_t)src.Np * sizeof(double);
-  X.ensure((size_t)src.N * src.d * sizeof(double));
+  X.ensure((size_t)(src.Np + TILE) * src.d * sizeof(double));
   HIPCHK(hipMemcpyAsync(X.p, src.X.p, (size_t)src.N * src.d * sizeof(double), hipMemcpyDeviceToDevice, stream));
   HIPCHK(hipMemcpyAsync(y.p, src.y.p, vec, hipMemcpyDeviceToDevice, stream));
   if (src.factored) {

@@ -826,7 +826,7 @@ void bobe_gp::set_data(const double* Xin, const double* ys, int64_t n) {
     nb = (int)(Np / TILE);
     alloc_for_n();
   }
-  X.ensure((size_t)N * d * sizeof(double));
+  X.ensure((size_t)(Np + TILE) * d * sizeof(double));     // (room for bobe_gp_append's rows up to the next block and one more)
   HIPCHK(hipMemcpyAsync(X.p, Xin, (size_t)N * d * sizeof(double),
                         is_device_ptr(Xin) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(y.p, 0, (size_t)Np * sizeof(double), stream));

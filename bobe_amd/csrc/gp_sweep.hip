@@ -496,14 +496,20 @@ int bobe_gp::append(const double* X_new, int64_t b, const double* y_all) {
   DBuf nx, oa, ol;
   try {
   // ---- training data: X gains b rows, every y changes (the caller re-standardised them, gp.py:520-536)
+  const bool xnew_on_device = is_device_ptr(X_new);
   {
-    nx.ensure((size_t)N1 * d * sizeof(double));
-    HIPCHK(hipMemcpyAsync(nx.p, X.p, (size_t)N0 * d * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    HIPCHK(hipMemcpyAsync(static_cast<double*>(nx.p) + N0 * d, X_new, (size_t)b * d * sizeof(double),
-                          is_device_ptr(X_new) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
-    sync();
-    std::swap(X, nx);
-    nx.release();
+    // (X keeps room for the rows up to the next multiple of 128 and one block more: a hipMalloc / hipFree pair per call
+    // was a third of an append at N = 600; the new rows land behind the old ones, in stream order)
+    const size_t need = (size_t)N1 * d * sizeof(double);
+    if (X.bytes < need) {
+      nx.ensure((size_t)(Np1 + TILE) * d * sizeof(double));
+      HIPCHK(hipMemcpyAsync(nx.p, X.p, (size_t)N0 * d * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      sync();
+      std::swap(X, nx);
+      nx.release();
+    }
+    HIPCHK(hipMemcpyAsync(X.d() + N0 * d, X_new, (size_t)b * d * sizeof(double),
+                          xnew_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
   }
   // ---- a larger padded size: move L and Linv into the new [[., 0], [0, I]] frame
   if (Np1 != Np0) {
@@ -549,7 +555,8 @@ int bobe_gp::append(const double* X_new, int64_t b, const double* y_all) {
   LAUNCH_CHECK();
   std::vector<double> hG((size_t)b * b), hK((size_t)b * b), hx((size_t)b * d);
   HIPCHK(hipMemcpyAsync(hG.data(), G, hG.size() * 8, hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipMemcpyAsync(hx.data(), X.d() + N0 * d, hx.size() * 8, hipMemcpyDeviceToHost, stream));
+  if (xnew_on_device) HIPCHK(hipMemcpyAsync(hx.data(), X.d() + N0 * d, hx.size() * 8, hipMemcpyDeviceToHost, stream));
+  else std::memcpy(hx.data(), X_new, hx.size() * 8);
   sync();
   // K(X_new, X_new) + noise I on the host (b <= 64 points; the kernel of gp.py:124-168 with direct differences)
   for (int64_t i = 0; i < b; ++i)
