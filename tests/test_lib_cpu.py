@@ -322,3 +322,32 @@ def test_fit_start_is_walked_back_to_a_factorisable_kernel_variance():
     hopeless.wall = -math.inf
     Fake.calls = 0
     assert _factorisable_start(hopeless, init) is init and Fake.calls == 2     # sixteen candidates, eight per batch
+
+
+def test_import_BOBE_alias_resolves_to_bobe_amd():
+    """bobe_amd/compat on the path: ``import BOBE`` and the reference's submodule paths bind to this package (no GPU is
+    touched by importing)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import BOBE, bobe_amd\n"
+            "from BOBE import BOBE as B, GP, Likelihood, WIPStd, scale_from_unit, get_logger\n"
+            "from BOBE.gp import GP as G2, rbf_kernel, gp_mll\n"
+            "from BOBE.bo import BOBE as B2, load_gp_file\n"
+            "from BOBE.utils.core import scale_to_unit, renormalise_log_weights, resample_equal\n"
+            "from BOBE.utils.seed import set_global_seed, get_numpy_rng\n"
+            "from BOBE.utils import get_logger as gl2\n"
+            "from BOBE.acquisition import EI, LogEI, WIPV, get_mc_samples\n"
+            "from BOBE.samplers import nested_sampling_Dy, sample_GP_NUTS\n"
+            "from BOBE.optim import optimize_scipy\n"
+            "from BOBE.clf import svm_predict, CLASSIFIER_REGISTRY\n"
+            "from BOBE.clf_gp import GPwithClassifier\n"
+            "assert B is bobe_amd.BOBE is B2 and GP is bobe_amd.GP is G2 and BOBE.gp is bobe_amd.gp\n"
+            "try:\n    BOBE.BOBEResults\n    raise SystemExit('results manager should not exist')\n"
+            "except AttributeError as e:\n    assert 'does not build' in str(e)\n"
+            "print('alias ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "bobe_amd", "compat"), root,
+                                                        os.environ.get("PYTHONPATH", "")]))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "alias ok" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
