@@ -156,3 +156,55 @@ def test_every_entry_point_refuses_a_null_handle_and_the_wrong_state():
     lib.bobe_gp_destroy(h2)
     assert c["predict"]() == 0 and np.array_equal(o8, ref)
     lib.bobe_gp_destroy(h)
+
+
+def test_round5_entry_points_error_contract():
+    """bobe_gp_dist_sq / _mll_from_k / _chol_row_update / _set_pivot_floor_ulp / _set_refine_kappa / _get_refine: NULL and
+    bad sizes are ERR_ARG with a message, a handle that holds training data of another size refuses a free-function call
+    with ERR_STATE (it would have to resize the workspace under the data), and a refused call leaves the handle as it was."""
+    from bobe_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    d, n = 2, 30
+    X, y = np.ascontiguousarray(rng.uniform(size=(n, d))), np.ascontiguousarray(rng.normal(size=n))
+    K = np.ascontiguousarray(np.exp(-0.5 * ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1) / 0.25) + 1e-4 * np.eye(n))
+    L = np.ascontiguousarray(np.linalg.cholesky(K))
+    out, v, val, dg = np.empty((n, n)), np.empty(n), C.c_double(), C.c_double()
+    kap, act = C.c_double(), C.c_int()
+    # NULL handle
+    assert lib.bobe_gp_dist_sq(None, _p(X), n, _p(X), n, _p(out)) == ERR_ARG and lib.bobe_last_error()
+    assert lib.bobe_gp_mll_from_k(None, _p(K), n, _p(y), C.byref(val)) == ERR_ARG
+    assert lib.bobe_gp_chol_row_update(None, _p(L), n, _p(y), 2.0, _p(v), C.byref(dg)) == ERR_ARG
+    assert lib.bobe_gp_set_pivot_floor_ulp(None, 64.0) == ERR_ARG and lib.bobe_gp_get_pivot_floor_ulp(None) == -1.0
+    assert lib.bobe_gp_set_refine_kappa(None, 1e6) == ERR_ARG and lib.bobe_gp_get_refine(None, C.byref(kap), C.byref(act)) == ERR_ARG
+    h = C.c_void_p(0)
+    assert lib.bobe_gp_create(C.byref(h), 0, 0, d) == 0
+    try:
+        # data-less handle: the free functions work and leave it data-less; NULL arrays / n < 1 are refused
+        assert lib.bobe_gp_dist_sq(h, _p(X), n, _p(X), n, _p(out)) == 0 and np.allclose(np.diag(out), 0.0)
+        assert lib.bobe_gp_mll_from_k(h, _p(K), n, _p(y), C.byref(val)) == 0 and np.isfinite(val.value)
+        assert lib.bobe_gp_chol_row_update(h, _p(L), n, _p(K[:, 0].copy()), 5.0, _p(v), C.byref(dg)) == 0 and np.isfinite(dg.value)
+        assert lib.bobe_gp_npoints(h) in (0, n) and lib.bobe_gp_factor(h) == ERR_STATE          # still no training data
+        for rc in (lib.bobe_gp_dist_sq(h, None, n, _p(X), n, _p(out)), lib.bobe_gp_dist_sq(h, _p(X), 0, _p(X), n, _p(out)),
+                   lib.bobe_gp_mll_from_k(h, _p(K), 0, _p(y), C.byref(val)), lib.bobe_gp_mll_from_k(h, None, n, _p(y), C.byref(val)),
+                   lib.bobe_gp_mll_from_k(h, _p(K), n, _p(y), None), lib.bobe_gp_chol_row_update(h, _p(L), -3, _p(y), 1.0, _p(v), C.byref(dg)),
+                   lib.bobe_gp_chol_row_update(h, _p(L), n, None, 1.0, _p(v), C.byref(dg)),
+                   lib.bobe_gp_set_pivot_floor_ulp(h, -1.0), lib.bobe_gp_set_pivot_floor_ulp(h, float("nan")),
+                   lib.bobe_gp_set_refine_kappa(h, float("nan"))):
+            assert rc == ERR_ARG and lib.bobe_last_error(), rc
+        assert lib.bobe_gp_get_pivot_floor_ulp(h) == 64.0
+        assert lib.bobe_gp_get_refine(h, C.byref(kap), C.byref(act)) == 0 and kap.value == 1e6 and act.value == 0
+        assert lib.bobe_gp_get_refine(h, None, None) == 0
+        # a handle with training data of ANOTHER size refuses the free functions on matrices (ERR_STATE) and stays intact
+        ls = np.full(d, 0.5)
+        assert lib.bobe_gp_set_data(h, _p(X[:20].copy()), _p(y[:20].copy()), 20) == 0
+        assert lib.bobe_gp_set_hyper(h, _p(ls), 1.0, 1e-6) == 0 and lib.bobe_gp_factor(h) == 0
+        m0 = np.empty(4)
+        assert lib.bobe_gp_predict(h, _p(X[:4].copy()), 4, _p(m0), None, 1) == 0
+        assert lib.bobe_gp_mll_from_k(h, _p(K), n, _p(y), C.byref(val)) == ERR_STATE and b"another size" in lib.bobe_last_error()
+        assert lib.bobe_gp_chol_row_update(h, _p(L), n, _p(y), 2.0, _p(v), C.byref(dg)) == ERR_STATE
+        m1 = np.empty(4)
+        assert lib.bobe_gp_predict(h, _p(X[:4].copy()), 4, _p(m1), None, 1) == 0 and np.array_equal(m0, m1)
+        assert lib.bobe_gp_dist_sq(h, _p(X), n, _p(X), n, _p(out)) == 0                          # (needs no workspace of the factor)
+    finally:
+        lib.bobe_gp_destroy(h)
