@@ -1,9 +1,14 @@
-"""``Likelihood`` - counterpart of BOBE/likelihood.py:9-124: the wrapper ``BOBE`` puts around a plain callable (name,
-parameter names / labels / bounds, safe evaluation).  ``CobayaLikelihood`` (likelihood.py:126-) is an adaptor to an
-external sampler framework and outside the hot path's scope."""
+"""``Likelihood`` - counterpart of the wrapper class in BOBE/likelihood.py:9-124 that ``BOBE`` puts around a plain callable:
+a name, the parameter names / LaTeX labels / box bounds, and an evaluation that never raises.  (``CobayaLikelihood``,
+likelihood.py:126-, adapts an external sampler framework and is outside the hot path's scope: DESIGN.md 8.)
+
+Same constructor keywords, attributes (``logl, param_list, ndim, param_labels, param_bounds, name, minus_inf,
+logprior_vol``) and call convention as the reference class; the code is this build's own.
+"""
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Union
+import math
+from typing import Callable, List, Optional, Sequence, Union
 
 import numpy as np
 
@@ -12,51 +17,58 @@ from .utils.log import get_logger
 log = get_logger("likelihood")
 
 
+def _box(bounds, ndim: int) -> np.ndarray:
+    """The (2, ndim) array of lower / upper limits; ``None`` means the unit cube."""
+    if bounds is None:
+        log.warning("No param_bounds provided. Assuming unit cube [0,1] for all parameters.")
+        return np.vstack([np.zeros(ndim), np.ones(ndim)]).astype(int)
+    box = np.array(bounds)
+    if box.shape != (2, ndim):
+        raise ValueError(f"param_bounds must have shape (2, {ndim}), but got {box.shape}.")
+    return box
+
+
 class Likelihood:
-    """A log-likelihood with its parameter space.  ``loglikelihood(x) -> float`` on physical parameters; ``param_bounds`` has
-    shape (2, ndim) (default: the unit cube); a failed, NaN, infinite or below-``minus_inf`` evaluation returns
-    ``minus_inf`` (likelihood.py:61-83)."""
+    """A log-likelihood together with its parameter space.
+
+    ``loglikelihood(x) -> float`` takes the physical parameter vector.  An evaluation that raises, or returns NaN, an
+    infinity or anything below ``minus_inf``, counts as ``minus_inf`` (likelihood.py:61-83): the BO loop never sees an
+    exception or a non-finite target."""
 
     def __init__(self, loglikelihood: Callable, param_list: Optional[List[str]], param_labels: Optional[List[str]] = None,
                  param_bounds: Optional[Union[List, np.ndarray]] = None, name: Optional[str] = None,
                  minus_inf: float = -1e10):
-        self.logl = loglikelihood
-        if not all(isinstance(p, str) for p in param_list):
+        names: Sequence = param_list
+        if any(not isinstance(n, str) for n in names):
             raise ValueError("All elements of param_list must be strings corresponding to parameter names.")
+        self.logl = loglikelihood
         self.param_list = param_list
-        self.ndim = len(self.param_list)
-        self.param_labels = param_labels if param_labels is not None else [f"x_{{{i + 1}}}" for i in range(self.ndim)]
-        if param_bounds is None:
-            self.param_bounds = np.array(self.ndim * [[0, 1]]).T
-            log.warning("No param_bounds provided. Assuming unit cube [0,1] for all parameters.")
-        else:
-            param_bounds = np.array(param_bounds)
-            if param_bounds.shape != (2, self.ndim):
-                raise ValueError(f"param_bounds must have shape (2, {self.ndim}), but got {param_bounds.shape}.")
-            self.param_bounds = param_bounds
-        self.name = name or "loglikelihood"
+        self.ndim = len(names)
+        self.param_labels = ["x_{%d}" % (k + 1) for k in range(self.ndim)] if param_labels is None else param_labels
+        self.param_bounds = _box(param_bounds, self.ndim)
+        self.name = name if name else "loglikelihood"
         self.minus_inf = minus_inf
-        self.logprior_vol = np.log(np.prod(self.param_bounds[1] - self.param_bounds[0]))
-        log.info(f"Initialized {self.name} with {self.ndim} params: {self.param_list}; log prior volume = "
-                 f"{self.logprior_vol:.4f}")
+        widths = self.param_bounds[1] - self.param_bounds[0]
+        self.logprior_vol = np.log(np.prod(widths))                       # (likelihood.py:52: log of the box volume)
+        limits = ", ".join("'%s': [%.6g, %.6g]" % (n, lo, hi) for n, lo, hi in zip(names, *self.param_bounds))
+        log.info(f"{self.name}: {self.ndim} parameters {{{limits}}}, log prior volume {self.logprior_vol:.4f}")
 
     def _safe_eval(self, x: np.ndarray) -> float:
+        """The value at one parameter vector, ``minus_inf`` for every kind of failure."""
         try:
-            val = float(self.logl(x))
-        except Exception:
-            log.debug(f"Log-likelihood evaluation failed at point {x}", exc_info=True)
+            value = float(self.logl(x))
+        except Exception:                                   # whatever the user's function throws
+            log.debug("log-likelihood raised at %s", x, exc_info=True)
             return self.minus_inf
-        if np.isnan(val) or np.isinf(val) or val < self.minus_inf:
-            return self.minus_inf
-        return val
+        return value if (math.isfinite(value) and value >= self.minus_inf) else self.minus_inf
 
     def __call__(self, X: Union[np.ndarray, List[float]]) -> float:
-        """One point, shape (ndim,) or (1, ndim) (likelihood.py:85-124)."""
-        X = np.atleast_1d(X)
-        if X.ndim > 1:
-            if X.shape[0] != 1:
-                raise ValueError("__call__ expects a single point.")
-            X = X.flatten()
-        if X.shape[0] != self.ndim:
-            raise ValueError(f"Input shape {X.shape} does not match ndim {self.ndim}")
-        return self._safe_eval(X)
+        """One point, given as (ndim,) or (1, ndim) - batches go through the BO driver's loop (likelihood.py:85-124)."""
+        point = np.atleast_1d(X)
+        if point.ndim > 1:
+            if point.shape[0] != 1:
+                raise ValueError("__call__ expects a single point. Use pool.run_map_objective for batch evaluations.")
+            point = point.reshape(-1)
+        if point.shape[0] != self.ndim:
+            raise ValueError(f"Input shape {point.shape} does not match ndim {self.ndim}")
+        return self._safe_eval(point)
