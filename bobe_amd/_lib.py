@@ -73,6 +73,9 @@ SIGNATURES = [
     ("bobe_gp_set_pivot_floor_ulp", C.c_int, [C.c_void_p, C.c_double]),
     ("bobe_gp_get_pivot_floor_ulp", C.c_double, [C.c_void_p]),
     ("bobe_gp_set_refine_kappa", C.c_int, [C.c_void_p, C.c_double]),
+    ("bobe_gp_set_solve_block", C.c_int, [C.c_void_p, C.c_int]),
+    ("bobe_gp_get_solve_block", C.c_int, [C.c_void_p]),
+    ("bobe_debug_solve_opts", C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     ("bobe_gp_get_refine", C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_int)]),
     ("bobe_gp_get_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bobe_gp_set_chol", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -18,7 +18,7 @@ from scipy.stats import qmc
 
 from . import _lib
 from .gp import GP
-from .optim import optimize_scipy
+from .optim import optimize_optax, optimize_scipy
 from .utils import get_logger, get_numpy_rng
 
 log = get_logger("acq")
@@ -33,7 +33,7 @@ class AcquisitionFunction:
     def __init__(self, optimizer: str = "scipy", optimizer_options: Optional[Dict[str, Any]] = None):
         self.optimizer = optimizer
         self.optimizer_options = optimizer_options if optimizer_options is not None else {}
-        self.acq_optimize = optimize_scipy
+        self.acq_optimize = optimize_scipy if optimizer == "scipy" else optimize_optax      # acquisition.py:101-104
 
     def fun(self, x, *args, **kwargs):
         raise NotImplementedError

@@ -72,7 +72,7 @@ def _factorisable_start(gp: GP, init: np.ndarray) -> np.ndarray:
 
 
 def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.random.Generator] = None,
-           use_pool: bool = True, *, group=None, distributed: bool = True) -> dict:
+           use_pool: bool = True, *, group=None, distributed: bool = True, factorisable_start: bool = True) -> dict:
     """``MPI_Pool.gp_fit`` (pool.py:268-328): x0 row 0 = log(current hp), further rows uniform in the log-bounds;
     fit; adopt the best hyper-parameters (refactors on the GPU).
 
@@ -81,11 +81,14 @@ def gp_fit(gp: GP, maxiters: int = 1000, n_restarts: int = 8, rng: Optional[np.r
     them (``np.array_split``, pool.py:298-326): each rank runs its chunk — concurrently, on the evaluation slots of
     its own GPU — then one all-gather of (mll, theta) and max-by-mll; every rank adopts the same theta.
     ``use_pool=False`` (the reference's keyword, pool.py:239) or ``distributed=False`` keeps the fit on this rank (no
-    collective: for calls that not every rank makes)."""
+    collective: for calls that not every rank makes).  ``factorisable_start=False`` keeps row 0 = log(current hp) whatever
+    happens at it, as the reference does (pool.py:277-284; ``_factorisable_start`` above)."""
     distributed = bool(distributed and use_pool)
     rng = np.random.default_rng() if rng is None else rng
     n_params = gp.hyperparam_bounds.shape[1]
-    init = _factorisable_start(gp, np.log(gp.get_hyperparams()))
+    init = np.log(gp.get_hyperparams())
+    if factorisable_start:
+        init = _factorisable_start(gp, init)
     if n_restarts > 1:
         x0 = np.vstack([init, rng.uniform(gp.hyperparam_bounds[0], gp.hyperparam_bounds[1],
                                           size=(n_restarts - 1, n_params))])
@@ -148,8 +151,13 @@ class BOBE:
                  save_dir: str = ".", save: bool = True, save_step: int = 5, optimizer: str = "scipy",
                  acq: str = "WIPV", use_clf: bool = False, clf_type: str = "svm", clf_nsigma_threshold: float = 20,
                  clf_use_size: int = 10, clf_update_step: int = 1, minus_inf: float = -1e10,
-                 seed: Optional[int] = None, verbosity: str = "INFO", *, device: int = 0):
-        """Keywords, order and defaults of the reference constructor (bo.py:69-96) plus the keyword-only ``device``.
+                 seed: Optional[int] = None, verbosity: str = "INFO", *, device: int = 0,
+                 factorisable_start: bool = True):
+        """Keywords, order and defaults of the reference constructor (bo.py:69-96) plus the keyword-only ``device`` and
+        ``factorisable_start`` (deviation (viii), DESIGN.md 8: a fit whose incumbent no longer factorises starts from the
+        nearest kernel variance that does; False = the reference's starts).  The surrogate is built with the GP's own
+        defaults except one: ``pivot_floor_ulp = 64`` (deviation (vii), the rank test; the ``GP`` class by itself keeps the
+        reference's sign-only rule) - ``gp_kwargs={'pivot_floor_ulp': 0}`` switches it off for the run.
         ``loglikelihood`` must be a callable on physical parameters (Cobaya likelihoods belong to the parts that are not
         built).  ``acq`` is recorded among the settings only, as in the reference (bo.py:314): what runs is
         ``run``'s own ``acq``.  ``save`` (default True, bo.py:84) writes ``<save_dir>/<likelihood_name>_gp.npz`` after the
@@ -177,8 +185,13 @@ class BOBE:
         self.minus_inf = float(minus_inf)
         self.optimizer = optimizer
         self.device = device
-        self.is_main, self.is_mpi = True, False                             # (no MPI pool: one process per GPU)
-        self.save, self.save_dir, self.save_step = bool(save), save_dir, max(1, int(save_step))
+        # No MPI pool: one process per GPU, every rank runs this loop with the same seed.  Rank 0 of the
+        # initialised torch.distributed group is the main process (bo.py:97-101 asks the pool the same) and the ONLY one that
+        # writes files: the checkpoint generations, the run state and the reference's <name>_gp.npz.
+        self.is_main, self.is_mpi = dist_info(None, device)[1] == 0, False
+        self.save, self.save_dir, self.save_step = bool(save) and self.is_main, save_dir, max(1, int(save_step))
+        self.factorisable_start = bool(factorisable_start)
+        self.pivot_floor_ulp = float((gp_kwargs or {}).get("pivot_floor_ulp", 64.0))
         self.settings = {"n_cobaya_init": n_cobaya_init, "n_sobol_init": n_sobol_init, "acq": acq, "use_clf": use_clf,
                          "clf_type": clf_type, "clf_nsigma_threshold": clf_nsigma_threshold, "minus_inf": minus_inf,
                          "seed": seed}                                      # bo.py:311-320
@@ -257,7 +270,8 @@ class BOBE:
         if init_train_x is not None and init_train_y is not None:
             pts = np.vstack([np.atleast_2d(np.asarray(init_train_x, dtype=np.float64)), pts])
             vals = np.vstack([np.asarray(init_train_y, dtype=np.float64).reshape(-1, 1), vals])
-        kw = dict(optimizer=optimizer)               # everything else: the GP's own defaults, as bo.py:584-605 leaves them
+        # everything else: the GP's own defaults, as bo.py:584-605 leaves them
+        kw = dict(optimizer=optimizer, pivot_floor_ulp=self.pivot_floor_ulp)
         kw.update(gp_kwargs or {})
         t0 = time.time()
         x_u = scale_to_unit(pts, self.param_bounds)
@@ -272,7 +286,8 @@ class BOBE:
                                        device=self.device, **kw)
         else:
             self.gp = GP(x_u, vals, param_names=self.param_list, device=self.device, **kw)
-        gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng)        # bo.py:611
+        gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng,        # bo.py:611
+               factorisable_start=self.factorisable_start)
         self.timing["GP Training"] += time.time() - t0
 
     # ------------------------------------------------------------------ files
@@ -300,6 +315,7 @@ class BOBE:
                 if st.get("mc_file"):
                     z = np.load(os.path.join(base, st["mc_file"]), allow_pickle=False)
                     st["mc"] = {k: (z[k] if z[k].shape != () else z[k].item()) for k in z.files}
+                gp.pivot_floor_ulp = self.pivot_floor_ulp               # (a run's setting, not part of the reference's file)
                 self.gp, self.fresh_start, self._resume_state = gp, False, st
                 self._ckpt_gen = int(st.get("generation", 0))
                 self.start_iteration = int(st.get("iteration", 0))
@@ -314,6 +330,7 @@ class BOBE:
             log.info(f"Attempting to resume from file {resume_file}")
             self.gp = load_gp_file(gp_file, use_clf, device=self.device)
             _ = self.gp.predict_mean_single(self.gp.train_x[0])
+            self.gp.pivot_floor_ulp = self.pivot_floor_ulp
             log.info(f"Loaded GP with {self.gp.train_x.shape[0]} training points")
         except Exception as e:
             log.error(f"Failed to load GP from file {gp_file}: {e}")
@@ -326,7 +343,7 @@ class BOBE:
     def _save_gp_file(self, source: Optional[str] = None) -> None:
         """The reference's file ``<save_path>_gp.npz`` (bo.py:239; loadable by its ``load_gp_file``), moved into place
         under its final name only when complete."""
-        tmp = self.save_path + "_gp.tmp"                                  # (np.savez appends .npz)
+        tmp = f"{self.save_path}_gp.tmp{os.getpid()}"                     # (np.savez appends .npz)
         if source is None:
             self.gp.save(tmp)
         else:
@@ -355,7 +372,7 @@ class BOBE:
         st = dict(state, rng_state=self.np_rng.bit_generator.state, gp_training_set_size=int(self.gp.npoints),
                   n_points_since_last_fit=int(self.n_points_since_last_fit), timing=dict(self.timing),
                   generation=g, gp_file=gp_file, mc_file=mc_file)
-        tmp = self.save_path + "_run.json.tmp"
+        tmp = f"{self.save_path}_run.json.tmp{os.getpid()}"
         with open(tmp, "w") as fh:
             json.dump(st, fh)
         os.replace(tmp, self.save_path + "_run.json")                  # (never a half-written state file)
@@ -372,7 +389,7 @@ class BOBE:
     def _run_state(self) -> dict:
         """What a resumed run continues from (bo.py:337-372: iteration, histories, convergence state)."""
         num = (int, float, np.floating, np.integer)
-        return {"acq": self.acquisition.name if self.acquisition is not None else None,
+        return {"acq": self.acquisition.name if self.acquisition is not None else None, "stage": int(getattr(self, "_stage", 0)),
                 "iteration": int(self.current_iteration), "current_evals": int(self._current_evals),
                 "n_since_ns": int(self.n_points_since_last_ns), "counter": int(self.convergence_counter),
                 "acq_history": [float(a) for a in self.acquisition_history], "converged": bool(self.converged),
@@ -402,7 +419,8 @@ class BOBE:
         if refit:
             if verbose:
                 log.info(f"Refitting GP hyperparameters with {self.gp.train_x.shape[0]} training points ")
-            gp_fit(self.gp, n_restarts=n_restarts, maxiters=maxiter, rng=self.np_rng)
+            gp_fit(self.gp, n_restarts=n_restarts, maxiters=maxiter, rng=self.np_rng,
+                   factorisable_start=self.factorisable_start)
             self.n_points_since_last_fit = 0
         self.timing["GP Training"] += time.time() - t0
         self.gp_hyperparam_history.append({"iteration": int(step), "lengthscales": [float(v) for v in self.gp.lengthscales],
@@ -579,7 +597,16 @@ class BOBE:
                 raise ValueError(f"Invalid acquisition function '{a}'. Valid options are: {list(_ACQ)}")
         self.current_iteration = self.start_iteration
         rs, self._resume_state = self._resume_state, None        # (a second run() on this object starts from its current state)
-        if rs is not None and str(rs.get("acq") or acqs[0]).lower() == acqs[0].lower():
+        # A tuple of acquisition functions runs as stages, one after the other (bo.py:1149-1158); a saved run state names the
+        # stage it was written in and is continued there (the stages before it are done).
+        first_stage = 0
+        if rs is not None:
+            k = int(rs.get("stage", 0))
+            if 0 <= k < len(acqs) and str(rs.get("acq") or acqs[k]).lower() == acqs[k].lower():
+                first_stage = k
+            else:
+                rs = None
+        if rs is not None:
             # continue the interrupted run (bo.py:337-372: iteration, histories, convergence state)
             self.current_iteration, self._current_evals = int(rs["iteration"]), int(rs["current_evals"])
             self.n_points_since_last_ns, self.convergence_counter = int(rs["n_since_ns"]), int(rs["counter"])
@@ -594,7 +621,17 @@ class BOBE:
             if rs.get("converged"):                              # the saved run had already met its stopping rule
                 self.converged = True
                 self.termination_reason = rs.get("termination_reason", "LogZ converged")
-        for a in acqs:
+        for k, a in enumerate(acqs):
+            if k < first_stage:
+                continue
+            self._stage = k
+            if k > first_stage:
+                # every stage has its own stopping rule (the reference's loops keep `converged` local, bo.py:1188, 1257) but
+                # shares the budgets: a stage that would start past them is not entered at all
+                if self.check_max_evals_and_gpsize(self._current_evals):
+                    break
+                self.converged, self.convergence_counter = False, 0
+                self.termination_reason = "Max evaluation budget reached"
             self.acquisition = _ACQ[a.lower()](optimizer=self.optimizer)
             if a.lower() == "wipv":
                 self.run_WIPV(ii=self.current_iteration)
@@ -725,7 +762,7 @@ class BOBE:
         ns_success = self._ns_success
         if self.do_final_ns and not self.converged:                          # bo.py:1345-1366
             t0 = time.time()
-            gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng)
+            gp_fit(self.gp, n_restarts=4, maxiters=500, rng=self.np_rng, factorisable_start=self.factorisable_start)
             self.timing["GP Training"] += time.time() - t0
             t0 = time.time()
             self.ns_samples, logz_dict, ns_success = nested_sampling(self.gp, mode="convergence", dlogz=0.01,

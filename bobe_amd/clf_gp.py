@@ -31,8 +31,9 @@ class GPwithClassifier(GP):
                  gp_threshold=500.0, noise=1e-8, kernel="rbf", optimizer="scipy", optimizer_options={},
                  kernel_variance_bounds=[1e-4, 1e8], lengthscale_bounds=[0.01, 5.0], tausq=None,
                  tausq_bounds=[1e-4, 1e4], kernel_variance_prior=None, lengthscale_prior=None, lengthscales=None,
-                 kernel_variance=1.0, param_names=None, train_clf_on_init=True, device: int = 0):
-        """Same keywords as clf_gp.py:15-30 (+ ``device``)."""
+                 kernel_variance=1.0, param_names=None, train_clf_on_init=True, device: int = 0,
+                 pivot_floor_ulp: Optional[float] = None):
+        """Same keywords as clf_gp.py:15-30 (+ ``device``, ``pivot_floor_ulp``: see ``GP``)."""
         if clf_type.lower() != "svm":
             raise ValueError(f"Unsupported classifier type: {clf_type} (only 'svm' is built)")
         self.train_x_clf = np.array(train_x, dtype=np.float64)
@@ -49,7 +50,7 @@ class GPwithClassifier(GP):
                          lengthscales=lengthscales, kernel_variance=kernel_variance,
                          lengthscale_prior=lengthscale_prior if lengthscale_prior is not None else "DSLP",
                          kernel_variance_prior=kernel_variance_prior, tausq=tausq, tausq_bounds=tausq_bounds,
-                         param_names=param_names, device=device)
+                         param_names=param_names, device=device, pivot_floor_ulp=pivot_floor_ulp)
         self._gate_installed = False
         self._clf_predict_func: Optional[Callable] = None
         self.use_clf = self.clf_data_size >= self.clf_use_size

@@ -153,6 +153,19 @@ int bobe_gp_set_chunk(bobe_gp_t* g, int64_t chunk) {
   API_END
 }
 
+int bobe_debug_solve_opts(bobe_gp_t* g, int panel, int64_t chunk) {
+  API_BEGIN
+  NEED(g, "gp is NULL");
+  NEED(panel > 0 && panel % TILE == 0, "panel must be a positive multiple of 128");
+  NEED(chunk >= 0 && chunk % TILE == 0, "chunk must be 0 or a positive multiple of 128");
+  g->use();
+  g->sync();
+  g->solve_panel = panel;
+  g->solve_chunk = chunk;
+  return BOBE_OK;
+  API_END
+}
+
 int64_t bobe_gp_npoints(bobe_gp_t* g) { return g ? g->N : 0; }
 
 int bobe_gp_set_data(bobe_gp_t* g, const double* X, const double* ys, int64_t N) {
@@ -388,6 +401,17 @@ int bobe_gp_set_refine_kappa(bobe_gp_t* g, double kappa) {
   return BOBE_OK;
   API_END
 }
+
+int bobe_gp_set_solve_block(bobe_gp_t* g, int rows) {
+  API_BEGIN
+  NEED(g, "gp is NULL");
+  NEED(rows > 0 && rows % bobe::TILE == 0, "rows must be a positive multiple of 128");
+  g->solve_block = rows;
+  return BOBE_OK;
+  API_END
+}
+
+int bobe_gp_get_solve_block(bobe_gp_t* g) { return g ? g->solve_block : -1; }
 
 int bobe_gp_get_refine(bobe_gp_t* g, double* kappa, int* active) {
   API_BEGIN

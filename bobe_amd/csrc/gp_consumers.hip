@@ -276,6 +276,9 @@ void bobe_gp::clone_from(bobe_gp& src) {
   hyp = src.hyp;
   pivot_ulp = src.pivot_ulp;
   refine_kappa = src.refine_kappa;
+  solve_block = src.solve_block;
+  solve_panel = src.solve_panel;
+  solve_chunk = src.solve_chunk;
   refine_v = src.factored && src.refine_v;      // (A is copied with its diagonal blocks as the source left them)
   if (Np != src.Np) {
     Np = src.Np;

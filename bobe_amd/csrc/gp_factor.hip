@@ -82,12 +82,39 @@ double default_refine_kappa() {
   return v;
 }
 
+int default_solve_block() {
+  static const int v = [] {
+    const char* e = std::getenv("BOBE_SOLVE_BLOCK");
+    const int b = e ? std::atoi(e) : TILE;
+    return b > 0 ? (b + TILE - 1) / TILE * TILE : TILE;
+  }();
+  return v;
+}
+
+int default_solve_panel() {
+  static const int v = [] {
+    const char* e = std::getenv("BOBE_SOLVE_PANEL");
+    const int b = e ? std::atoi(e) : 512;
+    return b > 0 ? (b + TILE - 1) / TILE * TILE : 512;
+  }();
+  return v;
+}
+
+int64_t default_solve_chunk() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("BOBE_SOLVE_CHUNK");
+    const int64_t c = e ? std::atoll(e) : 32768;       // (K(X, chunk) and V: 1 GiB each at N = 4096)
+    return c > 0 ? (c + TILE - 1) / TILE * TILE : 0;
+  }();
+  return v;
+}
+
 double default_pivot_floor_ulp() {
   static const double v = [] {
     const char* e = std::getenv("BOBE_PIVOT_FLOOR_ULP");
-    if (!e) return 64.0;
+    if (!e) return 0.0;
     const double u = std::atof(e);
-    return u >= 0.0 ? u : 64.0;
+    return u >= 0.0 ? u : 0.0;
   }();
   return v;
 }
@@ -1035,16 +1062,22 @@ void bobe_gp::set_chol(const double* L, const double* alpha_in) {
                        static_cast<int*>(info.p));
   LAUNCH_CHECK();
   trtri(A.d(), Linv.d(), Tmp.d());
-  // the restored factor's smallest pivot decides about the refinement of the products with Linv, as after a factorisation
-  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w.d(), (const double*)A.d(), Np, Np, res.d(),
+  // the restored factor's smallest pivot decides how the products with Linv are formed, as after a factorisation
+  const double min_diag = min_pivot_root();
+  factored = true;
+  forget_z();
+  not_pd = false;
+  decide_refinement(min_diag);
+}
+
+// the smallest L_jj of the factor in A (k_mll_terms without a right-hand side); synchronises
+double bobe_gp::min_pivot_root() {
+  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)nullptr, (const double*)A.d(), Np, Np, res.d(),
                      (int64_t)0, (int64_t)0, (int64_t)0, (const int*)nullptr);
   LAUNCH_CHECK();
   HIPCHK(hipMemcpyAsync(h_res, res.p, 102 * sizeof(double), hipMemcpyDeviceToHost, stream));
   sync();
-  factored = true;
-  forget_z();
-  not_pd = false;
-  decide_refinement(h_res[101]);
+  return h_res[101];
 }
 
 // ---- the reference's free functions on caller-supplied matrices (gp.py:170-197), on a handle that holds no training data

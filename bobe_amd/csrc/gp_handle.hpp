@@ -84,16 +84,20 @@ struct DBuf {
 // log-determinant built on it (a too small one - the optimiser is drawn to exactly these hyper-parameters).  Such a
 // factorisation counts as NOT positive definite, like one with a non-positive pivot: NaN outputs, BOBE_NOT_PD.  (LAPACK's
 // dpotrf, the reference's Cholesky, tests the sign only and fails or passes on the last bit in this regime)
-// The factor (64) is per handle: bobe_gp_set_pivot_floor_ulp, default from BOBE_PIVOT_FLOOR_ULP; 0 switches the rank test
-// off, leaving LAPACK's rule (a pivot <= 0 or NaN fails, nothing else).
+// The factor is per handle: bobe_gp_set_pivot_floor_ulp, default from BOBE_PIVOT_FLOOR_ULP, else 0 = the rank test is OFF and
+// LAPACK's rule alone holds (a pivot <= 0 or NaN fails, nothing else: the reference's behaviour).  The BO driver opts in
+// with 64 (bobe_amd/bo.py).
 inline double pivot_floor(const Hyper& h, double ulp) {
   const double f = ulp * 2.220446049250313e-16 * (h.kvar + h.noise);
   return f < 0.25 ? f : 0.25;                        // (the identity padding's pivots are 1)
 }
 // min_diag: the smallest L_jj of a factor (k_mll_terms, res[101]); NaN counts as failed
 inline bool pivots_resolved(double min_diag, double floor) { return min_diag * min_diag >= floor; }
-double default_pivot_floor_ulp();                    // BOBE_PIVOT_FLOOR_ULP, else 64
+double default_pivot_floor_ulp();                    // BOBE_PIVOT_FLOOR_ULP, else 0 (the reference's sign test alone)
 double default_refine_kappa();                       // BOBE_REFINE_KAPPA, else 1e6
+int default_solve_block();                           // BOBE_SOLVE_BLOCK, else 128
+int default_solve_panel();                           // BOBE_SOLVE_PANEL, else 512
+int64_t default_solve_chunk();                       // BOBE_SOLVE_CHUNK, else 32768
 
 template <typename K>
 void allow_big_lds(K kernel, int bytes) {
@@ -155,14 +159,22 @@ struct bobe_gp {
   double pivot_ulp = bobe::default_pivot_floor_ulp();     // the rank test's factor (0: sign test only, as dpotrf)
   double pivot_floor(const Hyper& h) const { return bobe::pivot_floor(h, pivot_ulp); }
   bool have_data = false, factored = false, not_pd = false;
-  // One step of iterative refinement of every V = L^-1 K(X, .) (sweep_kernels.hpp, k_trimul_resid): on when the factor's
-  // (kvar + noise) / smallest pivot exceeds refine_kappa (bobe_gp_set_refine_kappa; default BOBE_REFINE_KAPPA, else 1e6;
-  // 0: always, negative: never).  Decided when a factor is installed: the same bits on every rank.
+  // Where the installed factor is ill conditioned - (kvar + noise) / smallest pivot above refine_kappa (bobe_gp_set_refine_kappa;
+  // default BOBE_REFINE_KAPPA, else 1e6; 0: always, negative: never) - every V = L^-1 K(X, .) is SOLVED for by a blocked
+  // forward substitution (sweep_kernels.hpp, k_blk_step) instead of multiplied out with the inverse factor; the vector form
+  // of bobe_gp_wip_grad's few-candidate path takes one step of iterative refinement.  Decided when a factor is installed: the
+  // same bits on every rank.
   double refine_kappa = bobe::default_refine_kappa();
   bool refine_v = false;
+  // solve_block: rows of the substitution's diagonal blocks (a multiple of 128; sets the accuracy).  Speed only: solve_panel
+  // = rows per long update launch, solve_chunk = candidates per launch sequence of that path (0: `chunk`)
+  int solve_block = bobe::default_solve_block();
+  int solve_panel = bobe::default_solve_panel();
+  int64_t solve_chunk = bobe::default_solve_chunk();
   void decide_refinement(double min_diag);
-  // V = L^-1 B for ncp (a multiple of 128) columns, refined when refine_v: B [Np x ldb] is then overwritten by the residual;
-  // V may be NULL only without refinement (callers pass a buffer whenever refine_v is set); qp: k_trimul's column sums
+  // V = L^-1 B for ncp (a multiple of 128) columns: the product with the inverse factor, or - refine_v - the blocked
+  // substitution, which overwrites B [Np x ldb] and needs V (V may be NULL only for the plain product); qp: the column sums
+  // of squares per row tile (k_trimul's epilogue)
   void solve_v(double* B, int64_t ldb, int64_t ncp, double* V, int64_t ldv, double* qp, int64_t ldq);
   // prepare_z() keeps its results (ZsT, W_Z, base_z) while the same host Z arrives again and nothing they depend on
   // changed: an L-BFGS refinement of one acquisition point calls bobe_gp_wip_grad dozens of times with one Z
@@ -370,6 +382,7 @@ struct bobe_gp {
   void copy_out_matrix(const double* src, double* dst, int lower_only);
   void get_chol(double* L, double* alpha_out);
   void set_chol(const double* L, const double* alpha_in);
+  double min_pivot_root();
   void kinv_debug(double* Kinv);
   double time_potrf(int reps);
   double time_potrf_batch(int B, int reps);

@@ -16,8 +16,7 @@ void configure_sweep_kernels() {
   allow_big_lds(k_trimul_t, GEMM_SMEM_BYTES);
   allow_big_lds(k_trimul_v64, GEMM64_SMEM_BYTES);
   allow_big_lds(k_trimul_t64, GEMM64_SMEM_BYTES);
-  allow_big_lds(k_trimul_resid, GEMM_SMEM_BYTES);
-  allow_big_lds(k_trimul_add, GEMM_SMEM_BYTES);
+  allow_big_lds(k_blk_step, GEMM_SMEM_BYTES);
   allow_big_lds(k_cross_vv<128>, GEMM_SMEM_BYTES);
   allow_big_lds(k_cross_vv<64>, GEMM64_SMEM_BYTES);
   done[dev] = true;
@@ -27,27 +26,38 @@ void configure_sweep_kernels() {
 void bobe_gp::decide_refinement(double min_diag) {
   const double piv = min_diag * min_diag;
   refine_v = refine_kappa >= 0.0 && piv > 0.0 && (hyp.kvar + hyp.noise) / piv > refine_kappa;
-  if (refine_v) {                       // (k_trimul_resid multiplies with L's diagonal blocks as they lie in A)
-    hipLaunchKernelGGL(k_zero_upper_diag, dim3((unsigned)nb), dim3(256), 0, stream, A.d(), Np);
-    LAUNCH_CHECK();
-  }
 }
 
 void bobe_gp::solve_v(double* B, int64_t ldb, int64_t ncp, double* V, int64_t ldv, double* qp, int64_t ldq) {
-  const dim3 grid((unsigned)(ncp / TILE), (unsigned)nb);
   if (!refine_v) {
-    hipLaunchKernelGGL(k_trimul, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)Linv.d(), Np, nb, (const double*)B,
-                       ldb, V, ldv, qp, ldq, (const double*)nullptr, (int64_t)0, 0, (double*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(k_trimul, dim3((unsigned)(ncp / TILE), (unsigned)nb), dim3(256), GEMM_SMEM_BYTES, stream,
+                       (const double*)Linv.d(), Np, nb, (const double*)B, ldb, V, ldv, qp, ldq, (const double*)nullptr,
+                       (int64_t)0, 0, (double*)nullptr, (int64_t)0);
     return;
   }
-  if (!V) throw Err(BOBE_ERR_STATE, "solve_v: the refined product needs a buffer for V");
-  hipLaunchKernelGGL(k_trimul, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)Linv.d(), Np, nb, (const double*)B,
-                     ldb, V, ldv, (double*)nullptr, (int64_t)0, (const double*)nullptr, (int64_t)0, 0, (double*)nullptr,
-                     (int64_t)0);
-  hipLaunchKernelGGL(k_trimul_resid, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)A.d(), Np, nb, (const double*)V,
-                     ldv, B, ldb);
-  hipLaunchKernelGGL(k_trimul_add, grid, dim3(256), GEMM_SMEM_BYTES, stream, (const double*)Linv.d(), Np, nb, (const double*)B,
-                     ldb, V, ldv, qp, ldq);
+  if (!V) throw Err(BOBE_ERR_STATE, "solve_v: the blocked substitution needs a buffer for V");
+  // Blocked forward substitution (sweep_kernels.hpp, k_blk_step) on two levels.  Panels of `pt` row tiles: ONE long launch
+  // applies every finished row to the panel (K = all rows above it: the bulk of the flops, pt x ncp/128 tiles); inside the
+  // panel, diagonal blocks of `bt` row tiles are solved one after the other, each followed by a short launch that applies it
+  // to the panel's remaining rows.  Accuracy is set by bt alone (the height of the blocks that meet an explicit inverse),
+  // speed by pt.  B is overwritten by the right-hand sides of the diagonal solves.
+  const int bt = std::max(1, solve_block / TILE);
+  const int pt = std::max(bt, (int)(solve_panel / TILE) / bt * bt);
+  const double* Lf = A.d();
+  const double* Li = Linv.d();
+  auto step = [&](int u_r0, int u_rows, int u_k0, int u_k1, int s_r0, int s_rows) {
+    hipLaunchKernelGGL(k_blk_step, dim3((unsigned)(ncp / TILE), (unsigned)(u_rows + s_rows)), dim3(256), GEMM_SMEM_BYTES,
+                       stream, Lf, Li, Np, B, ldb, V, ldv, qp, ldq, u_r0, u_rows, u_k0, u_k1, s_r0, s_rows);
+  };
+  for (int p0 = 0; p0 < nb; p0 += pt) {
+    const int p1 = std::min(nb, p0 + pt);
+    if (p0 > 0) step(p0, p1 - p0, 0, p0, 0, 0);                    // panel rows -= L[., 0:p0] V[0:p0]
+    for (int t0 = p0; t0 < p1; t0 += bt) {
+      const int t1 = std::min(p1, t0 + bt);
+      step(0, 0, 0, 0, t0, t1 - t0);                               // V[t0:t1] = inv(L_tt) B[t0:t1]
+      if (t1 < p1) step(t1, p1 - t1, t0, t1, 0, 0);                // the panel's remaining rows -= L[., t0:t1] V[t0:t1]
+    }
+  }
 }
 
 // Z-side quantities of the sweep: ZsT, kXZ, V_Z = Linv kXZ, base_z = kself - |V_Z[:,z]|^2 and - for the score gradients
@@ -117,7 +127,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   const bool need_s = wipstd || argmin_s || min_s;
   const double* cin = fetch(cand, (size_t)C * d, in_stage);
   if (do_wip) prepare_z(Z, M, Mp, false);
-  const int64_t CH = chunk;
+  const int64_t CH = (refine_v && solve_chunk > 0) ? solve_chunk : chunk;   // (BOBE_SOLVE_CHUNK: speed only)
   // scoring runs once per super-chunk of SC candidates (bounded crossT workspace: Mp x SC doubles)
   const int64_t SC = round_up(std::min<int64_t>(C, std::max<int64_t>(CH, 65536)), CH);
   CsT.ensure((size_t)d * SC * sizeof(double));
@@ -128,8 +138,8 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   if (do_wip) pv.ensure((size_t)Mp * SC * sizeof(double));                   // crossT
   if (do_wip || refine_v) vxc.ensure((size_t)Np * CH * sizeof(double));      // V = Linv K(X, chunk)
   // The cross-covariance tiles of a chunk ride in the launch that solves the NEXT chunk (k_trimul), so V alternates
-  // between two buffers; the last chunk of a super-chunk gets a launch of its own (k_cross_vv).  The refined path keeps
-  // its three launches per chunk and a separate cross launch.
+  // between two buffers; the last chunk of a super-chunk gets a launch of its own (k_cross_vv).  The blocked substitution of
+  // an ill-conditioned factor (solve_v) is followed by a separate cross launch per chunk.
   const bool fuse_cross = do_wip && !refine_v && C > CH;
   if (fuse_cross) vxc2.ensure((size_t)Np * CH * sizeof(double));
   double* vbuf[2] = {vxc.d(), fuse_cross ? vxc2.d() : vxc.d()};
@@ -308,7 +318,7 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
     hipLaunchKernelGGL((k_wg_col<KE, DC>), dim3((unsigned)(Np / 256 + 1), (unsigned)C), dim3(256), 0, stream,           \
                        (const double*)XsT.d(), Np, N, Np, cin, h, kc);                                                 \
     solve_alpha(li, vv, uu, part.d(), (int)C, 0, Np, (int64_t)nb * Np, (const double*)kc, Np);                             \
-    if (refine_v) {   /* v += Linv (k - L v), u += Linv^T of the same correction (sweep_kernels.hpp, k_trimul_resid) */   \
+    if (refine_v) {   /* one step of iterative refinement in vector form: v += Linv (k - L v), u += Linv^T of the same */   \
       const unsigned gv_ = (unsigned)((n_vec + 255) / 256);                                                              \
       hipLaunchKernelGGL(k_gemv_lower, dim3((unsigned)(Np / 4), (unsigned)C), dim3(256), 0, stream, (const double*)A.d(), \
                          Np, Np, (const double*)vv, t1, (int64_t)0, Np, Np);                                             \
@@ -611,12 +621,7 @@ int bobe_gp::append(const double* X_new, int64_t b, const double* y_all) {
   LAUNCH_CHECK();
   scale(X.d(), N1, Np, hyp, XsT.d(), Np);                                    // all points again
   solve_alpha(Linv.d(), w.d(), alpha.d(), part.d());                     // alpha = Linv^T Linv y
-  hipLaunchKernelGGL(k_mll_terms, dim3(1), dim3(256), 0, stream, (const double*)w.d(), (const double*)A.d(), Np, Np, res.d(),
-                     (int64_t)0, (int64_t)0, (int64_t)0, (const int*)nullptr);     // (the grown factor's smallest pivot)
-  LAUNCH_CHECK();
-  HIPCHK(hipMemcpyAsync(h_res, res.p, 102 * sizeof(double), hipMemcpyDeviceToHost, stream));
-  sync();                               // (s22 / hG are host temporaries of this call)
-  decide_refinement(h_res[101]);
+  decide_refinement(min_pivot_root());  // (the grown factor's smallest pivot; synchronises: s22 / hG are host temporaries)
   } catch (...) {
     nx.release();
     oa.release();

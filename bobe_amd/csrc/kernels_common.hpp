@@ -298,11 +298,11 @@ static __global__ void k_colsum_parts(const double* __restrict__ part, int64_t l
 }
 
 // ---- scalar reductions ------------------------------------------------------------------------------
-// res[0] = sum_i w_i^2 ; res[1] = sum_i log L_ii ; res[101] = min_i L_ii        (single workgroup, fixed order)
+// res[0] = sum_i w_i^2 (0 without w) ; res[1] = sum_i log L_ii ; res[101] = min_i L_ii        (single workgroup, fixed order)
 __device__ __forceinline__ void mll_terms_body(int slot, const double* __restrict__ w, const double* __restrict__ L, int64_t ld,
                                                    int64_t np, double* __restrict__ res, int64_t bsW,
                                                    int64_t bsL, int64_t bsR, const int* __restrict__ info) {
-  w += slot * bsW;      // batched: blockIdx.x = slot
+  if (w) w += slot * bsW;      // batched: blockIdx.x = slot
   L += slot * bsL;
   res += slot * bsR;
   // (the factorisation's info word rides along in res[100], so that one copy brings everything to the host)
@@ -311,7 +311,7 @@ __device__ __forceinline__ void mll_terms_body(int slot, const double* __restric
   double a = 0.0, b = 0.0, mn = 1.0;                  // (the padding's diagonal is 1)
   for (int64_t i = threadIdx.x; i < np; i += 256) {
     const double lii = L[i * ld + i];
-    a += w[i] * w[i];
+    if (w) a += w[i] * w[i];
     b += log(lii);
     mn = (lii < mn || lii != lii) ? lii : mn;     // (fmin would drop a NaN diagonal: NaN counts as failed)
   }

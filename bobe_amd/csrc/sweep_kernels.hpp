@@ -58,56 +58,50 @@ __global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Li
   }
 }
 
-// ---- one step of iterative refinement of V = L^-1 B with the factor itself --------------------------------------------
-// The product Linv * B is not a backward-stable solve: its error is eps |Linv| |B|, far above eps |V| when K(X, .) lies in
-// the span of K's large eigenvectors - which it does for a smooth kernel.  The posterior variance tolerates that, the
+// ---- V = L^-1 B as a BLOCKED FORWARD SUBSTITUTION (the reference's solve_triangular, gp.py:462, 484, 571) -----------------
+// The product Linv * B (k_trimul) is not a backward-stable solve: its error is eps |Linv| |B|, far above eps |V| when K(X, .)
+// lies in the span of K's large eigenvectors - which it does for a smooth kernel.  The posterior variance tolerates that, the
 // fantasy variance base_z - cross^2 / s_c does not: it is a difference of quantities that are each exact only for a
 // CONSISTENTLY perturbed factor.  Measured at the reference's default noise of 1e-8 on a BO design of 1800 points
-// (profiles/r05_conditioning.txt): kernel variance 4.67e4 (cond K ~3e14) WIPV 1.3e-2 off the extended-precision value,
-// 3.5e5 1.0 off; a triangular solve with the same L: 6e-5 / 2e-3; ONE refinement step V += Linv (B - L V): 6e-5 / 7e-4.
-// Two more triangular GEMMs per chunk, so the step runs only where it is needed (bobe_gp::refine_v: (kvar + noise) /
-// smallest pivot above BOBE_REFINE_KAPPA, default 1e6 - where the plain product's error in the scores, ~8e-14 x that ratio,
-// reaches the 1e-7 of the stated fp64 tolerance; the benchmark configurations sit at 7 ... 3e5).
-//   k_trimul_resid : B[i][c] <- B[i][c] - sum_{k<=i} L[i][k] V[k][c]     (row tile ti = nb-1-y, in place over B)
-//   k_trimul_add   : V[i][c] <- V[i][c] + sum_{k<=i} Linv[i][k] R[k][c], qpart[ti*ldq + c] = column sums of squares of
-//                    the new V over the tile's rows (k_trimul's epilogue)
-// L's diagonal 128-blocks must hold zeros above the diagonal (k_zero_upper_diag; the factorisation leaves them alone).
-__global__ __launch_bounds__(256, 2) void k_trimul_resid(const double* __restrict__ L, int64_t ldl, int nb,
-                                                         const double* __restrict__ V, int64_t ldv,
-                                                         double* __restrict__ B, int64_t ldb) {
+// (profiles/r06_conditioning.txt): kernel variance 4.67e4 (cond K ~3e14) WIPV 1.3e-2 off the extended-precision value, 3.5e5
+// 1.0 off; LAPACK's triangular solve with its own factor 1.8e-4 / 1.5e-2.  So where the factor is ill conditioned
+// (bobe_gp::refine_v: (kvar + noise) / smallest pivot above BOBE_REFINE_KAPPA, default 1e6 - where the plain product's error
+// in the scores, ~8e-14 x that ratio, reaches the 1e-7 of the stated fp64 tolerance; the benchmark configurations sit at 7 ...
+// 3e5) V is SOLVED for, block row by block row, top to bottom:
+//     V_t = inv(L_tt) (B_t - sum_{j<t} L_tj V_j),      diagonal blocks of `bs` = 128 * bt rows.
+// The diagonal bs-blocks of the inverse factor the handle already holds ARE inv(L_tt); everything off the diagonal blocks is
+// multiplied by L itself, so the error is eps |L| |V| plus eps cond(L_tt) per block: with bs = 128 4.8e-5 / 2.5e-3 on the two
+// rungs above, at or below LAPACK's on every rung and quantity of the ladder (256 and 512 lose the fantasy variance from
+// kernel variances of 8.5e5 / 3.5e5 on: cond(L_tt) grows with the block).  N^2 flops per column like ONE k_trimul.  Round 5's
+// form of the same repair - one step of iterative refinement V += Linv (B - L V), three triangular GEMMs - was 60.6 ms per
+// headline-sized sweep against 29.8 this way (profiles/r06_solve_block_ab_headline.txt) and no more accurate; removed.
+// One launch of this kernel carries up to two kinds of row tiles (grid.y; grid.x = column tile):
+//   y <  u_rows : update tile ti = u_r0 + y:            B[ti] <- B[ti] - L[ti, u_k0:u_k1] V[u_k0:u_k1]     (in place)
+//   y >= u_rows : solve tile  ti = s_r0 + s_rows-1-(..): V[ti] <- Linv[ti, s_r0*128 : (ti+1)*128] B[same rows]
+//                 + k_trimul's epilogue (qpart[ti*ldq + c] = the tile's column sums of squares)
+// The update tiles of a launch never touch the rows its solve tiles read (host: bobe_gp::solve_v).
+__global__ __launch_bounds__(256, 2) void k_blk_step(const double* __restrict__ L, const double* __restrict__ Linv,
+                                                     int64_t ld, double* __restrict__ B, int64_t ldb,
+                                                     double* __restrict__ V, int64_t ldv, double* __restrict__ qpart,
+                                                     int64_t ldq, int u_r0, int u_rows, int u_k0, int u_k1, int s_r0,
+                                                     int s_rows) {
   extern __shared__ double smem[];
   const int tc = blockIdx.x;
-  const int ti = nb - 1 - (int)blockIdx.y;
   v4d acc[4][4];
   acc_zero(acc);
-  gemm_tile<KC, RC, TILE, TILE, BK128, false, WgSync, true>(acc, L, ldl, (int64_t)ti * TILE, V, ldv, (int64_t)tc * TILE, 0,
-                                                            (int64_t)(ti + 1) * TILE, smem);
-  store_tile(acc, B, ldb, (int64_t)ti * TILE, (int64_t)tc * TILE, -1.0, 1.0);
-}
-
-__global__ __launch_bounds__(256, 2) void k_trimul_add(const double* __restrict__ Linv, int64_t ldi, int nb,
-                                                       const double* __restrict__ Rm, int64_t ldr, double* __restrict__ V,
-                                                       int64_t ldv, double* __restrict__ qpart, int64_t ldq) {
-  extern __shared__ double smem[];
-  const int tc = blockIdx.x;
-  const int ti = nb - 1 - (int)blockIdx.y;
-  v4d acc[4][4];
-  acc_zero(acc);
-  gemm_tile<KC, RC, TILE, TILE, BK128, false, WgSync, true>(acc, Linv, ldi, (int64_t)ti * TILE, Rm, ldr, (int64_t)tc * TILE, 0,
-                                                            (int64_t)(ti + 1) * TILE, smem);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* q = V + ((int64_t)ti * TILE + acc_row(i, r)) * ldv + (int64_t)tc * TILE + acc_col(j);
-        acc[i][j][r] += *q;
-        *q = acc[i][j][r];
-      }
+  if ((int)blockIdx.y < u_rows) {
+    const int ti = u_r0 + (int)blockIdx.y;
+    gemm_tile<KC, RC>(acc, L, ld, (int64_t)ti * TILE, V, ldv, (int64_t)tc * TILE, (int64_t)u_k0 * TILE,
+                      (int64_t)u_k1 * TILE, smem);
+    store_tile(acc, B, ldb, (int64_t)ti * TILE, (int64_t)tc * TILE, -1.0, 1.0);
+    return;
+  }
+  const int ti = s_r0 + s_rows - 1 - ((int)blockIdx.y - u_rows);
+  gemm_tile<KC, RC, TILE, TILE, BK128, false, WgSync, true>(acc, Linv, ld, (int64_t)ti * TILE, B, ldb, (int64_t)tc * TILE,
+                                                            (int64_t)s_r0 * TILE, (int64_t)(ti + 1) * TILE, smem);
+  store_tile(acc, V, ldv, (int64_t)ti * TILE, (int64_t)tc * TILE, 1.0, 0.0);
   if (qpart) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    __syncthreads();                 // (the K loop's last LDS reads are behind every wave before the image is reused)
     double* red = smem;  // [2][128]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -122,15 +116,6 @@ __global__ __launch_bounds__(256, 2) void k_trimul_add(const double* __restrict_
     }
     __syncthreads();
     if (t < TILE) qpart[(int64_t)ti * ldq + (int64_t)tc * TILE + t] = red[t] + red[TILE + t];
-  }
-}
-
-// zeros above the diagonal of every diagonal 128-block of a lower factor (grid = nb)
-__global__ __launch_bounds__(256) void k_zero_upper_diag(double* __restrict__ A, int64_t ld) {
-  double* blk = A + ((int64_t)blockIdx.x * TILE) * ld + (int64_t)blockIdx.x * TILE;
-  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
-    const int r = e / TILE, c = e % TILE;
-    if (c > r) blk[(int64_t)r * ld + c] = 0.0;
   }
 }
 

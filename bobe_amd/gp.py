@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import List, Optional
 
 import numpy as np
@@ -44,8 +45,12 @@ def saas_prior_logprob(lengthscales, kernel_variance, tausq):
 _KERNEL_HANDLES: dict = {}
 
 
+_FREE_LOCK = threading.RLock()     # the module-level functions share handles: one caller at a time
+
+
 def _free_handle(kernel_id: int, d: int, device: int = 0):
-    """The cached data-less handle per (kernel, d, device) behind the module-level functions."""
+    """The cached data-less handle per (kernel, d, device) behind the module-level kernel / distance functions (they hold
+    O(n1 n2) scratch only).  Callers hold ``_FREE_LOCK`` for the duration of the library call."""
     lib = _lib.load()
     key = (kernel_id, d, device)
     if key not in _KERNEL_HANDLES:
@@ -55,15 +60,34 @@ def _free_handle(kernel_id: int, d: int, device: int = 0):
     return lib, _KERNEL_HANDLES[key]
 
 
+class _scratch_handle:
+    """A data-less handle for ONE call of a matrix-input function (``gp_mll``, ``fast_update_cholesky``): the library sizes a
+    factorisation workspace of several n^2 doubles for it, which goes back to the device when the call is over."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+
+    def __enter__(self):
+        self.lib = _lib.load()
+        self.h = C.c_void_p(0)
+        _lib.check(self.lib.bobe_gp_create(C.byref(self.h), self.device, KERNEL_IDS["rbf"], 1), "bobe_gp_create")
+        return self.lib, self.h
+
+    def __exit__(self, *exc):
+        self.lib.bobe_gp_destroy(self.h)
+        return False
+
+
 def dist_sq(x, y):
     """gp.py:80-96: squared Euclidean distances (n1, n2) of the rows of ``x`` and ``y``, on the GPU (bobe_gp_dist_sq)."""
     x = _lib.as_f64(np.atleast_2d(x))
     y = _lib.as_f64(np.atleast_2d(y))
     if x.shape[1] != y.shape[1]:
         raise ValueError("x and y must have the same number of columns")
-    lib, h = _free_handle(KERNEL_IDS["rbf"], x.shape[1])
     out = np.empty((x.shape[0], y.shape[0]))
-    _lib.check(lib.bobe_gp_dist_sq(h, _lib.ptr(x), x.shape[0], _lib.ptr(y), y.shape[0], _lib.ptr(out)), "bobe_gp_dist_sq")
+    with _FREE_LOCK:
+        lib, h = _free_handle(KERNEL_IDS["rbf"], x.shape[1])
+        _lib.check(lib.bobe_gp_dist_sq(h, _lib.ptr(x), x.shape[0], _lib.ptr(y), y.shape[0], _lib.ptr(out)), "bobe_gp_dist_sq")
     return out
 
 
@@ -75,9 +99,9 @@ def gp_mll(k, train_y, num_points):
     n = int(num_points)
     if k.shape != (n, n) or y.shape[0] != n:
         raise ValueError(f"k must be ({n}, {n}) and train_y must hold {n} values")
-    lib, h = _free_handle(KERNEL_IDS["rbf"], 1)
     mll = C.c_double(0.0)
-    _lib.check(lib.bobe_gp_mll_from_k(h, _lib.ptr(k), n, _lib.ptr(y), C.byref(mll)), "bobe_gp_mll_from_k")
+    with _scratch_handle() as (lib, h):
+        _lib.check(lib.bobe_gp_mll_from_k(h, _lib.ptr(k), n, _lib.ptr(y), C.byref(mll)), "bobe_gp_mll_from_k")
     return float(mll.value)
 
 
@@ -89,11 +113,11 @@ def fast_update_cholesky(L, k, k_self):
     k = _lib.as_f64(k).reshape(-1)
     if L.shape != (n, n) or k.shape[0] != n:
         raise ValueError("L must be (n, n) and k must hold n values")
-    lib, h = _free_handle(KERNEL_IDS["rbf"], 1)
     v = np.empty(n)
     diag = C.c_double(0.0)
-    _lib.check(lib.bobe_gp_chol_row_update(h, _lib.ptr(L), n, _lib.ptr(k), _tofloat(k_self), _lib.ptr(v), C.byref(diag)),
-               "bobe_gp_chol_row_update")
+    with _scratch_handle() as (lib, h):
+        _lib.check(lib.bobe_gp_chol_row_update(h, _lib.ptr(L), n, _lib.ptr(k), _tofloat(k_self), _lib.ptr(v), C.byref(diag)),
+                   "bobe_gp_chol_row_update")
     new_L = np.zeros((n + 1, n + 1))
     new_L[:n, :n] = L
     new_L[n, :n] = v
@@ -106,14 +130,15 @@ def _kernel_on_gpu(kernel_id: int, xa, xb, lengthscales, kernel_variance, noise,
     xa = _lib.as_f64(np.atleast_2d(xa))
     xb = _lib.as_f64(np.atleast_2d(xb))
     d = xa.shape[1]
-    lib, handle = _free_handle(kernel_id, d, device)
     ls = _lib.as_f64(lengthscales).reshape(-1)
     if ls.size == 1 and d > 1:
         ls = np.full(d, float(ls[0]))
     out = np.empty((xa.shape[0], xb.shape[0]))
-    _lib.check(lib.bobe_gp_kernel(handle, _lib.ptr(xa), xa.shape[0], _lib.ptr(xb), xb.shape[0],
-                                  _lib.ptr(ls), float(kernel_variance), float(noise), 1 if include_noise else 0,
-                                  _lib.ptr(out)), "bobe_gp_kernel")
+    with _FREE_LOCK:
+        lib, handle = _free_handle(kernel_id, d, device)
+        _lib.check(lib.bobe_gp_kernel(handle, _lib.ptr(xa), xa.shape[0], _lib.ptr(xb), xb.shape[0],
+                                      _lib.ptr(ls), float(kernel_variance), float(noise), 1 if include_noise else 0,
+                                      _lib.ptr(out)), "bobe_gp_kernel")
     return out
 
 
@@ -138,9 +163,11 @@ class GP:
                  kernel_variance_bounds=[1e-4, 1e8], lengthscale_bounds=[0.01, 5], lengthscales=None,
                  kernel_variance=None, kernel_variance_prior=None, lengthscale_prior=None, tausq=None,
                  tausq_bounds=[1e-4, 1e4], param_names: Optional[List[str]] = None, device: int = 0,
-                 _factor: bool = True):
-        """Same keywords as BOBE/gp.py:201-203 plus ``device`` (HIP device index).  ``_factor=False`` (internal) leaves
-        the factorisation to the caller, which is about to install a known one (``from_state_dict``, ``copy``)."""
+                 pivot_floor_ulp: Optional[float] = None, _factor: bool = True):
+        """Same keywords as BOBE/gp.py:201-203 plus ``device`` (HIP device index) and ``pivot_floor_ulp`` (None: the
+        library's default, 0 = the reference's rule - a factorisation fails only on a pivot <= 0, gp.py:175, 549; 64 is
+        what ``BOBE(...)`` passes, see the property).  ``_factor=False`` (internal) leaves the factorisation to the caller,
+        which is about to install a known one (``from_state_dict``, ``copy``)."""
         self._lib = _lib.load()
         self._h = C.c_void_p(0)
         self.device = int(device)
@@ -181,6 +208,8 @@ class GP:
         self._pushed_hyper = None              # hyper-parameters of the factor on the device (set by _push_hyper)
         self.not_pd = False
         self._rank_test_noted = False
+        if pivot_floor_ulp is not None:
+            self.pivot_floor_ulp = pivot_floor_ulp
         self._push_data()
         if _factor:
             self.recompute_cholesky()                                           # gp.py:257-260
@@ -417,14 +446,15 @@ class GP:
         if not self._rank_test_noted and "rank test" in _lib.last_error():
             self._rank_test_noted = True
             log.warning(f"{_lib.last_error()} at kernel variance {self.kernel_variance:.3g}, noise {self.noise:.3g}: "
-                        "treated as not positive definite (NaN).  GP.pivot_floor_ulp = 0 (or BOBE_PIVOT_FLOOR_ULP=0) "
-                        "restores the reference's sign-only test.")
+                        "treated as not positive definite (NaN).  pivot_floor_ulp = 0 (GP attribute, or "
+                        "BOBE(gp_kwargs={'pivot_floor_ulp': 0})) restores the reference's sign-only test.")
 
     @property
     def refine_kappa(self) -> float:
-        """Threshold of the refined products with the inverse factor (include/bobe_gp.h, bobe_gp_set_refine_kappa): one
-        step of iterative refinement where (kernel_variance + noise) / smallest pivot exceeds it.  1e6 by default, 0 =
-        always, negative = never; takes effect at the next factorisation."""
+        """Where (kernel_variance + noise) / smallest pivot of the factor exceeds this, v = L^-1 k is solved for by blocked
+        forward substitution (the reference's ``solve_triangular``, gp.py:462, 484, 571) instead of multiplied out with the
+        inverse factor (include/bobe_gp.h, bobe_gp_set_refine_kappa).  1e6 by default, 0 = always, negative = never; takes
+        effect at the next factorisation."""
         k = C.c_double()
         _lib.check(self._lib.bobe_gp_get_refine(self._h, C.byref(k), None), "bobe_gp_get_refine")
         return float(k.value)
@@ -434,16 +464,28 @@ class GP:
         _lib.check(self._lib.bobe_gp_set_refine_kappa(self._h, float(kappa)), "bobe_gp_set_refine_kappa")
 
     @property
+    def solve_block(self) -> int:
+        """Rows of the diagonal blocks of that substitution (a positive multiple of 128, default 128: the accuracy of
+        LAPACK's triangular solve or better; include/bobe_gp.h, bobe_gp_set_solve_block)."""
+        return int(self._lib.bobe_gp_get_solve_block(self._h))
+
+    @solve_block.setter
+    def solve_block(self, rows: int) -> None:
+        _lib.check(self._lib.bobe_gp_set_solve_block(self._h, int(rows)), "bobe_gp_set_solve_block")
+
+    @property
     def refining(self) -> bool:
-        """Whether the current factor's products with the inverse factor take the refinement step."""
+        """Whether the current factor counts as ill conditioned: v = L^-1 k is solved for, not multiplied out."""
         a = C.c_int()
         _lib.check(self._lib.bobe_gp_get_refine(self._h, None, C.byref(a)), "bobe_gp_get_refine")
         return bool(a.value)
 
     @property
     def pivot_floor_ulp(self) -> float:
-        """The rank test's factor (include/bobe_gp.h, "Conventions"): 64 by default, 0 = the reference's rule (only a
-        pivot <= 0 fails, as LAPACK's dpotrf reports it).  Takes effect at the next factorisation / MLL evaluation."""
+        """The rank test's factor (include/bobe_gp.h, "Conventions"): 0 by default = the reference's rule (only a pivot <= 0
+        fails, as LAPACK's dpotrf reports it, gp.py:175, 549); u > 0: a positive pivot below u machine epsilons of k(x,x) +
+        noise fails too (``BOBE(...)`` runs its surrogate with 64).  Takes effect at the next factorisation / MLL
+        evaluation."""
         return float(self._lib.bobe_gp_get_pivot_floor_ulp(self._h))
 
     @pivot_floor_ulp.setter

@@ -140,8 +140,9 @@ def _minimize_concurrently(batch_fun: Callable, starts: np.ndarray, has_grad: bo
 # for a value, the pending points go to ``batch_fun`` in one call, the values are handed back.  No condition variables, no
 # GIL hand-offs between R threads: at the sizes of the BO loop (N = 100 ... 1200), where an evaluation is a ~100 us
 # graph replay, those cost more than the evaluation itself.  This is the loop of scipy.optimize._lbfgsb_py
-# ._minimize_lbfgsb (SciPy 1.15), statement for statement, per restart; it uses a private SciPy module, so it is verified
-# against ``minimize`` on a quadratic at first use and the thread driver above stays as the fallback.
+# ._minimize_lbfgsb (as of SciPy 1.15), statement for statement, per restart; it uses a private SciPy module, so the
+# routine's argument list is checked (``_setulb_mismatch``) and the loop is verified against ``minimize`` on a quadratic at
+# first use; the thread driver above stays as the fallback.
 # --------------------------------------------------------------------------------------------------------------
 _RC_STATE = {"checked": False, "ok": False}
 
@@ -272,18 +273,48 @@ def lbfgs_driver() -> str:
     return "stepped" if _rc_available() else "threads"
 
 
+_SETULB_ARGS = ("m", "x", "l", "u", "nbd", "f", "g", "factr", "pgtol", "wa", "iwa", "task", "lsave", "isave", "dsave", "maxls",
+                "ln_task")
+
+
+def _setulb_mismatch() -> Optional[str]:
+    """None when SciPy's reverse-communication routine takes the arguments ``_RcRun.advance`` hands it, else the reason.
+    What is tested is the routine itself - its name, its argument list as its docstring states it, the two message
+    tables ``_RcRun.result`` reads - not SciPy's version text: any release that keeps them takes the stepped driver (and
+    still has to reproduce ``minimize`` bit for bit in the self-check below)."""
+    try:
+        from scipy.optimize import _lbfgsb, _lbfgsb_py
+    except Exception as e:
+        return f"scipy.optimize._lbfgsb is not importable ({e})"
+    fn = getattr(_lbfgsb, "setulb", None)
+    if fn is None:
+        return "scipy.optimize._lbfgsb has no setulb"
+    doc = (getattr(fn, "__doc__", None) or "").strip().splitlines()
+    head = doc[0].replace(" ", "") if doc else ""
+    # "setulb(m,x,...,ln_task)" (the C routine of SciPy >= 1.15) - an f2py wrapper writes "... = setulb(m,x,...,[n,...])"
+    if "setulb(" not in head or ")" not in head:
+        return "setulb states no argument list"
+    args = head[head.index("setulb(") + len("setulb("):head.rindex(")")]
+    required = tuple(a for a in args.split("[")[0].split(",") if a)
+    if required != _SETULB_ARGS:
+        return f"setulb takes ({', '.join(required)}), the stepped driver was written for ({', '.join(_SETULB_ARGS)})"
+    if not (hasattr(_lbfgsb_py, "status_messages") and hasattr(_lbfgsb_py, "task_messages")):
+        return "scipy.optimize._lbfgsb_py has no status_messages / task_messages"
+    return None
+
+
 def _rc_available() -> bool:
-    """The private routine is there, has the signature this file was written against, and the stepped loop reproduces
-    ``minimize`` exactly on a bounded quadratic (checked once per process)."""
+    """The private routine is there, takes the arguments this file hands it (``_setulb_mismatch``), and the stepped loop
+    reproduces ``minimize`` exactly on a bounded quadratic (checked once per process)."""
     if _RC_STATE["checked"]:
         return _RC_STATE["ok"]
     _RC_STATE["checked"] = True
     try:
         import scipy
-        if tuple(int(v) for v in scipy.__version__.split(".")[:2]) != (1, 15):
-            log.warning(f"SciPy {scipy.__version__}: the stepped L-BFGS-B driver was written against the private routine of "
-                        "SciPy 1.15 and is switched off; concurrent restarts run one `minimize` per thread (same results, "
-                        "slower at BO-loop sizes)")
+        why = _setulb_mismatch()
+        if why:
+            log.warning(f"SciPy {scipy.__version__}: {why}; the stepped L-BFGS-B driver is switched off and concurrent "
+                        "restarts run one `minimize` per thread (same results, slower at BO-loop sizes)")
             return False
         A = np.array([[3.0, 0.4, 0.1], [0.4, 2.0, -0.3], [0.1, -0.3, 1.5]])
         b = np.array([1.0, -2.0, 0.5])

@@ -15,12 +15,12 @@
  *   - return value: 0 ok; > 0 numerical condition (BOBE_NOT_PD: outputs are NaN, like XLA's
  *     Cholesky, so np.isfinite filters such as optim.py:328,341 keep working); < 0 usage / HIP error,
  *     text in bobe_last_error().  Nothing throws or aborts across this boundary;
- *   - BOBE_NOT_PD is raised by a pivot <= 0 (what LAPACK's dpotrf, the reference's Cholesky, reports) AND by a positive pivot
- *     below 64 ulp of the kernel matrix's diagonal k(x,x) + noise: such a pivot is the rounding of its column's update, the
- *     log-determinant built on it is too small, and a fit is drawn to exactly those hyper-parameters (dpotrf passes or fails
- *     on the last bit there).  With the reference's default noise of 1e-8 this bounds the usable kernel variance near 1e6.
- *     The factor is a per-handle setting (bobe_gp_set_pivot_floor_ulp; process default: BOBE_PIVOT_FLOOR_ULP, else 64);
- *     0 leaves the reference's rule alone (sign test only);
+ *   - BOBE_NOT_PD is raised by a pivot <= 0 or NaN: what LAPACK's dpotrf, the reference's Cholesky (gp.py:175, 549), reports.
+ *     A handle can be told to refuse a positive pivot below `ulp` machine epsilons of the kernel matrix's diagonal k(x,x) +
+ *     noise as well (bobe_gp_set_pivot_floor_ulp; process default BOBE_PIVOT_FLOOR_ULP, else 0 = off): such a pivot is the
+ *     rounding of its column's update, the log-determinant built on it is too small, and a fit is drawn to exactly those
+ *     hyper-parameters (dpotrf passes or fails on the last bit there).  The BO driver (bobe_amd/bo.py) runs its surrogate
+ *     with ulp = 64; at the reference's default noise of 1e-8 that bounds the usable kernel variance near 1e6;
  *   - a handle is not thread-safe; distinct handles are independent (own stream).
  *   - limits: d <= 32.
  */
@@ -162,21 +162,28 @@ int bobe_gp_chol_row_update(bobe_gp_t* gp, const double* L, int64_t n, const dou
                             double* diag);
 
 /* The rank test's factor (see "Conventions"): a positive pivot below `ulp` machine epsilons of k(x,x) + noise counts as
- * not positive definite.  0 = LAPACK's sign test alone (the reference's behaviour); applies to bobe_gp_factor, the
+ * not positive definite.  0 (the default) = LAPACK's sign test alone (the reference's behaviour); applies to bobe_gp_factor, the
  * bobe_gp_mll family and bobe_gp_append of this handle; copied by bobe_gp_clone_state.  get returns -1 for NULL. */
 int bobe_gp_set_pivot_floor_ulp(bobe_gp_t* gp, double ulp);
 double bobe_gp_get_pivot_floor_ulp(bobe_gp_t* gp);
 
-/* Products with the explicit inverse factor (v = Linv k in bobe_gp_predict, _wip_sweep, _fantasy_var, _wip_grad,
- * _predict_grad, _append) take ONE step of iterative refinement with the factor itself, v += Linv (k - L v), when the
- * installed factor's (kernel_variance + noise) / smallest pivot exceeds `kappa`: that restores the accuracy of the
- * reference's triangular solve (gp.py:462, 571) where the plain product loses it - the fantasy variance at the default noise
- * of 1e-8 from kernel variances of ~1e4 (profiles/r05_conditioning.txt) - at three times the GEMM work of those calls.
- * Default: BOBE_REFINE_KAPPA, else 1e6; 0 = always, negative = never.  The decision is taken when a factor is installed
- * (bobe_gp_factor, _set_chol, _append, _clone_state) - set kappa before.  get: either output may be NULL; *active = 1
- * while the current factor's products are refined. */
+/* Where the installed factor is ill conditioned - (kernel_variance + noise) / smallest pivot above `kappa` - the products
+ * with the explicit inverse factor (v = Linv k in bobe_gp_predict, _wip_sweep, _fantasy_var, _wip_grad, _predict_grad,
+ * _append) are replaced by a SOLVE with the factor, as the reference does everywhere (solve_triangular, gp.py:462, 484, 571):
+ * a blocked forward substitution V_t = inv(L_tt) (B_t - sum_{j<t} L_tj V_j) whose diagonal blocks of `rows` rows are the
+ * diagonal blocks of the inverse factor (bobe_gp_wip_grad's path for <= 16 candidates: one step of iterative refinement in
+ * vector form instead).  The plain product loses the fantasy variance at the reference's default noise of 1e-8 from kernel
+ * variances of ~1e4 on; the substitution with rows = 128 is at or below the error of LAPACK's dtrsm on every rung of
+ * profiles/r06_conditioning.txt, at 1.3 x the time of the plain product (N = 4096, 65 536 candidates).
+ * kappa: default BOBE_REFINE_KAPPA, else 1e6; 0 = always, negative = never.  The decision is taken when a factor is
+ * installed (bobe_gp_factor, _set_chol, _append, _clone_state) - set kappa before.  get: either output may be NULL; *active
+ * = 1 while the current factor's products are solved for.
+ * rows: a positive multiple of 128; default BOBE_SOLVE_BLOCK, else 128 (256 / 512 are ~10 % faster and lose the fantasy
+ * variance two decades of kernel variance earlier); copied by bobe_gp_clone_state.  get returns -1 for NULL. */
 int bobe_gp_set_refine_kappa(bobe_gp_t* gp, double kappa);
 int bobe_gp_get_refine(bobe_gp_t* gp, double* kappa, int* active);
+int bobe_gp_set_solve_block(bobe_gp_t* gp, int rows);
+int bobe_gp_get_solve_block(bobe_gp_t* gp);
 
 /* GP.cholesky / GP.alphas (gp.py:259-260; state_dict keys gp.py:626-627): L is N x N lower with
  * zeros above the diagonal, alpha has N entries.  Either may be NULL. */
@@ -320,6 +327,9 @@ int bobe_debug_mfma_peak(int device, int waves_per_simd, double* tflops);
 int bobe_debug_wave_sums(int device, int D, const double* in, double* out);
 /* candidate chunk size of the sweep (multiple of 128); 0 keeps the default */
 int bobe_gp_set_chunk(bobe_gp_t* gp, int64_t chunk);
+/* launch shape of the blocked forward substitution (bobe_gp_set_solve_block), speed only: panel = rows per long update
+ * launch (a multiple of 128), chunk = candidates per launch sequence (0: the sweep's) */
+int bobe_debug_solve_opts(bobe_gp_t* gp, int panel, int64_t chunk);
 
 #ifdef __cplusplus
 }

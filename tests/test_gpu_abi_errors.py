@@ -192,7 +192,12 @@ def test_round5_entry_points_error_contract():
                    lib.bobe_gp_set_pivot_floor_ulp(h, -1.0), lib.bobe_gp_set_pivot_floor_ulp(h, float("nan")),
                    lib.bobe_gp_set_refine_kappa(h, float("nan"))):
             assert rc == ERR_ARG and lib.bobe_last_error(), rc
-        assert lib.bobe_gp_get_pivot_floor_ulp(h) == 64.0
+        assert lib.bobe_gp_get_pivot_floor_ulp(h) == 0.0                       # the reference's sign-only rule
+        assert lib.bobe_gp_get_solve_block(h) == 128 and lib.bobe_gp_get_solve_block(None) == -1
+        for rc in (lib.bobe_gp_set_solve_block(None, 128), lib.bobe_gp_set_solve_block(h, 0), lib.bobe_gp_set_solve_block(h, 100),
+                   lib.bobe_debug_solve_opts(h, 100, 0), lib.bobe_debug_solve_opts(h, 512, 77), lib.bobe_debug_solve_opts(None, 512, 0)):
+            assert rc == ERR_ARG and lib.bobe_last_error(), rc
+        assert lib.bobe_gp_set_solve_block(h, 256) == 0 and lib.bobe_gp_get_solve_block(h) == 256
         assert lib.bobe_gp_get_refine(h, C.byref(kap), C.byref(act)) == 0 and kap.value == 1e6 and act.value == 0
         assert lib.bobe_gp_get_refine(h, None, None) == 0
         # a handle with training data of ANOTHER size refuses the free functions on matrices (ERR_STATE) and stays intact

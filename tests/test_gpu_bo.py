@@ -136,7 +136,7 @@ def test_fit_of_a_surrogate_whose_hyperparameters_no_longer_factorise(caplog):
     n, d = 600, 5
     X = rng.uniform(size=(n, d))
     y = -np.sum((X - 0.4) ** 2, axis=1) - 0.3 * np.prod(X[:, :2], axis=1)
-    gp = GP(X, y, noise=1e-8, lengthscales=np.full(d, 1.0), kernel_variance=10.0)
+    gp = GP(X, y, noise=1e-8, lengthscales=np.full(d, 1.0), kernel_variance=10.0, pivot_floor_ulp=64.0)   # (as BOBE builds it)
     assert not gp.not_pd
     gp.update_hyperparams(np.log(np.append(np.full(d, 3.5), 1e7)))
     assert gp.not_pd and np.all(np.isnan(gp.predict_mean_batched(X[:3])))

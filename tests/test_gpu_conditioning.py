@@ -7,9 +7,10 @@ runs from ~1e9 to beyond 1e16 and no fixed tolerance separates "wrong" from "as 
 implementations are compared on identical inputs:
 
   (i)   the HIP path - which forms v = L^-1 k with an EXPLICIT inverse factor (k_trtri_* -> k_trimul) where the reference
-        does a triangular solve (gp.py:462, 571), plus ONE step of iterative refinement with the factor where the
-        factor's (kvar + noise) / smallest pivot exceeds 1e6 (bobe_gp_set_refine_kappa) - the plain product, recorded
-        beside it as 'raw', loses the fantasy variance from kernel variances of ~5e4 on (WIPV 1e-2 ... 1 off);
+        does a triangular solve (gp.py:462, 571) and switches to a blocked forward substitution with 128-row diagonal
+        blocks (k_blk_step) where the factor's (kvar + noise) / smallest pivot exceeds 1e6 (bobe_gp_set_refine_kappa) -
+        the plain product, recorded beside it as 'raw', loses the fantasy variance from kernel variances of ~5e4 on
+        (WIPV 1e-2 ... 1 off); larger diagonal blocks (256, 512) are recorded below the table;
   (ii)  the oracle's LAPACK / TRSM form (oracle/bobe_oracle.py: dpotrf + dtrsm, what jax.scipy lowers to on CPU);
   (iii) an extended-precision truth (oracle/bobe_oracle_xp.c: x87 long double, 64-bit significand, cross-checked against
         __float128 on the first rung)
@@ -18,7 +19,7 @@ and the assertion is   err(HIP vs truth) <= 4 x err(LAPACK vs truth) + floor   (
 SURVEY.md 8(d), ``TOL`` below) for the log marginal likelihood and its
 gradient, posterior mean and variance, the fantasy variance var+(z|c), the WIPV / WIPStd scores; the chosen candidate
 must be the truth's, or one the truth scores within that error of its best.  The table goes to
-``gpurun_out/r05_conditioning.txt`` (committed as profiles/r05_conditioning.txt).
+``gpurun_out/r06_conditioning.txt`` (committed as profiles/r06_conditioning.txt).
 
 Deviation (vii) (the rank test) is switched OFF for the comparison (``pivot_floor_ulp = 0``: the reference's
 sign-only rule) and its verdict at the default setting is recorded per rung.
@@ -86,6 +87,7 @@ NOISE = 1e-8
 # the floor of the assertion: the fp64 parity tolerances of SURVEY.md 8(d) (|dLML| / |LML| <= 1e-10, gradient 1e-8, mean 1e-8,
 # variance 1e-9 relative ... 1e-7) - an error inside them passes whatever LAPACK's happens to be on a well-conditioned rung
 TOL = {"mll": 1e-10, "grad": 1e-8, "mean": 1e-8, "var": 1e-9, "fantasy": 1e-9, "wipv": 1e-7, "wipstd": 1e-7}
+BLOCKS = [int(b) for b in os.environ.get("BOBE_LADDER_BLOCKS", "256,512").split(",") if b]
 _ROWS = []
 
 
@@ -186,6 +188,20 @@ def test_conditioning_ladder(rung):
             row["hip_wipstd_grad_" + label] = _err(ws, T["wipstd"][idx], np.max(np.abs(T["wipstd"])))
     scales = {"mll": None, "grad": None, "mean": None, "var": kvar + NOISE, "fantasy": kvar + NOISE, "wipv": None,
               "wipstd": None}
+    # the same quantities through the blocked forward substitution (bobe_gp_set_solve_block) at several block heights
+    if hip_ok:
+        keep = gp.solve_block
+        for b in BLOCKS:
+            gp.solve_block = b
+            gp.recompute_cholesky()
+            swb = gp.wip_sweep(cand, Z, want_mean_var=True)
+            fb = gp.fantasy_var(cand, Z) / og.y_std ** 2
+            for q, val in (("var", swb["var"]), ("fantasy", fb), ("wipv", swb["wipv"]), ("wipstd", swb["wipstd"])):
+                row[f"blk{b}_{q}"] = _err(val, T[q], scales[q])
+            row[f"blk{b}_argmin"] = (int(swb["argmin_v"]) == int(np.argmin(T["wipv"])),
+                                     int(swb["argmin_s"]) == int(np.argmin(T["wipstd"])))
+        gp.solve_block = keep
+        gp.recompute_cholesky()
     for q in ("fantasy", "wipv", "wipstd"):
         row["raw_" + q] = _err(raw[q], T[q], scales[q]) if raw is not None else float("nan")
     for q, sc_ in scales.items():
@@ -214,7 +230,7 @@ def test_conditioning_ladder(rung):
 
 
 def _write_table():
-    out = os.environ.get("BOBE_CONDITIONING_OUT", os.path.join("gpurun_out", "r05_conditioning.txt"))
+    out = os.environ.get("BOBE_CONDITIONING_OUT", os.path.join("gpurun_out", "r06_conditioning.txt"))
     try:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
     except OSError:
@@ -227,7 +243,7 @@ def _write_table():
              "# mll / grad / mean / wipv / wipstd: max |delta| / max |truth|;  var / fantasy: max |delta| / (kvar + noise)",
              "# kappa = N kvar / smallest pivot (a lower bound of cond K);  rank64 = the default rank test (64 ulp) refuses the "
              "rung;  argmin columns: picks the truth's candidate (gap = relative score excess of the pick)",
-             "# refine = the HIP path took the refinement step v += Linv (k - L v) (default threshold 1e6); raw_* = the same "
+             "# refine = the HIP path solved for v by blocked forward substitution (default threshold 1e6, 128-row diagonal blocks); raw_* = the same "
              "quantity WITHOUT it (bobe_gp_set_refine_kappa(-1))", ""]
     hdr = f"{'rung':<28}{'kappa':>9}{'minpiv':>9} {'lapack':>6} {'rank64':>6} {'refine':>6} " + " ".join(f"{'hip_' + q:>11}{'lap_' + q:>11}" for q in qs) \
         + f" {'raw_fantasy':>11} {'raw_wipv':>9} {'raw_wipstd':>10} {'argv h/l':>9} {'args h/l':>9} {'gap_v':>8} {'gap_s':>8}"
@@ -239,5 +255,15 @@ def _write_table():
                      f"{str(r['refined']):>6} {cells} {r['raw_fantasy']:>11.2e} {r['raw_wipv']:>9.2e} {r['raw_wipstd']:>10.2e} {str(r.get('hip_argmin_v', '-'))[0]}/{str(r.get('lap_argmin_v', '-'))[0]:<7} "
                      f"{str(r.get('hip_argmin_s', '-'))[0]}/{str(r.get('lap_argmin_s', '-'))[0]:<7} "
                      f"{r.get('gap_argmin_v', float('nan')):>8.1e} {r.get('gap_argmin_s', float('nan')):>8.1e}")
+    lines += ["", "# larger diagonal blocks of the substitution (bobe_gp_set_solve_block = b) on the same rungs, beside the shipped default "
+              "('hip': b = 128) and LAPACK's triangular solve ('lap'); argmin = (WIPV, WIPStd) picks the truth's candidate"]
+    qb = ["var", "fantasy", "wipv", "wipstd"]
+    for r in _ROWS:
+        name = f"N{r['N']}_{r['kernel']}_ls{r['ls0']:g}_kv{r['kvar']:g}"
+        lines.append(f"{name:<28} " + " ".join(f"{'hip_' + q:>8}={r['hip_' + q]:<9.2e}{'lap':>4}={r['lap_' + q]:<9.2e}" for q in qb))
+        for b in BLOCKS:
+            if f"blk{b}_var" in r:
+                lines.append(f"{'  b=' + str(b):<28} " + " ".join(f"{'blk_' + q:>8}={r[f'blk{b}_{q}']:<9.2e}{'':>14}" for q in qb)
+                             + f" argmin {r[f'blk{b}_argmin']}")
     with open(out, "w") as fh:
         fh.write("\n".join(lines) + "\n")

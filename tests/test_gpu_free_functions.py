@@ -2,6 +2,7 @@
 ``dist_sq`` gp.py:80-96, ``gp_mll`` gp.py:170-178, ``fast_update_cholesky`` gp.py:181-197), the rank test's switch
 (``bobe_gp_set_pivot_floor_ulp``, deviation (vii) of DESIGN.md 8) and the unmodified ``BOBE(...).run()`` call."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -78,19 +79,22 @@ def test_prior_helpers_of_the_reference_module():
     assert saas_prior_logprob(ls, 1.3, 0.4) == pytest.approx(float(O.saas_prior_logprob(ls, 1.3, 0.4)), rel=1e-12)
 
 
-def test_rank_test_switch_recovers_the_sign_only_rule(caplog):
-    """Deviation (vii): a positive pivot below 64 ulp of k(x,x) + noise is NOT_PD by default; ``pivot_floor_ulp = 0`` leaves
-    the reference's rule (LAPACK: only a pivot <= 0 fails).  Band between the two: both outcomes are exercised on one
-    matrix, and the sign-only result agrees with LAPACK's dpotrf on the same K."""
+def test_default_is_the_reference_rule_and_the_rank_test_is_opt_in(caplog):
+    """The drop-in class keeps the reference's positive-definiteness rule (gp.py:175, 549: ``jnp.linalg.cholesky`` fails on a
+    pivot <= 0 only, like LAPACK's dpotrf): ``GP(...).pivot_floor_ulp == 0`` with no environment variable.  Deviation (vii),
+    the rank test - a positive pivot below 64 ulp of k(x,x) + noise is NOT_PD - is what ``BOBE(...)`` opts into
+    (``pivot_floor_ulp=64``).  Band between the two rules: both outcomes are exercised on one matrix, and the default's
+    result agrees with LAPACK's dpotrf on the same K."""
     import logging
     from bobe_amd import GP
     from oracle import bobe_oracle as O
+    assert "BOBE_PIVOT_FLOOR_ULP" not in os.environ
     rng = np.random.default_rng(3)
     n, d = 100, 2
     X = rng.uniform(size=(n, d))
     y = np.sin(3 * X[:, 0]) + X[:, 1]
     ls = np.array([1.5, 1.5])
-    # walk the kernel variance up until the default rank test refuses while LAPACK still factors
+    # walk the kernel variance up until the rank test refuses while LAPACK still factors
     found = None
     for kvar in 2.0 ** np.arange(10, 32):
         K = O.rbf_kernel(X, X, ls, kvar, 1e-8, include_noise=True)
@@ -98,48 +102,87 @@ def test_rank_test_switch_recovers_the_sign_only_rule(caplog):
             Lref = sla.cholesky(K, lower=True)
         except sla.LinAlgError:
             break
-        gp = GP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=float(kvar))
+        gp = GP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=float(kvar), pivot_floor_ulp=64.0)
         if gp.not_pd:
             found = (float(kvar), Lref)
             break
     assert found is not None, "no kernel variance in the band between the rank test and LAPACK's sign test"
     kvar, Lref = found
-    caplog.clear()                                             # (the search above logged for its own GPs)
-    with caplog.at_level(logging.WARNING, logger="bobe_amd"):
-        strict = GP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=kvar)
-        strict.recompute_cholesky()
-    assert strict.pivot_floor_ulp == 64.0 and strict.not_pd and np.all(np.isnan(strict.cholesky))
-    assert sum("rank test" in r.getMessage() for r in caplog.records) == 1            # logged, once per GP
     th = np.log(np.append(ls, kvar))
-    assert np.isnan(strict.neg_mll(th))
-    strict.pivot_floor_ulp = 0.0
-    assert strict.pivot_floor_ulp == 0.0
-    strict.recompute_cholesky()
-    assert not strict.not_pd and np.all(np.isfinite(strict.cholesky))
+    # ---- the default: the reference's rule
+    plain = GP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=kvar)
+    assert plain.pivot_floor_ulp == 0.0 and not plain.not_pd and np.all(np.isfinite(plain.cholesky))
     # what the sign-only rule lets through is as good as LAPACK's factor of the same matrix: compare the reconstructions
     K = O.rbf_kernel(X, X, ls, kvar, 1e-8, include_noise=True)
-    Lg = strict.cholesky
+    Lg = plain.cholesky
     err_gpu = np.max(np.abs(Lg @ Lg.T - K)) / kvar
     err_lapack = np.max(np.abs(Lref @ Lref.T - K)) / kvar
     assert err_gpu <= max(8 * err_lapack, n * np.finfo(float).eps)          # (backward-stable: ||L L^T - K|| <= c n eps ||K||)
-    f = strict.neg_mll(th)
+    f = plain.neg_mll(th)
     og = O.OracleGP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=kvar)
     # in this band the log-determinant is built on pivots of rounding noise: the two fp64 factorisations differ in the
     # fourth digit, so each is measured against the extended-precision value (oracle/bobe_oracle_xp.c)
     from oracle import c_binding as CB
     tr = CB.gp_truth(0, X, np.asarray(og.train_y).reshape(-1), ls, kvar, 1e-8, want_grad=False)
-    lp = float(strict.prior_func(ls, kvar))
+    lp = float(plain.prior_func(ls, kvar))
     err_hip, err_lap = abs(-f - lp - tr["mll"]), abs(-og.neg_mll(th) - lp - tr["mll"])
     assert tr["info"] == 0 and np.isfinite(f) and err_hip <= 4 * err_lap + 1e-10 * abs(tr["mll"]), (err_hip, err_lap)
     # the batch / slot paths take the handle's setting too
-    fb = strict.neg_mll_value_and_grad_batch([th, th], want_grad=False)
+    fb = plain.neg_mll_value_and_grad_batch([th, th], want_grad=False)
     assert all(np.isfinite(v[0]) for v in fb)
+    # ---- opted in: refused, logged once per GP, NaN everywhere; switchable on a live GP; travels with copy()
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="bobe_amd"):
+        strict = GP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=kvar, pivot_floor_ulp=64.0)
+        strict.recompute_cholesky()
+    assert strict.pivot_floor_ulp == 64.0 and strict.not_pd and np.all(np.isnan(strict.cholesky))
+    assert sum("rank test" in r.getMessage() for r in caplog.records) == 1
+    assert np.isnan(strict.neg_mll(th))
+    strict.pivot_floor_ulp = 0.0
+    strict.recompute_cholesky()
+    assert not strict.not_pd and np.array_equal(strict.cholesky, plain.cholesky)
     strict.pivot_floor_ulp = 64.0
     assert np.isnan(strict.neg_mll(th))
     with pytest.raises(Exception):
         strict.pivot_floor_ulp = -1.0
-    c = strict.copy()
-    assert c.pivot_floor_ulp == 64.0
+    assert strict.copy().pivot_floor_ulp == 64.0 and plain.copy().pivot_floor_ulp == 0.0
+
+
+def test_large_kernel_variance_at_the_default_noise_gives_lapacks_mll():
+    """``GP`` at kernel variance 3.5e5 and the reference's default noise of 1e-8 on a clustered 10-D design (the regime of the
+    config-5 fits; with the 64-ulp rank test on, the top decades of ``kernel_variance_bounds`` = [1e-4, 1e8], gp.py:202, were
+    NaN): a finite log marginal likelihood, LAPACK's value to the accuracy either has against the extended-precision one."""
+    from bobe_amd import GP
+    from oracle import bobe_oracle as O
+    from oracle import c_binding as CB
+    assert "BOBE_PIVOT_FLOOR_ULP" not in os.environ
+    rng = np.random.default_rng(11)
+    n, d = 700, 10
+    centre = np.full(d, 0.6)
+    X = np.clip(np.vstack([rng.uniform(size=(200, d)), centre + 0.05 * rng.standard_normal((n - 200, d))]), 0.0, 1.0)
+    y = -np.sum((X - centre) ** 2, axis=1) * 40.0
+    ls = np.full(d, 3.0)
+    for kvar in (3.5e5, 3.0e7):
+        K = O.rbf_kernel(X, X, ls, kvar, 1e-8, include_noise=True)
+        try:
+            sla.cholesky(K, lower=True)
+            lapack_ok = True
+        except sla.LinAlgError:
+            lapack_ok = False
+        gp = GP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=kvar)
+        refused = GP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=kvar, pivot_floor_ulp=64.0).not_pd
+        if not lapack_ok:
+            continue                                               # (beyond 1 / eps either factorisation may fail: no claim)
+        assert not gp.not_pd, kvar
+        th = np.log(np.append(ls, kvar))
+        f = gp.neg_mll(th)
+        og = O.OracleGP(X, y, noise=1e-8, lengthscales=ls, kernel_variance=kvar)
+        tr = CB.gp_truth(0, X, np.asarray(og.train_y).reshape(-1), ls, kvar, 1e-8, want_grad=False)
+        lp = float(gp.prior_func(ls, kvar))
+        err_hip, err_lap = abs(-f - lp - tr["mll"]), abs(-og.neg_mll(th) - lp - tr["mll"])
+        assert np.isfinite(f) and err_hip <= 4 * err_lap + 1e-10 * abs(tr["mll"]), (kvar, refused, err_hip, err_lap)
+        if kvar == 3.5e5:
+            assert abs(-f - (-og.neg_mll(th))) <= 1e-6 * abs(tr["mll"])      # the LAPACK-matching value itself
 
 
 def test_sampler_entry_points_refuse_device_pointers():

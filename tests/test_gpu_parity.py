@@ -130,7 +130,8 @@ def test_not_positive_definite_gives_nan_not_exception():
 
 
 def test_numerically_singular_kernel_matrix_counts_as_not_positive_definite():
-    """The factorisation's rank test (gp_handle.hpp, pivot_floor): with the default noise of 1e-8 and a kernel variance
+    """The factorisation's rank test (gp_handle.hpp, pivot_floor; opted into with ``pivot_floor_ulp=64``, as the BO driver
+    does - the GP class alone keeps the reference's sign-only rule): with the default noise of 1e-8 and a kernel variance
     of 1e7 at long length scales every trailing pivot is rounding noise (64 ulp of the diagonal is 1.4e-7 > noise); the
     log-determinant built on them is too small and draws the optimiser in (profiles/r04_config5.txt, section 9).  LAPACK -
     the reference's Cholesky - fails or passes on the last bit there; the library says BOBE_NOT_PD every time: NaN value and
@@ -141,9 +142,9 @@ def test_numerically_singular_kernel_matrix_counts_as_not_positive_definite():
     n, d = 500, 5
     X = rng.uniform(size=(n, d))
     y = -np.sum((X - 0.4) ** 2, axis=1) - 0.3 * np.prod(X[:, :2], axis=1)
-    gp = GP(X, y, noise=1e-8, lengthscales=np.full(d, 0.5), kernel_variance=1.0)
+    gp = GP(X, y, noise=1e-8, lengthscales=np.full(d, 0.5), kernel_variance=1.0, pivot_floor_ulp=64.0)
     og = O.OracleGP(X, y, noise=1e-8, lengthscales=np.full(d, 0.5), kernel_variance=1.0)
-    assert not gp.not_pd
+    assert not gp.not_pd and gp.pivot_floor_ulp == 64.0
     good, bad = (np.full(d, 0.5), 1.0), (np.full(d, 3.5), 1e7)
     m, g = gp.mll_data(*good)
     mo, go = O.cycle_value_and_grad(og.train_x, og.train_y.reshape(-1), good[0], good[1], 1e-8)
@@ -167,7 +168,7 @@ def test_numerically_singular_kernel_matrix_counts_as_not_positive_definite():
     for r2, refused in ((1e-15, True), (1e-12, False)):
         X3 = np.array([[0.3], [0.3 + 0.5 * np.sqrt(r2)], [0.9]])
         y3 = np.array([0.1, 0.1, -1.0])
-        g3 = GP(X3, y3, noise=0.0, lengthscales=[0.5], kernel_variance=1.0)
+        g3 = GP(X3, y3, noise=0.0, lengthscales=[0.5], kernel_variance=1.0, pivot_floor_ulp=64.0)
         assert g3.not_pd == refused
         v3, _ = g3.mll_data(np.array([0.5]), 1.0)
         if refused:

@@ -1,12 +1,13 @@
-"""The refinement step of the products with the inverse factor (include/bobe_gp.h: bobe_gp_set_refine_kappa),
-entry point by entry point.
+"""The blocked forward substitution that replaces the products with the inverse factor where the factor is ill conditioned
+(include/bobe_gp.h: bobe_gp_set_refine_kappa, bobe_gp_set_solve_block), entry point by entry point.
 
 Where it matters - the reference's default noise of 1e-8 with large kernel variances - is tests/test_gpu_conditioning.py.
-Here the step is FORCED ON (kappa = 0) for a well-conditioned GP, where the plain product is already accurate: every entry
+Here it is FORCED ON (kappa = 0) for a well-conditioned GP, where the plain product is already accurate: every entry
 point that forms v = L^-1 k (predict, sweep, fantasy_var, wip_grad on both of its paths, predict_grad, the rank-b append)
-must return what it returns without the step, up to rounding, and the oracle's values.  That exercises the three-launch
-path (k_trimul -> k_trimul_resid -> k_trimul_add), its vector form and the standalone cross launch on ragged sizes, both
-kernels and more than one candidate chunk."""
+must return what it returns with the plain product, up to rounding, and the oracle's values.  That exercises the launch
+sequence of bobe_gp::solve_v (k_blk_step: long panel updates, diagonal solves, short updates inside a panel) at several
+block / panel heights, the vector form of the few-candidate path (one refinement step) and the standalone cross launch on
+ragged sizes, both kernels and more than one candidate chunk."""
 import numpy as np
 import pytest
 
@@ -20,19 +21,24 @@ def _problem(n, d, seed):
     return rng, X, y
 
 
+@pytest.mark.parametrize("block,panel", [(128, 512), (128, 128), (128, 256), (256, 256), (256, 1024), (384, 512)])
 @pytest.mark.parametrize("n,d,kernel", [(130, 2, "rbf"), (641, 5, "matern"), (1000, 3, "rbf")])
-def test_forced_refinement_changes_nothing_beyond_rounding(n, d, kernel):
+def test_forced_substitution_changes_nothing_beyond_rounding(n, d, kernel, block, panel):
+    """diagonal blocks of `block` rows, `panel` rows per long update launch (bobe_gp_set_solve_block, bobe_debug_solve_opts)"""
     from bobe_amd import GP
     from oracle import bobe_oracle as O
     rng, X, y = _problem(n, d, n)
     ls = np.full(d, 0.45)
     plain = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.4)
-    assert plain.refine_kappa == 1e6                                    # the default
+    assert plain.refine_kappa == 1e6 and plain.solve_block == 128       # the defaults
     plain.refine_kappa = -1.0                                           # never: the plain product with the inverse factor
     plain.recompute_cholesky()
     assert not plain.refining
     forced = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.4)
     forced.refine_kappa = 0.0
+    forced.solve_block = block
+    assert forced.solve_block == block
+    assert forced._lib.bobe_debug_solve_opts(forced._h, panel, 0) == 0
     forced.recompute_cholesky()
     assert forced.refining and np.array_equal(forced.cholesky, plain.cholesky)
     og = O.OracleGP(X, y, noise=1e-6, kernel=kernel, lengthscales=ls, kernel_variance=1.4)
@@ -63,7 +69,7 @@ def test_forced_refinement_changes_nothing_beyond_rounding(n, d, kernel):
 
 def test_refinement_through_update_append_and_copy():
     """GP.update at unchanged hyper-parameters is a rank-b append (bobe_gp_append) whose new rows are L^-1 K(X_old, X_new):
-    with the step forced on they must still be the rows a fresh factorisation gives, the setting must survive the append
+    with the substitution forced on they must still be the rows a fresh factorisation gives, the setting must survive the append
     and travel with copy()."""
     from bobe_amd import GP
     rng, X, y = _problem(300, 3, 9)
@@ -86,10 +92,15 @@ def test_refinement_through_update_append_and_copy():
     assert not c.refining
     with pytest.raises(Exception):
         c.refine_kappa = float("nan")
+    for bad in (0, 100, -128):
+        with pytest.raises(Exception):
+            c.solve_block = bad
+    c.solve_block = 256
+    assert c.copy().solve_block == 256
 
 
 def test_default_threshold_switches_on_where_the_factor_is_ill_conditioned():
-    """noise 1e-8 with a long length scale: (kvar + noise) / smallest pivot passes 1e6 and the step is on by itself; at
+    """noise 1e-8 with a long length scale: (kvar + noise) / smallest pivot passes 1e6 and the substitution is on by itself; at
     noise 1e-6 with unit kernel variance (the headline configuration) it never is."""
     from bobe_amd import GP
     _, X, y = _problem(400, 2, 4)

@@ -186,7 +186,7 @@ def test_stepped_lbfgsb_driver_is_scipy_minimize_restart_for_restart():
             return float("nan"), np.full_like(x, np.nan)
         return f, g
 
-    assert optim._rc_available()                              # this image's SciPy is the one the loop was written against
+    assert optim._rc_available()                              # this image's SciPy has the routine the loop was written against
     starts = np.random.default_rng(3).uniform(-2, 2, size=(6, 5))
     starts[2, 0] = 1.95
     bounds = [(-2.0, 2.0), (-0.5, 2.0), (None, 1.5), (-2.0, None), (None, None)]
@@ -287,6 +287,54 @@ def test_an_exception_in_one_restart_ends_that_restart_only():
     # (optimize_scipy's own options differ from `kw`: same optimum, not the same last digits)
     assert np.allclose(best_x, ref[0].x, atol=1e-3) and best_f == pytest.approx(min(r.fun for r in ref), rel=1e-4)
     assert optim.lbfgs_driver() == "stepped"
+
+
+def test_stepped_driver_is_gated_on_the_routine_not_on_the_version_text(monkeypatch):
+    """The stepped L-BFGS-B driver is tied to SciPy's private ``setulb``: what it checks is the routine's own argument list
+    (its docstring) and the message tables, not ``scipy.__version__``.  Another version string with the same routine keeps the
+    stepped driver; a routine with another argument list (or none stated) switches to the thread driver - and that
+    fallback gives ``minimize``'s iterates, bit for bit."""
+    import scipy
+    from scipy.optimize import _lbfgsb, minimize
+    from bobe_amd import optim
+
+    def fresh():
+        optim._RC_STATE.update(checked=False, ok=False)
+        return optim._rc_available()
+
+    saved = dict(optim._RC_STATE)
+    try:
+        assert optim._setulb_mismatch() is None and fresh()
+        monkeypatch.setattr(scipy, "__version__", "9.99.0")                      # the version text alone changes nothing
+        assert optim._setulb_mismatch() is None and fresh() and optim.lbfgs_driver() == "stepped"
+
+        class Other:                                                             # a routine with one argument more
+            __doc__ = "setulb(m,x,l,u,nbd,f,g,factr,pgtol,wa,iwa,task,iprint,lsave,isave,dsave,maxls,ln_task)"
+
+            def __call__(self, *a):
+                raise AssertionError("the stepped driver must not call a routine it was not written for")
+        monkeypatch.setattr(_lbfgsb, "setulb", Other())
+        assert "setulb takes" in optim._setulb_mismatch() and not fresh() and optim.lbfgs_driver() == "threads"
+
+        def vg(x):
+            x = np.asarray(x)
+            return float(np.sum((x - 0.3) ** 2) + 0.1 * np.sum(x ** 4)), 2 * (x - 0.3) + 0.4 * x ** 3
+        starts = np.array([[1.0, -1.0, 0.5], [-1.2, 0.2, 0.1], [0.9, 0.9, -0.9]])
+        kw = dict(method="L-BFGS-B", bounds=[(-2, 2)] * 3, options={"maxiter": 50})
+        monkeypatch.undo()                                                       # (minimize itself needs the real routine;
+        optim._RC_STATE.update(checked=True, ok=False)                           #  the driver decision stays "threads")
+        ref = [minimize(vg, x0, jac=True, **kw) for x0 in starts]
+        out = optim._minimize_concurrently(lambda xs: [vg(x) for x in xs], starts, True, **kw)
+        for r, o in zip(ref, out):
+            assert np.array_equal(o.x, r.x) and o.fun == r.fun and o.nit == r.nit and o.nfev == r.nfev and o.message == r.message
+        for doc in (None, "", "reverse communication routine"):                  # no argument list stated: switched off
+            class NoDoc:
+                __doc__ = doc
+            monkeypatch.setattr(_lbfgsb, "setulb", NoDoc())
+            assert optim._setulb_mismatch() is not None
+            monkeypatch.undo()
+    finally:
+        optim._RC_STATE.update(saved)
 
 
 def test_fit_start_is_walked_back_to_a_factorisable_kernel_variance():
