@@ -480,8 +480,10 @@ def main():
                     "wipstd_max_rel_vs_plain_product": float(np.max(np.abs(acc_w - plain_w) / np.abs(plain_w))),
                     "same_pick": bool(acc_pick == int(asd.value))}
 
-        def whole_cycle(g):
-            """fit (lock-step rounds of four) + refactor + sweep on another GP object's handle"""
+        def whole_cycle(g, ls_ref=None):
+            """fit (lock-step rounds of four) + refactor (at ls_ref, else the schedule's last theta) + sweep on another GP
+            object's handle"""
+            ls_ref = ls_last if ls_ref is None else ls_ref
             hh = g._h
             for j in range(len(thetas) // 4):
                 idx = np.arange(4 * j, 4 * j + 4)
@@ -489,7 +491,7 @@ def main():
                 mr, gr = np.empty(4), np.empty((4, d + 1))
                 _lib.check(lib.bobe_gp_mll_batch(hh, 4, _lib.ptr(lsr), _lib.ptr(kvr), _lib.ptr(mr), _lib.ptr(gr), None), "mll_batch")
             t_a = time.perf_counter()
-            _lib.check(lib.bobe_gp_set_hyper(hh, _lib.ptr(ls_last), kv_last, float(g.noise)), "set_hyper")
+            _lib.check(lib.bobe_gp_set_hyper(hh, _lib.ptr(ls_ref), kv_last, float(g.noise)), "set_hyper")
             st = _lib.check(lib.bobe_gp_factor(hh), "factor")
             t_b = time.perf_counter()
             _lib.check(lib.bobe_gp_wip_sweep(hh, _lib.ptr(work["cand"]), Cn, _lib.ptr(Z_d), M, 1.0, _lib.ptr(work["wipv"]),
@@ -497,12 +499,12 @@ def main():
                                              C.byref(av), C.byref(mv), C.byref(asd), C.byref(ms)), "sweep")
             return st, mr, (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3
 
-        def time_cycles(g, reps=3):
-            whole_cycle(g)
+        def time_cycles(g, reps=3, ls_ref=None):
+            whole_cycle(g, ls_ref)
             ts, last_ = [], None
             for _ in range(reps):
                 t_a = time.perf_counter()
-                last_ = whole_cycle(g)
+                last_ = whole_cycle(g, ls_ref)
                 ts.append((time.perf_counter() - t_a) * 1e3)
             return float(np.median(ts)), last_
 
@@ -514,6 +516,12 @@ def main():
                      "finite_mll_of_last_round": int(np.sum(np.isfinite(mll8))), "pivot_floor_ulp": g8.pivot_floor_ulp,
                      "note": "same data and theta schedule; the accurate solve switches on by itself when (kvar + noise) / "
                              "smallest pivot of the installed factor exceeds 1e6"}
+        # ... and with the refactor at a longer length scale (1.2 in every dimension: what a fit of a smooth likelihood reaches),
+        # where the factor's pivots fall to the noise and the rule trips: the sweep is then the substitution's, unforced
+        ls_long = np.full(d, 1.2)
+        ms8l, (st8l, _, rf8l, sw8l) = time_cycles(g8, ls_ref=ls_long)
+        ref_noise["long_lengthscale"] = {"lengthscale": 1.2, "ms_per_cycle": ms8l, "cycles_per_s": 1e3 / ms8l, "refactor_ms": rf8l,
+                                         "sweep_ms": sw8l, "substitution_on": bool(g8.refining), "factor_status": int(st8l)}
         del g8
         # ---- (c) the same cycle with the Matern-5/2 kernel (north_star names both kernels)
         gm = GP(X, y, noise=noise, kernel="matern", lengthscales=np.full(d, 0.6), kernel_variance=1.0, device=local)

@@ -23,6 +23,14 @@ void configure_sweep_kernels() {
 }
 }  // namespace bobe
 
+static int trimul_colmap() {
+  static const int v = [] {
+    const char* e = std::getenv("BOBE_TRIMUL_CONTIG");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+
 void bobe_gp::decide_refinement(double min_diag) {
   const double piv = min_diag * min_diag;
   refine_v = refine_kappa >= 0.0 && piv > 0.0 && (hyp.kvar + hyp.noise) / piv > refine_kappa;
@@ -199,7 +207,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
           const int nz = pend.valid ? nzt : 0;
           hipLaunchKernelGGL(k_trimul, dim3((unsigned)std::max(ncv, ncx), (unsigned)(nb + nz)), dim3(256), GEMM_SMEM_BYTES,
                              stream, (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, vcur, CH, qpart.d(), CH,
-                             (const double*)VZ.d(), Mp, nz, pend.cross, SC, pend.V, CH, ncx, ncv);
+                             (const double*)VZ.d(), Mp, nz, pend.cross, SC, pend.V, CH, ncx, ncv, trimul_colmap());
           pend = {true, vcur, ncp, pv.d() + c0};
           vsel ^= 1;
         } else {

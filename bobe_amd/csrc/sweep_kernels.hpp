@@ -20,9 +20,13 @@ __global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Li
                                                    const double* __restrict__ VZ, int64_t ldw, int nzt,
                                                    double* __restrict__ crossT, int64_t ldx,
                                                    const double* __restrict__ Bx = nullptr, int64_t ldbx = 0, int ncx = 0,
-                                                   int ncv = 1 << 30) {
+                                                   int ncv = 1 << 30, int colmap = 0) {
   extern __shared__ double smem[];
-  const int tc = blockIdx.x;
+  int tc = blockIdx.x;
+  // (round-6 A/B, BOBE_TRIMUL_CONTIG: with a grid of 8 m column tiles workgroup ids go round-robin over the 8 XCDs, so XCD k
+  // holds the columns k, k + 8, ... of 8 consecutive row tiles - an 8 x 8 tile group per XCD already; colmap = 1 hands it
+  // the CONTIGUOUS columns [k m, (k + 1) m) instead: the same sharing, another permutation)
+  if (colmap && (gridDim.x & 7) == 0) tc = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
   v4d acc[4][4];
   acc_zero(acc);
   if ((int)blockIdx.y < nzt) {
