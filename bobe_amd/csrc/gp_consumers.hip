@@ -316,6 +316,8 @@ void bobe_gp::release_all() {
     (void)hipEventDestroy(pr.second);
   }
   if (h_res) (void)hipHostFree(h_res);
+  if (h_in) (void)hipHostFree(h_in);
+  h_in = nullptr;
   for (hipStream_t st : slot_streams) {
     (void)hipStreamSynchronize(st);
     (void)hipStreamDestroy(st);

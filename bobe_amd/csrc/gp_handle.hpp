@@ -192,6 +192,7 @@ struct bobe_gp {
       o_misc, kin_a, kin_b, kout, vxc, vxc2;
   std::vector<bobe::Depth> depths;
   double* h_res = nullptr;  // pinned, 128 doubles
+  double* h_in = nullptr;   // pinned, 16 x MAX_D doubles: host coordinates of bobe_gp_wip_grad's few-candidate path
 
   // ---- classifier gate (gp_consumers.hip): support vectors SoA + dual coefficients on the device
   DBuf gate_sv, gate_dual;

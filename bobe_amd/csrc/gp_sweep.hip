@@ -23,14 +23,6 @@ void configure_sweep_kernels() {
 }
 }  // namespace bobe
 
-static int trimul_colmap() {
-  static const int v = [] {
-    const char* e = std::getenv("BOBE_TRIMUL_CONTIG");
-    return e ? std::atoi(e) : 0;
-  }();
-  return v;
-}
-
 void bobe_gp::decide_refinement(double min_diag) {
   const double piv = min_diag * min_diag;
   refine_v = refine_kappa >= 0.0 && piv > 0.0 && (hyp.kvar + hyp.noise) / piv > refine_kappa;
@@ -207,7 +199,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
           const int nz = pend.valid ? nzt : 0;
           hipLaunchKernelGGL(k_trimul, dim3((unsigned)std::max(ncv, ncx), (unsigned)(nb + nz)), dim3(256), GEMM_SMEM_BYTES,
                              stream, (const double*)Linv.d(), Np, nb, (const double*)kXC.d(), CH, vcur, CH, qpart.d(), CH,
-                             (const double*)VZ.d(), Mp, nz, pend.cross, SC, pend.V, CH, ncx, ncv, trimul_colmap());
+                             (const double*)VZ.d(), Mp, nz, pend.cross, SC, pend.V, CH, ncx, ncv);
           pend = {true, vcur, ncp, pv.d() + c0};
           vsel ^= 1;
         } else {
@@ -289,7 +281,10 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
   use();
   const int64_t Mp = round_up(M, TILE), CH = std::min<int64_t>(chunk, 1024);
   const double kself = hyp.kvar + hyp.noise;
-  const double* cin = fetch(cand, (size_t)C * d, in_stage);
+  const bool few_path = C <= 16 && N <= 4096;
+  // (the few-candidate path reads host coordinates through the pinned block h_in: no copy command in front of its chain)
+  const bool cand_pinned = few_path && !is_device_ptr(cand);
+  const double* cin = cand_pinned ? nullptr : fetch(cand, (size_t)C * d, in_stage);
   prepare_z(Z, M, Mp, true);                             // ZsT, V_Z, W_Z = K^-1 K(X,Z), base_z
   CsT.ensure((size_t)d * std::max<int64_t>(CH, chunk) * sizeof(double));
   kXC.ensure((size_t)Np * std::max<int64_t>(CH, chunk) * sizeof(double));
@@ -302,7 +297,16 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
   double* d_dv = out_dev(dwipv, (size_t)C * d, o_mean);
   double* d_ds = out_dev(dwipstd, (size_t)C * d, o_var);
   const int dcap = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
-  if (C <= 16 && N <= 4096) {
+  if (few_path) {
+    double* cdev = nullptr;                        // device copy of pinned-host coordinates, written by the first stage
+    if (cand_pinned) {
+      if (!h_in) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_in), 16 * MAX_D * sizeof(double), hipHostMallocDefault));
+      std::memcpy(h_in, cand, (size_t)C * d * sizeof(double));
+      in_stage.ensure((size_t)16 * MAX_D * sizeof(double));
+      cdev = in_stage.d();
+    }
+    const double* cfirst = cand_pinned ? (const double*)h_in : cin;   // what the first stage reads
+    if (cand_pinned) cin = cdev;                                      // what the later stages read
     // A handful of candidates (the L-BFGS refinement sends one): matrix-vector stages spread over the chip instead of
     // 128-column tile passes and one workgroup per candidate (kernels.hpp, "the same for a HANDFUL of candidates").
     const int nzw = (int)(Mp / 64), nnw = (int)((N + WG_ROWS - 1) / WG_ROWS);
@@ -324,7 +328,7 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
 #define FEW(KE, DC)                                                                                                      \
   do {                                                                                                                   \
     hipLaunchKernelGGL((k_wg_col<KE, DC>), dim3((unsigned)(Np / 256 + 1), (unsigned)C), dim3(256), 0, stream,           \
-                       (const double*)XsT.d(), Np, N, Np, cin, h, kc);                                                 \
+                       (const double*)XsT.d(), Np, N, Np, cfirst, h, kc, cdev);                                        \
     solve_alpha(li, vv, uu, part.d(), (int)C, 0, Np, (int64_t)nb * Np, (const double*)kc, Np);                             \
     if (refine_v) {   /* one step of iterative refinement in vector form: v += Linv (k - L v), u += Linv^T of the same */   \
       const unsigned gv_ = (unsigned)((n_vec + 255) / 256);                                                              \
@@ -355,13 +359,11 @@ void bobe_gp::wip_grad(const double* cand, int64_t C, const double* Z, int64_t M
     const size_t n_out = (size_t)C * (2 + 2 * d);
     const bool packed = n_out <= 96 && !(wipv && is_device_ptr(wipv)) && !(wipstd && is_device_ptr(wipstd)) &&
                         !(dwipv && is_device_ptr(dwipv)) && !(dwipstd && is_device_ptr(dwipstd));
-    if (packed) {                                  // one copy through the pinned result block instead of four
-      o_wipv.ensure(n_out * sizeof(double));
-      double* ob = o_wipv.d();
+    if (packed) {                                  // the last stage writes the pinned result block itself: no copy command
+      double* ob = h_res;
       hipLaunchKernelGGL(k_wg_final, dim3((unsigned)C), dim3(256), 0, stream, (const double*)pz, nzw, (const double*)pn,
                          nnw, h, M, ob, ob + C, ob + 2 * C, ob + 2 * C + C * d);
       LAUNCH_CHECK();
-      HIPCHK(hipMemcpyAsync(h_res, ob, n_out * sizeof(double), hipMemcpyDeviceToHost, stream));
       sync();
       const double* hr = h_res;
       if (wipv) std::memcpy(wipv, hr, (size_t)C * sizeof(double));

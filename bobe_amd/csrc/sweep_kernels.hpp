@@ -20,13 +20,12 @@ __global__ __launch_bounds__(256, 2) void k_trimul(const double* __restrict__ Li
                                                    const double* __restrict__ VZ, int64_t ldw, int nzt,
                                                    double* __restrict__ crossT, int64_t ldx,
                                                    const double* __restrict__ Bx = nullptr, int64_t ldbx = 0, int ncx = 0,
-                                                   int ncv = 1 << 30, int colmap = 0) {
+                                                   int ncv = 1 << 30) {
   extern __shared__ double smem[];
-  int tc = blockIdx.x;
-  // (round-6 A/B, BOBE_TRIMUL_CONTIG: with a grid of 8 m column tiles workgroup ids go round-robin over the 8 XCDs, so XCD k
-  // holds the columns k, k + 8, ... of 8 consecutive row tiles - an 8 x 8 tile group per XCD already; colmap = 1 hands it
-  // the CONTIGUOUS columns [k m, (k + 1) m) instead: the same sharing, another permutation)
-  if (colmap && (gridDim.x & 7) == 0) tc = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  // (with a grid of 8 m column tiles the workgroup ids go round-robin over the 8 XCDs: XCD k holds the columns k, k + 8, ...
+  // of the 8 row tiles in flight - an 8 x 8 tile group per XCD, the fewest operand panels 64 tiles can share; contiguous
+  // columns per XCD instead measured the same traffic and time, profiles/r06_traffic_k_trimul_contig.json)
+  const int tc = blockIdx.x;
   v4d acc[4][4];
   acc_zero(acc);
   if ((int)blockIdx.y < nzt) {
@@ -684,8 +683,12 @@ __global__ __launch_bounds__(256) void k_wip_grad(const double* __restrict__ XsT
 // k_wg_final.  All sums in a fixed order.
 template <int KERN, int DCAP>
 __global__ __launch_bounds__(256) void k_wg_col(const double* __restrict__ XsT, int64_t ldx, int64_t n, int64_t np,
-                                                const double* __restrict__ cand, Hyper h, double* __restrict__ kc) {
+                                                const double* __restrict__ cand, Hyper h, double* __restrict__ kc,
+                                                double* __restrict__ cand_dev = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  // (cand may be the caller's coordinates in PINNED HOST memory, read here over the fabric once: the device copy for the
+  // later stages is left on the way instead of a host -> device copy command in front of the chain)
+  if (cand_dev && blockIdx.x == 0 && (int)threadIdx.x < h.d) cand_dev[c * h.d + threadIdx.x] = cand[c * h.d + threadIdx.x];
   if (i >= np) return;
   double r2 = 0.0;
 #pragma unroll

@@ -3,7 +3,7 @@
 # (1) kernel stats of the TIMED CYCLES ONLY (bench.py --no-secondary): headline, config 2, and the headline with every factor
 #     treated as ill conditioned (BOBE_REFINE_KAPPA=0: the blocked substitution's launches, k_blk_step),
 # (2) PMC passes of the same command, each counter set in its own run, program directly after `--`:
-#     FETCH_SIZE / WRITE_SIZE -> fabric traffic of k_trimul (also with BOBE_TRIMUL_CONTIG=1: the column-order A/B), k_blk_step,
+#     FETCH_SIZE / WRITE_SIZE -> fabric traffic of k_trimul, k_blk_step,
 #     k_cross_vv and the two assembly kernels (tools/pmc_traffic.py); MFMA busy cycles -> utilisation,
 # (3) the bench lines (headline with the CPU baseline, config 2, config 4 on one GPU, N = 8192),
 # (4) config 5 under the kernel trace + tools/config5_breakdown.py.
@@ -32,14 +32,7 @@ python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE "k_trimul("
 python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE "k_cross_vv" 4096 65536 8192 "$cmd" "round 6, $head" > $out/traffic_k_cross_vv.json
 python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE "k_kernel_matrix<0, false, 8, true>" 4096 65536 8192 "$cmd" "round 6, $head" > $out/traffic_k_kernel_matrix_0_false_8_true.json
 python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE "k_kernel_matrix<0, true, 8, true>" 4096 65536 8192 "$cmd" "round 6, $head" > $out/traffic_k_kernel_matrix_0_true_8_true.json
-export BOBE_TRIMUL_CONTIG=1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $out/pmcc_$c -- python3 bench.py --steps 2 --warmup 1 --no-secondary > /dev/null 2>&1 || exit 1
-done
-python3 tools/pmc_traffic.py $out/pmcc_FETCH_SIZE $out/pmcc_WRITE_SIZE "k_trimul(" 4096 65536 8192 "BOBE_TRIMUL_CONTIG=1 $cmd" "round 6, $head" > $out/traffic_k_trimul_contig.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cycle_contig -- python3 bench.py --steps 5 --warmup 2 --no-secondary > $out/bench_cycle_contig.json 2> /dev/null || exit 1
-cp "$(ls $out/prof_cycle_contig/*/*kernel_stats.csv | head -1)" $out/cycle_kernel_stats_contig.csv
-unset BOBE_TRIMUL_CONTIG
+# (the column-order A/B of k_trimul, profiles/r06_traffic_k_trimul_contig.json, was collected here with a knob that has since been removed)
 echo "pmc traffic done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-secondary > /dev/null 2>&1 || exit 1
 python3 tools/pmc_mfma.py $out/pmc_mfma > $out/mfma_util.json
@@ -58,6 +51,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c5 -- python3 
 cp "$(ls $out/prof_c5/*/*kernel_stats.csv | head -1)" $out/config5_kernel_stats.csv
 python3 tools/config5_run.py seed=7 > $out/config5_plain.txt 2>&1 || exit 1
 python3 tools/config5_breakdown.py $out/config5_kernel_stats.csv $out/config5_rocprof.txt $out/config5_plain.txt > $out/config5_breakdown.txt
-rm -rf $out/prof_cycle $out/prof_cycle_small $out/prof_cycle_subst $out/prof_cycle_contig $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmcs_FETCH_SIZE $out/pmcs_WRITE_SIZE $out/pmcc_FETCH_SIZE $out/pmcc_WRITE_SIZE $out/pmc_mfma $out/pmc_mfma_s $out/prof_c5
+rm -rf $out/prof_cycle $out/prof_cycle_small $out/prof_cycle_subst $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmcs_FETCH_SIZE $out/pmcs_WRITE_SIZE $out/pmc_mfma $out/pmc_mfma_s $out/prof_c5
 head -12 $out/config5_breakdown.txt
 tail -c 300 $out/bench_headline.json

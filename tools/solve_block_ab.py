@@ -1,11 +1,13 @@
-"""A/B of the three ways the sweep forms V = L^-1 K(X, C) (round 6, verdict item 1):
+"""A/B of the ways the sweep forms V = L^-1 K(X, C) (round 6, verdict item 1):
 
   plain    the product with the explicit inverse factor (k_trimul, cross tiles fused)          refine_kappa < 0
-  refine   plain + one step of iterative refinement (k_trimul, k_trimul_resid, k_trimul_add)  refine_kappa = 0, block 0
   hybrid   blocked forward substitution (k_blk_step), diagonal blocks b, update panels p        refine_kappa = 0, block b
 
-on the headline workload (N = 4096, d = 8, 65 536 candidates, M = 512; well conditioned, so all three must agree to
-rounding) - times only; the accuracy side is tests/test_gpu_conditioning.py.  Writes gpurun_out/r06_solve_block_ab.txt."""
+on the headline workload (N = 4096, d = 8, 65 536 candidates, M = 512; well conditioned, so both must agree to rounding) -
+times only; the accuracy side is tests/test_gpu_conditioning.py.  Writes gpurun_out/r06_solve_block_ab_<config>.txt.
+The committed profiles/r06_solve_block_ab_{headline,small}.txt were written by this script at commit 01a1561 + the first
+form of the kernel, when round 5's refinement step (k_trimul -> k_trimul_resid -> k_trimul_add, line "refine") still
+existed: 60.6 ms per sweep against 29.8 (b = 128, panels of 512 rows, 32 768 candidates per launch sequence)."""
 import ctypes as C
 import os
 import sys
@@ -57,7 +59,7 @@ def main():
 
     rows = []
     ref = None
-    variants = [("plain", -1.0, 0, 512, 0), ("refine", 0.0, 0, 512, 0)]
+    variants = [("plain", -1.0, 128, 512, 0)]
     for b, pn in ((128, 128), (128, 256), (128, 512), (128, 1024), (256, 512), (256, 1024), (512, 512), (1024, 1024)):
         for ch in (0, 16384, 32768):
             variants.append((f"hybrid b={b} panel={pn} chunk={ch or 8192}", 0.0, b, pn, ch))
