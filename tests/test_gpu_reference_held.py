@@ -43,6 +43,45 @@ def test_first_fit_of_the_notebook_run_digit_for_digit():
     assert gp.hyperparams_dict() == NB["logged_hyperparameters_after_refit"]
 
 
+def test_first_acquisition_value_of_the_notebook_run_on_the_gpu():
+    """'Mean acquisition value 3.4146e+00 at new points' - iteration 1 of the reference's notebook run, the one number it
+    holds for the acquisition half at a known state (tests/test_reference_held_cpu.py has the argument).  Here the GPU path
+    produces it: ``BOBE(...)`` at the logged seed (the logged first fit), then ``WIPStd.get_next_batch`` - sweep, argmin,
+    L-BFGS-B refinement on bobe_gp_wip_grad, kriging-believer update - over (a) the same exact posterior samples the oracle
+    uses, seed by seed: the oracle's values (its refinement differentiates numerically: 1e-3), and the logged value a typical
+    draw of theirs; (b) the product's own sampler (``get_mc_samples``: HMC chains on the device) as ``run()`` would call it:
+    the logged value inside the spread of those draws too."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_reference_held_cpu as T
+    from bobe_amd.acquisition import WIPStd, get_mc_samples
+    from oracle import bobe_oracle as O
+    from oracle import bobe_oracle_loop as OL
+    held = NB["logged_mean_acquisition_values"]["iteration_1_to_15"][0]
+    b = _notebook_bobe(NB["seed"])
+    gp = b.gp
+    assert gp.hyperparams_dict() == NB["logged_hyperparameters_after_refit"]
+    og = O.OracleGP(gp.train_x, gp.train_y * gp.y_std + gp.y_mean, lengthscales=gp.lengthscales, kernel_variance=gp.kernel_variance)
+    acq = WIPStd()
+
+    def gpu_batch(g, mc, r):
+        return acq.get_next_batch(g, n_batch=2, acq_kwargs={"mc_samples": {"x": mc}, "mc_points_size": 64}, n_restarts=1,
+                                  maxiter=100, early_stop_patience=10, verbose=False, rng=r)[1]
+    seeds = T.FIRST_ACQ_SEEDS
+    got = T.first_acquisition_values(gp, gpu_batch, seeds=seeds)
+    ref = T.first_acquisition_values(og, lambda g, mc, r: OL.get_next_batch(g, "wipstd", mc, 64, 2, r)[1], seeds=seeds)
+    assert np.allclose(got, ref, rtol=2e-3), (got, ref)
+    assert abs(held - got.mean()) <= 2.0 * got.std() and 0.75 <= held / got.mean() <= 1.33, (held, got)
+    # (b) integration samples from the product's sampler, with the notebook run's defaults (bo.py:978-980: 512 warm-up, 512 samples)
+    own = []
+    for s in range(6):
+        r = np.random.default_rng(100 + s)
+        mc = get_mc_samples(gp, warmup_steps=512, num_samples=512, thinning=4, method="NUTS", num_chains=4, np_rng=r)
+        own.append(float(np.mean(gpu_batch(gp, mc["x"], r))))
+    own = np.array(own)
+    assert 0.6 <= held / own.mean() <= 1.6 and own.min() / 1.5 <= held <= own.max() * 1.5, (held, own)
+
+
 def test_config1_notebook_run_lands_in_the_reference_band():
     """BASELINE config 1 with the notebook's run settings.  The reference's own two estimates (its BO run: -3.1302 +-
     0.0353; dynesty on the true likelihood: -3.2340 +- 0.0391) differ by 0.104, and the quadrature of the likelihood
