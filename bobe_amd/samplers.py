@@ -325,7 +325,8 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     samples is the reference's.  The cube constraint is handled like NumPyro does it, by sampling u = logit(x) with
     the Jacobian term; step size by dual averaging to 0.8 acceptance and a diagonal mass matrix from the warm-up
     spread of the chains.  Chains start at the best training point and at ``gp.get_random_point`` draws
-    (samplers.py:296-300).  Works for ``GPwithClassifier`` too: infeasible points carry ``minus_inf`` and are never
+    (samplers.py:296-300); a chain that is still tens of log units below the others at a warm-up window restarts from a
+    healthy chain's state (``cull_lost_chains``, see the loop).  Works for ``GPwithClassifier`` too: infeasible points carry ``minus_inf`` and are never
     accepted."""
     rng = np_rng if isinstance(np_rng, np.random.Generator) else np.random.default_rng(np_rng)
     d = gp.ndim
@@ -380,8 +381,23 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
             hist, _, _ = gp.hmc_run(state, adapt, inv_mass, seed, it, n_it, True, temp,
                                     hist_from=None if last else n_it // 2)
             it = cut
-            if not last:                                       # mass matrix from the spread of the batch
-                inv_mass = np.var(hist.reshape(-1, d), axis=0) + 1e-3
+            # Chains that never found the posterior: with 16 x num_chains chains started at uniform random points (the
+            # reference's recipe, samplers.py:296-300) one now and then spends the whole warm-up on a plateau tens of log units
+            # below the others (after the notebook run's first fit the surface is -103 everywhere but within a length scale of
+            # the best point, -34.8: 3 of 8 runs kept one such chain, 1.6 % of the samples where the target puts e^-68).  At
+            # every window such a chain restarts from the state of a randomly chosen healthy one (fresh momenta decorrelate
+            # them within the window); ``cull_lost_chains=False`` switches this off.
+            healthy = np.ones(P, dtype=bool)
+            if kwargs.get("cull_lost_chains", True):
+                lp_now = state[:, 3 * d]
+                lost = ~(lp_now >= np.nanmax(lp_now) - (20.0 + 2.0 * d))
+                if lost.any() and not lost.all():
+                    healthy = ~lost
+                    src = rng.choice(np.flatnonzero(healthy), size=int(lost.sum()))
+                    state[lost] = state[src]
+                    adapt[lost] = adapt[src]
+            if not last:                                       # mass matrix from the spread of the batch (healthy chains)
+                inv_mass = np.var(hist[:, healthy, :].reshape(-1, d), axis=0) + 1e-3
                 # restart the dual averaging for the new metric (NumPyro / Stan do at every window): mu, hbar,
                 # log_eps_bar AND the step counter m - with m left at several hundred, eta = m^-0.75 is ~0.01 and the
                 # zeroed log_eps_bar keeps a quarter of its weight to the end of the warm-up (step size biased to 1)
