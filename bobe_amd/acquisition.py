@@ -55,13 +55,14 @@ class AcquisitionFunction:
         if n_batch > 1:
             dummy_gp = _believer_gp(gp)                                        # acquisition.py:175-180
             dummy_gp.update(x_next, dummy_gp.predict_mean_single(x_next))
-            for _ in range(1, n_batch):
+            for member in range(1, n_batch):
                 x_next, val = self.get_next_point(dummy_gp, acq_kwargs=acq_kwargs, maxiter=maxiter,
                                                   n_restarts=n_restarts, verbose=verbose,
                                                   early_stop_patience=early_stop_patience, rng=rng)
                 x_batch.append(np.asarray(x_next))
                 acq_vals.append(val)
-                dummy_gp.update(x_next, dummy_gp.predict_mean_single(x_next))
+                if member + 1 < n_batch:      # (the reference also updates after the LAST member, acquisition.py:194: the dummy
+                    dummy_gp.update(x_next, dummy_gp.predict_mean_single(x_next))     # GP is dropped right after - not done here)
         return np.array(x_batch), np.array(acq_vals)
 
 

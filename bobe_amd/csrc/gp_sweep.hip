@@ -128,15 +128,23 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   const double* cin = fetch(cand, (size_t)C * d, in_stage);
   if (do_wip) prepare_z(Z, M, Mp, false);
   const int64_t CH = (refine_v && solve_chunk > 0) ? solve_chunk : chunk;   // (BOBE_SOLVE_CHUNK: speed only)
+  // The reference sweeps the integration points themselves (acquisition.py:394: candidates = mc_points).  Then K(X, C) and
+  // V_C = L^-1 K(X, C) are what prepare_z has just made for Z: no second assembly and solve, the column sums come from V_Z in
+  // the association the candidates' solve would have used (k_colsq_tile_parts: same bits as the long way).
+  bool cand_is_z = false;
+  if (do_wip && C == M && C <= CH && !mean && !var) {
+    if (is_device_ptr(cand) || is_device_ptr(Z)) cand_is_z = (cand == Z);
+    else cand_is_z = std::memcmp(cand, Z, (size_t)C * d * sizeof(double)) == 0;
+  }
   // scoring runs once per super-chunk of SC candidates (bounded crossT workspace: Mp x SC doubles)
   const int64_t SC = round_up(std::min<int64_t>(C, std::max<int64_t>(CH, 65536)), CH);
   CsT.ensure((size_t)d * SC * sizeof(double));
-  kXC.ensure((size_t)Np * CH * sizeof(double));
+  if (!cand_is_z) kXC.ensure((size_t)Np * CH * sizeof(double));
   sc.ensure((size_t)SC * sizeof(double));
   qpart.ensure((size_t)nb * (Mp > CH ? Mp : CH) * sizeof(double));
   part.ensure((size_t)nb * (Np > CH ? Np : CH) * sizeof(double));
   if (do_wip) pv.ensure((size_t)Mp * SC * sizeof(double));                   // crossT
-  if (do_wip || refine_v) vxc.ensure((size_t)Np * CH * sizeof(double));      // V = Linv K(X, chunk)
+  if ((do_wip || refine_v) && !cand_is_z) vxc.ensure((size_t)Np * CH * sizeof(double));      // V = Linv K(X, chunk)
   // The cross-covariance tiles of a chunk ride in the launch that solves the NEXT chunk (k_trimul), so V alternates
   // between two buffers; the last chunk of a super-chunk gets a launch of its own (k_cross_vv).  The blocked substitution of
   // an ill-conditioned factor (solve_v) is followed by a separate cross launch per chunk.
@@ -145,15 +153,15 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   double* vbuf[2] = {vxc.d(), fuse_cross ? vxc2.d() : vxc.d()};
   int vsel = 0;
   struct { bool valid; const double* V; int64_t ncp; double* cross; } pend = {false, nullptr, 0, nullptr};
-  auto cross_alone = [&](const double* Vc, int64_t ncp_, double* cross_out) {
+  auto cross_alone = [&](const double* Vc, int64_t ncp_, double* cross_out, int64_t ldvc) {
     // cross-covariances from the two solved factors (sweep_kernels.hpp, k_cross_vv): crossT[z][c] = VZ[:, z] . V[:, c]
     prof_begin(BOBE_PROF_CROSSVV);
     if ((int64_t)nzt * (ncp_ / TILE) >= 2 * std::max(num_cus, 1))
       hipLaunchKernelGGL(k_cross_vv<128>, dim3((unsigned)(ncp_ / TILE), (unsigned)nzt), dim3(256), GEMM_SMEM_BYTES, stream,
-                         (const double*)VZ.d(), Mp, Vc, CH, Np, cross_out, SC);
+                         (const double*)VZ.d(), Mp, Vc, ldvc, Np, cross_out, SC);
     else
       hipLaunchKernelGGL(k_cross_vv<64>, dim3((unsigned)(ncp_ / 64), (unsigned)(Mp / 64)), dim3(256), GEMM64_SMEM_BYTES,
-                         stream, (const double*)VZ.d(), Mp, Vc, CH, Np, cross_out, SC);
+                         stream, (const double*)VZ.d(), Mp, Vc, ldvc, Np, cross_out, SC);
     prof_end(BOBE_PROF_CROSSVV);
   };
   double* d_mean = out_dev(mean, C, o_mean);
@@ -182,6 +190,15 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
     for (int64_t c0 = 0; c0 < ns; c0 += CH) {
       const int64_t nc = (ns - c0 < CH) ? (ns - c0) : CH;
       const int64_t ncp = round_up(nc, TILE);
+      if (cand_is_z) {                // (one chunk: C <= CH) V_C = V_Z, s_c from its column sums, the cross tiles V_Z^T V_Z
+        hipLaunchKernelGGL(k_colsq_tile_parts, dim3((unsigned)((ncp + 255) / 256), (unsigned)nb), dim3(256), 0, stream,
+                           (const double*)VZ.d(), Mp, ncp, qpart.d(), CH);
+        cross_alone(VZ.d(), ncp, pv.d() + c0, Mp);
+        hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
+                           (const double*)qpart.d(), CH, nb, nc, kself, policy, sc.d() + c0, (double*)nullptr);
+        LAUNCH_CHECK();
+        continue;
+      }
       // (posterior mean: the assembly leaves K(X, chunk)^T alpha per row tile on the way, k_gemv_t_part's partial sums)
       prof_begin(BOBE_PROF_KXC);
       kernel_matrix_cross(XsT.d(), Np, N, Np, CsT.d() + c0, SC, nc, ncp, hyp, kXC.d(), CH,
@@ -206,7 +223,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
           solve_v(kXC.d(), CH, ncp, (do_wip || refine_v) ? vcur : nullptr, CH, qpart.d(), CH);
         }
         prof_end(BOBE_PROF_TRIMUL);
-        if (do_wip && !fuse_cross) cross_alone(vcur, ncp, pv.d() + c0);
+        if (do_wip && !fuse_cross) cross_alone(vcur, ncp, pv.d() + c0, CH);
         // s_c for the scorer, var for the caller
         hipLaunchKernelGGL(k_predict_finalize, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream,
                            (const double*)qpart.d(), CH, nb, nc, kself, policy, sc.d() + c0,
@@ -215,7 +232,7 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
       LAUNCH_CHECK();
     }
     if (pend.valid) {                 // the super-chunk's last chunk: no next launch to ride in
-      cross_alone(pend.V, pend.ncp, pend.cross);
+      cross_alone(pend.V, pend.ncp, pend.cross, CH);
       pend.valid = false;
     }
     if (do_wip) {

@@ -129,6 +129,38 @@ __global__ void k_vec_axpy(double* __restrict__ y, const double* __restrict__ a,
   if (i < n) y[i] = a[i] + sb * b[i];
 }
 
+// qpart[ti*ldq + c] = the sum of squares of column c over the 128 rows of row tile ti of V, in EXACTLY the association of
+// k_trimul's epilogue (per 64-row half: four lane groups q = row mod 4 within a 16-row fragment, each summing its fragments
+// i = 0..3 and registers r = 0..3 in that order, then (s0 + s1) + (s2 + s3); then half 0 + half 1) - so that a V obtained
+// elsewhere (the integration points' own solve, when the candidates ARE the integration points) yields the bits the
+// candidates' solve would have left.  grid (ceil(ncols / 256), nb).
+__global__ __launch_bounds__(256) void k_colsq_tile_parts(const double* __restrict__ V, int64_t ldv, int64_t ncols,
+                                                          double* __restrict__ qpart, int64_t ldq) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int ti = blockIdx.y;
+  if (c >= ncols) return;
+  const double* col = V + ((int64_t)ti * TILE) * ldv + c;
+  double half[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    double sq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = col[(int64_t)(64 * h + 16 * i + q + 4 * r) * ldv];
+          s += v * v;
+        }
+      sq[q] = s;
+    }
+    half[h] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+  }
+  qpart[(int64_t)ti * ldq + c] = half[0] + half[1];
+}
+
 // ---- the sweep's cross-covariance product: G[z][c] = sum_n VZ[n][z] V[n][c], VZ = L^-1 K(X,Z), V = L^-1 K(X,C) -------
 // cross(c, z) = k(x_c, z) - G[z][c] is the reference's own form: fantasy_var solves with the (N+1)-row factor
 // (gp.py:552-576), whose last row is L^-1 k_c, so the cross term is an inner product of two triangular-solve results.

@@ -172,3 +172,31 @@ def test_few_candidate_gradient_path_equals_the_batched_one_at_large_n():
             scale = np.max(np.abs(big[k]))
             assert np.max(np.abs(np.concatenate([f[k] for f in one]) - big[k])) < 1e-8 * scale
             assert np.max(np.abs(five[k] - big[k][:5])) < 1e-8 * scale
+
+
+@pytest.mark.parametrize("n,d,m,kernel,kappa", [(300, 3, 96, "rbf", -1.0), (300, 3, 96, "matern", 0.0), (700, 10, 256, "rbf", 0.0),
+                                                (1000, 6, 130, "rbf", -1.0), (4096, 4, 2048, "rbf", -1.0), (4096, 4, 2048, "rbf", 0.0)])
+def test_sweeping_the_integration_points_themselves_reuses_their_solve_bit_for_bit(n, d, m, kernel, kappa):
+    """acquisition.py:394 sweeps the integration points themselves (candidates = mc_points).  The library then reuses V_Z = L^-1
+    K(X, Z) as the candidates' V (no second assembly and solve) and takes the column sums from it in the association the
+    candidates' solve would have used (k_colsq_tile_parts): the scores must be the BITS of the long way - which the same call
+    takes when the posterior mean / variance are asked for as well - for both forms of the solve (plain product / blocked
+    substitution), both tilings of the Z side (64 x 64 tiles for few integration points, 128 x 128 above) and ragged sizes."""
+    from bobe_amd import GP
+    rng = np.random.default_rng(n + m)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X[:, 0]) - np.sum((X - 0.4) ** 2, axis=1)
+    gp = GP(X, y, noise=1e-6, kernel=kernel, lengthscales=np.full(d, 0.5), kernel_variance=1.3)
+    gp.refine_kappa = kappa
+    gp.recompute_cholesky()
+    assert gp.refining == (kappa == 0.0)
+    Z = rng.uniform(size=(m, d))
+    short = gp.wip_sweep(Z, Z)                                   # the shortcut
+    long_ = gp.wip_sweep(Z, Z, want_mean_var=True)               # mean / variance asked for: assembly + solve of the candidates
+    other = gp.wip_sweep(Z.copy() + 0.0, np.array(Z))           # equal content in other buffers: still the shortcut
+    for k in ("wipv", "wipstd"):
+        assert np.array_equal(short[k], long_[k]) and np.array_equal(short[k], other[k]), k
+    assert short["argmin_v"] == long_["argmin_v"] and short["argmin_s"] == long_["argmin_s"]
+    fa = gp.fantasy_var(Z[:40], Z[:40])                          # (candidates == integration points here as well)
+    fb = gp.fantasy_var(Z[:40], np.vstack([Z[:40], Z[:1]]))[:, :40]
+    assert np.allclose(fa, fb, rtol=1e-9, atol=1e-13)
