@@ -124,6 +124,42 @@ def test_run_level_resume_continues_the_interrupted_run(tmp_path):
     assert fresh.fresh_start and fresh.gp.npoints == 8
 
 
+def test_stages_of_a_tuple_acq_share_the_budgets_and_resume_in_place(tmp_path):
+    """``run(acq=('ei', 'wipstd'))`` runs the acquisition functions as stages (bo.py:1149-1158).  A stage that would start past
+    the budgets is not entered (round 5's driver evaluated one more batch there), a later stage starts with its own stopping
+    flags, and the run state names the stage it was written in so that a resume continues THERE."""
+    import json
+    from bobe_amd.bo import BOBE
+    bounds = np.array([[-4.0, 4.0], [-4.0, 4.0]]).T
+    calls = []
+
+    def counted(x):
+        calls.append(1)
+        return himmelblau(x)
+    kw = dict(fit_n_points=2, batch_size=2, mc_points_size=64, num_mc_samples=256, mc_points_method="uniform", min_evals=100)
+    # stage 1 (EI, one point per iteration) spends the whole budget: stage 2 must not evaluate anything
+    b = BOBE(counted, ["x", "y"], bounds, n_sobol_init=8, seed=2, save=False)
+    res = b.run(acq=("ei", "wipstd"), max_evals=12, **kw)
+    assert res["n_evals"] == 12 and len(calls) == 12 and res["termination_reason"] == "Maximum evaluations reached"
+    # stage 1 ends on ITS rule (a log-EI goal that the first iteration meets): stage 2 runs on with the rest of the budget
+    calls.clear()
+    d1 = str(tmp_path / "run")
+    b = BOBE(counted, ["x", "y"], bounds, n_sobol_init=8, seed=2, likelihood_name="himmel", save=True, save_dir=d1, save_step=1)
+    res = b.run(acq=("ei", "wipstd"), max_evals=15, ei_goal=1e300, **kw)
+    assert res["gp"].npoints >= 13 and len(calls) == res["n_evals"]
+    assert res["termination_reason"] == "Maximum evaluations reached"       # stage 2's own ending, not 'EI goal reached'
+    st = json.load(open(tmp_path / "run" / "himmel_run.json"))
+    assert st["stage"] == 1 and st["acq"].lower() == "wipstd"
+    # resume: continues in stage 2 (no second EI stage), with a larger budget
+    calls.clear()
+    again = BOBE(counted, ["x", "y"], bounds, n_sobol_init=8, seed=9, likelihood_name="himmel", resume=True,
+                 resume_file=str(tmp_path / "run" / "himmel"), save=False)
+    assert not again.fresh_start and not calls
+    n0 = again.gp.npoints
+    res2 = again.run(acq=("ei", "wipstd"), max_evals=n0 + 4, ei_goal=1e300, **kw)
+    assert res2["n_evals"] == n0 + 4 and len(calls) == 4 and again.acquisition.name.lower() == "wipstd"
+
+
 def test_fit_of_a_surrogate_whose_hyperparameters_no_longer_factorise(caplog):
     """bo.py::_factorisable_start on the device: hyper-parameters at which K is numerically singular (``not_pd``: NaN factor,
     NaN predictions) - the fit starts from the incumbent with a smaller kernel variance instead of from the random starts
