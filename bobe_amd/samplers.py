@@ -15,7 +15,6 @@ dynesty and NumPyro themselves are not re-implemented (no multi-ellipsoid decomp
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -332,7 +331,7 @@ def sample_GP_NUTS(gp, np_rng=None, rng_key=None, num_chains: int = 4, temp: flo
     d = gp.ndim
     warmup_steps, num_samples, thinning = get_hmc_settings(d, kwargs.get("warmup_steps"), kwargs.get("num_samples"),
                                                            kwargs.get("thinning"))
-    mult = int(kwargs.get("chain_multiplier", os.environ.get("BOBE_HMC_MULT", 16)))
+    mult = int(kwargs.get("chain_multiplier", 16))        # (64 = one chain per CU: no faster, profiles/HISTORY.md round 6)
     P = mult * max(1, int(num_chains))
     n_keep_total = max(1, (int(num_chains) * num_samples) // thinning)
     keep_per_chain = -(-n_keep_total // P)
