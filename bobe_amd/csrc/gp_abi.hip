@@ -144,11 +144,13 @@ int bobe_gp_sync(bobe_gp_t* g) {
 int bobe_gp_set_chunk(bobe_gp_t* g, int64_t chunk) {
   API_BEGIN
   NEED(g, "gp is NULL");
-  if (chunk == 0) chunk = 8192;
+  const bool reset = chunk == 0;
+  if (reset) chunk = 8192;
   NEED(chunk >= TILE && chunk % TILE == 0, "chunk must be a positive multiple of 128");
   g->use();
   g->sync();
   g->chunk = chunk;
+  g->chunk_set = !reset;
   return BOBE_OK;
   API_END
 }

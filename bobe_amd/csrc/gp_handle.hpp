@@ -183,6 +183,7 @@ struct bobe_gp {
   bool wz_ready = false;        // W_Z = K^-1 K(X,Z) (the score GRADIENTS need it; the sweep itself does not)
   void forget_z() { z_seen_m = -1; wz_ready = false; }
   int64_t chunk = 8192;
+  bool chunk_set = false;       // bobe_gp_set_chunk was called: the caller's chunk holds for the substitution path too
 
   DBuf X, y, XsT, XsT2, A, Linv, A2, Linv2, Tmp, alpha, w, alpha2, w2, part, gpart, res, info, probs, flags, diag;
   int num_cus = 0;

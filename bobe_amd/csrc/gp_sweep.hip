@@ -127,7 +127,8 @@ void bobe_gp::sweep(const double* cand, int64_t C, const double* Z, int64_t M, d
   const bool need_s = wipstd || argmin_s || min_s;
   const double* cin = fetch(cand, (size_t)C * d, in_stage);
   if (do_wip) prepare_z(Z, M, Mp, false);
-  const int64_t CH = (refine_v && solve_chunk > 0) ? solve_chunk : chunk;   // (BOBE_SOLVE_CHUNK: speed only)
+  // (the substitution path takes wider chunks - BOBE_SOLVE_CHUNK, speed only - unless the caller has set the chunk)
+  const int64_t CH = (refine_v && solve_chunk > 0 && !chunk_set) ? solve_chunk : chunk;
   // The reference sweeps the integration points themselves (acquisition.py:394: candidates = mc_points).  Then K(X, C) and
   // V_C = L^-1 K(X, C) are what prepare_z has just made for Z: no second assembly and solve, the column sums come from V_Z in
   // the association the candidates' solve would have used (k_colsq_tile_parts: same bits as the long way).

@@ -325,7 +325,8 @@ int bobe_debug_mfma_peak(int device, int waves_per_simd, double* tflops);
  * D = 8, 16 or 32; out[j] = sum over the lanes of component j by the all-components butterfly, out[D + j] = the same by the
  * single-value sum. */
 int bobe_debug_wave_sums(int device, int D, const double* in, double* out);
-/* candidate chunk size of the sweep (multiple of 128); 0 keeps the default */
+/* candidate chunk size of the sweep (multiple of 128); 0 returns to the defaults (8192; 32 768 on the substitution path of an
+ * ill-conditioned factor) */
 int bobe_gp_set_chunk(bobe_gp_t* gp, int64_t chunk);
 /* launch shape of the blocked forward substitution (bobe_gp_set_solve_block), speed only: panel = rows per long update
  * launch (a multiple of 128), chunk = candidates per launch sequence (0: the sweep's) */
