@@ -470,6 +470,18 @@ def test_headline_config_properties(lib):
     gp2 = GP(X, 2.0 * y + 1.0, noise=1e-6, lengthscales=ls, kernel_variance=kv)   # standardisation removes scale/shift
     assert np.allclose(gp2.predict_batched(cand[:512])[0], r["mean"][:512], atol=1e-9)
     assert np.allclose(gp2.predict_mean_batched(cand[:512]), 2.0 * (r["mean"][:512] * gp.y_std + gp.y_mean) + 1.0, atol=1e-8)
+    # (6) the same sweep with v = L^-1 k SOLVED for (blocked forward substitution, the path an ill-conditioned factor takes:
+    # two chunks of 32 768 candidates, 512-row panels, 128-row diagonal blocks): on this well-conditioned factor it must give
+    # the plain product's scores to rounding, the same picks, and the oracle's triangular-solve variance on the spot check
+    gp.refine_kappa = 0.0
+    gp.recompute_cholesky()
+    assert gp.refining
+    rs = gp.wip_sweep(cand, Z, want_mean_var=True)
+    assert np.array_equal(rs["mean"], r["mean"])                                   # (the mean never goes through the solve)
+    for k in ("wipv", "wipstd"):
+        assert np.max(np.abs(rs[k] - r[k]) / np.abs(r[k])) <= 1e-11, k
+    assert rs["argmin_v"] == r["argmin_v"] and rs["argmin_s"] == r["argmin_s"]
+    assert_var_close(rs["var"][idx], np.maximum(kv + 1e-6 - np.sum(vc * vc, axis=0), 1e-12), kv + 1e-6)
 
 
 def test_negative_fantasy_pivot_floors_everything(lib):
