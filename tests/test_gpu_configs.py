@@ -12,15 +12,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_config4_full_size_eight_shards_bit_identical_to_the_unsharded_sweep():
+@pytest.mark.parametrize("kappa", [1e6, 0.0], ids=["plain_product", "substitution"])
+def test_config4_full_size_eight_shards_bit_identical_to_the_unsharded_sweep(kappa):
     """N = 4096, d = 8, 262 144 candidates: eight contiguous shards (np.array_split bounds, BOBE/pool.py:302) scored
-    separately and merged by the all-gather's rule must give the unsharded sweep's scores to the bit and its argmin."""
+    separately and merged by the all-gather's rule must give the unsharded sweep's scores to the bit and its argmin - for the
+    plain product with the inverse factor and for the blocked substitution an ill-conditioned factor takes (there the shards
+    are one chunk of 32 768 each, the unsharded sweep eight of them)."""
     from bobe_amd import GP
     from bobe_amd.dist_sweep import reduce_argmin, shard_bounds
     from bobe_amd.synthetic import synthetic_problem
     N, d, Ctot, M, G = 4096, 8, 262144, 512, 8
     X, y, cand, Z = synthetic_problem(N, d, Ctot, M, noise=1e-6)
     gp = GP(X, y, noise=1e-6, lengthscales=np.full(d, 0.6), kernel_variance=1.0)
+    gp.refine_kappa = kappa
+    gp.recompute_cholesky()
+    assert gp.refining == (kappa == 0.0)
     full = gp.wip_sweep(cand, Z, want_mean_var=True)
     mins_s, idx_s, mins_v, idx_v = [], [], [], []
     for r in range(G):
